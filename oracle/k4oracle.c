@@ -1,0 +1,771 @@
+/* oracle/k4oracle.c -- TEST INFRASTRUCTURE ONLY (see k4oracle.h).
+ *
+ * Plain-C, byte-per-base restatement of the reference CPU algorithm for the kalign hot path:
+ *   .sfx container            libkit4b/SfxArray.h:95-123,191-223, SfxArray.cpp:380-620,629-825
+ *   suffix order              libkit4b/SfxArray.cpp:9779-9834 (QSortSeqCmp32/40)
+ *   SfxOfsToLoci              libkit4b/SfxArray.cpp:49-60
+ *   MapChunkHit2Entry         libkit4b/SfxArray.cpp:2609-2654
+ *   LocateFirstExact          libkit4b/SfxArray.cpp:7938-8058
+ *   LocateCoreMultiples       libkit4b/SfxArray.cpp:5806-6369 (default, non-chimeric, base-space branch)
+ *   AlignReads                libkit4b/SfxArray.cpp:7838-7933 (phases; InDel/splice/chimeric phases are off)
+ *   CKAligner::AlignRead      ngskit4b/KAligner.cpp:9583-10105 (parameter derivation + NAR classification)
+ * It is deliberately simple and sequential per read; threads only split reads.
+ * Not restated (out of scope): bisulfite, colourspace, chimeric trimming, microInDel, splice.
+ */
+#define _GNU_SOURCE
+#include "k4oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#define K4O_HDR_SIZE 1224       /* sizeof(tsSfxHeaderV3), pack(4) */
+#define K4O_BLOCK_HDR 20        /* tsSfxBlock up to SeqSuffix[0], pack(1) */
+#define K4O_ENTRY_SIZE 111      /* sizeof(tsSfxEntry), pack(1) */
+#define K4O_MAX_IDENT_NODES 1024000 /* cMaxNumIdentNodes, SfxArray.h:15 */
+#define K4O_DFLT_MAX_ITER 50000 /* cDfltMaxIter, SfxArray.h:12 */
+
+struct k4o_index {
+  uint64_t n;  /* ConcatSeqLen: bases + one EOS per entry == number of SA elements */
+  uint32_t el; /* SfxElSize 4|5 */
+  uint8_t* seq;
+  uint8_t* sa;
+  uint32_t n_entries;
+  k4o_entry* entries;
+  char dataset[81];
+  int max_iter;
+  void* map; /* non-NULL when seq/sa point into an mmap of the file */
+  size_t map_len;
+  int owns;  /* seq/sa malloc'd by us */
+};
+
+/* ------------------------------------------------------------------------------------------------ */
+static uint64_t rd_u64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static uint32_t rd_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint16_t rd_u16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+/* SfxOfsToLoci, SfxArray.cpp:49-60 */
+int64_t k4o_sa_at(const k4o_index* ix, int64_t i) {
+  const uint8_t* p = ix->sa + (uint64_t)i * ix->el;
+  uint64_t v = rd_u32(p);
+  if (ix->el == 5) v |= (uint64_t)p[4] << 32;
+  return (int64_t)v;
+}
+
+static void sa_put(uint8_t* sa, uint32_t el, uint64_t i, uint64_t v) {
+  uint8_t* p = sa + i * el;
+  uint32_t lo = (uint32_t)v;
+  memcpy(p, &lo, 4);
+  if (el == 5) p[4] = (uint8_t)(v >> 32);
+}
+
+uint64_t k4o_concat_len(const k4o_index* ix) { return ix->n; }
+uint32_t k4o_el_size(const k4o_index* ix) { return ix->el; }
+const uint8_t* k4o_seq(const k4o_index* ix) { return ix->seq; }
+const uint8_t* k4o_sa_bytes(const k4o_index* ix) { return ix->sa; }
+uint32_t k4o_num_entries(const k4o_index* ix) { return ix->n_entries; }
+const k4o_entry* k4o_entries(const k4o_index* ix) { return ix->entries; }
+void k4o_set_max_iter(k4o_index* ix, int max_iter) { ix->max_iter = max_iter > 0 ? max_iter : 0; }
+
+uint64_t k4o_tot_seqs_len(const k4o_index* ix) {
+  uint64_t t = 0;
+  for (uint32_t i = 0; i < ix->n_entries; i++) t += ix->entries[i].seq_len;
+  return t;
+}
+
+/* CUtility::GenHash16, libkit4b/Utility.cpp:402-420 */
+static uint16_t gen_hash16(const char* name) {
+  int h = 19937;
+  if (!name || !name[0]) return 0;
+  for (; *name; name++) {
+    h = (h ^ (int)tolower((unsigned char)*name)) * 3119;
+    h ^= (h >> 13);
+    h &= 0xffff;
+  }
+  if (h == 0) h = 19937;
+  return (uint16_t)h;
+}
+
+/* ---- .sfx reader: Disk2Hdr :629, Disk2Entries :714, Disk2SfxBlock :1915 ------------------------- */
+k4o_index* k4o_open(const char* path, char* err, size_t errlen) {
+#define FAIL(...) do { if (err) snprintf(err, errlen, __VA_ARGS__); if (map && map != MAP_FAILED) munmap(map, len); if (fd >= 0) close(fd); free(ix); return NULL; } while (0)
+  k4o_index* ix = NULL;
+  void* map = NULL;
+  size_t len = 0;
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) FAIL("unable to open %s", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0) FAIL("unable to stat %s", path);
+  len = (size_t)st.st_size;
+  if (len < K4O_HDR_SIZE) FAIL("%s too short for a .sfx header", path);
+  map = mmap(NULL, len, PROT_READ, MAP_PRIVATE, fd, 0);
+  if (map == MAP_FAILED) FAIL("mmap failed on %s", path);
+  const uint8_t* f = (const uint8_t*)map;
+  if (tolower(f[0]) != 's' || tolower(f[1]) != 'f' || tolower(f[2]) != 'x' || f[3] < '3' || f[3] > '5')
+    FAIL("%s: bad magic, not a kit4b suffix array file", path);
+  uint32_t ver = rd_u32(f + 4);
+  if (ver < 4 || ver > 5) FAIL("%s: structure version %u not supported by the oracle (4..5)", path, ver);
+  uint32_t attr = rd_u32(f + 8);
+  if (attr & 3) FAIL("%s: bisulfite/colourspace indexes are out of scope", path);
+  uint64_t entries_ofs = rd_u64(f + 20);
+  uint32_t entries_size = rd_u32(f + 28);
+  uint32_t n_blocks = rd_u32(f + 32);
+  uint64_t block_ofs = rd_u64(f + 44);
+  if (n_blocks != 1) FAIL("%s: NumSfxBlocks=%u (expected 1)", path, n_blocks);
+  if (block_ofs + K4O_BLOCK_HDR > len) FAIL("%s: block offset beyond file", path);
+  ix = (k4o_index*)calloc(1, sizeof(*ix));
+  memcpy(ix->dataset, f + 52, 80);
+  const uint8_t* b = f + block_ofs;
+  ix->n = rd_u64(b + 8);
+  ix->el = rd_u32(b + 16);
+  if (ix->el != 4 && ix->el != 5) FAIL("%s: SfxElSize %u", path, ix->el);
+  if (block_ofs + K4O_BLOCK_HDR + ix->n + ix->n * ix->el > len) FAIL("%s: block truncated", path);
+  ix->seq = (uint8_t*)(b + K4O_BLOCK_HDR);
+  ix->sa = (uint8_t*)(b + K4O_BLOCK_HDR + ix->n);
+  if (entries_ofs == 0 || entries_ofs + entries_size > len || entries_size < 8) FAIL("%s: bad entries block", path);
+  const uint8_t* e = f + entries_ofs;
+  ix->n_entries = rd_u32(e);
+  if (8 + (uint64_t)ix->n_entries * K4O_ENTRY_SIZE > entries_size) FAIL("%s: entries block truncated", path);
+  ix->entries = (k4o_entry*)calloc(ix->n_entries ? ix->n_entries : 1, sizeof(k4o_entry));
+  for (uint32_t i = 0; i < ix->n_entries; i++) {
+    const uint8_t* p = e + 8 + (size_t)i * K4O_ENTRY_SIZE;
+    k4o_entry* d = &ix->entries[i];
+    d->entry_id = rd_u32(p);
+    d->fblock_id = rd_u32(p + 4);
+    memcpy(d->name, p + 8, 81);
+    d->name[80] = 0;
+    d->name_hash = rd_u16(p + 89);
+    d->seq_len = rd_u32(p + 91);
+    d->start_ofs = rd_u64(p + 95);
+    d->end_ofs = rd_u64(p + 103);
+  }
+  ix->max_iter = K4O_DFLT_MAX_ITER;
+  ix->map = map;
+  ix->map_len = len;
+  close(fd);
+  return ix;
+#undef FAIL
+}
+
+void k4o_close(k4o_index* ix) {
+  if (!ix) return;
+  if (ix->map) munmap(ix->map, ix->map_len);
+  if (ix->owns) { free(ix->seq); free(ix->sa); }
+  free(ix->entries);
+  free(ix);
+}
+
+k4o_index* k4o_from_parts(uint64_t n, uint32_t el, uint8_t* seq, uint8_t* sa, uint32_t n_entries,
+                          const k4o_entry* entries, const char* dataset) {
+  k4o_index* ix = (k4o_index*)calloc(1, sizeof(*ix));
+  ix->n = n; ix->el = el; ix->seq = seq; ix->sa = sa; ix->n_entries = n_entries;
+  ix->entries = (k4o_entry*)calloc(n_entries ? n_entries : 1, sizeof(k4o_entry));
+  memcpy(ix->entries, entries, sizeof(k4o_entry) * n_entries);
+  if (dataset) strncpy(ix->dataset, dataset, 80);
+  ix->max_iter = K4O_DFLT_MAX_ITER;
+  return ix;
+}
+
+/* ---- suffix sort: order of QSortSeqCmp32/40, SfxArray.cpp:9779-9834 ------------------------------
+ * bytewise on the low nibble, A<C<G<T<N<EOS(7); stops after the first EOS (both reach it together => equal).
+ * The reference's parallel quicksort leaves tied suffixes in arbitrary order; we break ties by offset. */
+static const uint8_t* g_sort_seq; /* set before sorting; sort workers only read it */
+
+static int sfx_cmp(uint64_t a, uint64_t b) {
+  const uint8_t* p = g_sort_seq + a;
+  const uint8_t* q = g_sort_seq + b;
+  for (;;) {
+    uint8_t x = *p++ & 0x0f, y = *q++ & 0x0f;
+    if (x != y) return x < y ? -1 : 1;
+    if (x == K4O_EOS) break;
+  }
+  return a < b ? -1 : (a > b ? 1 : 0);
+}
+static int cmp_u64_sfx(const void* a, const void* b) { return sfx_cmp(*(const uint64_t*)a, *(const uint64_t*)b); }
+
+typedef struct { uint64_t* idx; uint64_t* bstart; int nb; int next; pthread_mutex_t mtx; } sort_job;
+
+static void* sort_worker(void* arg) {
+  sort_job* j = (sort_job*)arg;
+  for (;;) {
+    pthread_mutex_lock(&j->mtx);
+    int b = j->next++;
+    pthread_mutex_unlock(&j->mtx);
+    if (b >= j->nb) break;
+    uint64_t cnt = j->bstart[b + 1] - j->bstart[b];
+    if (cnt > 1) qsort(j->idx + j->bstart[b], cnt, sizeof(uint64_t), cmp_u64_sfx);
+  }
+  return NULL;
+}
+
+static uint32_t bucket_key(const uint8_t* s) { /* first 3 symbols, constant after an EOS */
+  uint32_t k = 0;
+  int eos = 0;
+  for (int i = 0; i < 3; i++) {
+    uint32_t c = eos ? 0 : (uint32_t)(s[i] & 0x0f);
+    if (c == K4O_EOS) eos = 1;
+    k = (k << 3) | (c & 7);
+  }
+  return k;
+}
+
+/* AddEntry :1518-1753 + Finalise/QSortSeq :1758,9739 */
+k4o_index* k4o_build(int nseq, const char* const* names, const uint8_t* const* seqs, const uint32_t* lens,
+                     const char* dataset, int force_el, int nthreads) {
+  uint64_t n = 0;
+  for (int i = 0; i < nseq; i++) n += (uint64_t)lens[i] + 1;
+  k4o_index* ix = (k4o_index*)calloc(1, sizeof(*ix));
+  ix->n = n;
+  ix->el = force_el ? (uint32_t)force_el : (n < 4000000000ULL ? 4 : 5); /* cThres8ByteSfxEls, SfxArray.cpp:906-909 */
+  ix->seq = (uint8_t*)malloc(n + 16);
+  memset(ix->seq + n, K4O_EOS, 16); /* slack so bucket_key may read 2 bytes past the final EOS */
+  ix->sa = (uint8_t*)malloc(n * ix->el + 8);
+  ix->owns = 1;
+  ix->n_entries = (uint32_t)nseq;
+  ix->entries = (k4o_entry*)calloc(nseq ? nseq : 1, sizeof(k4o_entry));
+  ix->max_iter = K4O_DFLT_MAX_ITER;
+  if (dataset) strncpy(ix->dataset, dataset, 80);
+  uint64_t ofs = 0;
+  for (int i = 0; i < nseq; i++) {
+    k4o_entry* e = &ix->entries[i];
+    e->entry_id = (uint32_t)i + 1;
+    e->fblock_id = 1;
+    strncpy(e->name, names[i], 80);
+    e->name_hash = gen_hash16(names[i]);
+    e->seq_len = lens[i];
+    e->start_ofs = ofs;
+    e->end_ofs = ofs + lens[i] - 1;
+    for (uint32_t k = 0; k < lens[i]; k++) ix->seq[ofs + k] = seqs[i][k] & ~0x08; /* strip cRptMskFlg */
+    ix->seq[ofs + lens[i]] = K4O_EOS;
+    ofs += (uint64_t)lens[i] + 1;
+  }
+  /* bucket by the first 3 symbols, then comparison-sort each bucket */
+  enum { NB = 512 };
+  uint64_t* bstart = (uint64_t*)calloc(NB + 1, sizeof(uint64_t));
+  uint64_t* idx = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
+  for (uint64_t i = 0; i < n; i++) bstart[bucket_key(ix->seq + i) + 1]++;
+  for (int b = 0; b < NB; b++) bstart[b + 1] += bstart[b];
+  uint64_t* fill = (uint64_t*)malloc(sizeof(uint64_t) * NB);
+  memcpy(fill, bstart, sizeof(uint64_t) * NB);
+  for (uint64_t i = 0; i < n; i++) idx[fill[bucket_key(ix->seq + i)]++] = i;
+  free(fill);
+  g_sort_seq = ix->seq;
+  sort_job job = { idx, bstart, NB, 0, PTHREAD_MUTEX_INITIALIZER };
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 64) nthreads = 64;
+  pthread_t th[64];
+  for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, sort_worker, &job);
+  for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  for (uint64_t i = 0; i < n; i++) sa_put(ix->sa, ix->el, i, idx[i]);
+  free(idx);
+  free(bstart);
+  return ix;
+}
+
+/* ---- .sfx writer: Hdr2Disk :380, SfxBlock2Disk :499, Entries2Disk :583 --------------------------- */
+int k4o_write(const k4o_index* ix, const char* path) {
+  FILE* fp = fopen(path, "wb");
+  if (!fp) return -1;
+  uint8_t hdr[K4O_HDR_SIZE];
+  memset(hdr, 0, sizeof(hdr));
+  memcpy(hdr, "sfx5", 4);
+  uint32_t ver = 5, attr = 0, nblocks = 1;
+  uint64_t block_ofs = K4O_HDR_SIZE;
+  uint64_t block_size = K4O_BLOCK_HDR + ix->n + ix->n * ix->el;
+  uint64_t entries_ofs = block_ofs + block_size;
+  uint32_t entries_size = 8 + K4O_ENTRY_SIZE * ix->n_entries;
+  uint64_t file_len = entries_ofs + entries_size;
+  memcpy(hdr + 4, &ver, 4);
+  memcpy(hdr + 8, &attr, 4);
+  memcpy(hdr + 12, &file_len, 8);
+  memcpy(hdr + 20, &entries_ofs, 8);
+  memcpy(hdr + 28, &entries_size, 4);
+  memcpy(hdr + 32, &nblocks, 4);
+  memcpy(hdr + 36, &block_size, 8);
+  memcpy(hdr + 44, &block_ofs, 8);
+  strncpy((char*)hdr + 52, ix->dataset, 80);
+  strncpy((char*)hdr + 133, "k4oracle", 1023);
+  strncpy((char*)hdr + 1157, "k4oracle", 63);
+  fwrite(hdr, 1, sizeof(hdr), fp);
+  uint8_t bh[K4O_BLOCK_HDR];
+  uint32_t bid = 1;
+  memcpy(bh, &bid, 4);
+  memcpy(bh + 4, &ix->n_entries, 4);
+  memcpy(bh + 8, &ix->n, 8);
+  memcpy(bh + 16, &ix->el, 4);
+  fwrite(bh, 1, sizeof(bh), fp);
+  fwrite(ix->seq, 1, ix->n, fp);
+  fwrite(ix->sa, 1, ix->n * ix->el, fp);
+  uint32_t ne[2] = { ix->n_entries, ix->n_entries };
+  fwrite(ne, 4, 2, fp);
+  for (uint32_t i = 0; i < ix->n_entries; i++) {
+    uint8_t e[K4O_ENTRY_SIZE];
+    const k4o_entry* s = &ix->entries[i];
+    memset(e, 0, sizeof(e));
+    memcpy(e, &s->entry_id, 4);
+    memcpy(e + 4, &s->fblock_id, 4);
+    strncpy((char*)e + 8, s->name, 80);
+    memcpy(e + 89, &s->name_hash, 2);
+    memcpy(e + 91, &s->seq_len, 4);
+    memcpy(e + 95, &s->start_ofs, 8);
+    memcpy(e + 103, &s->end_ofs, 8);
+    fwrite(e, 1, sizeof(e), fp);
+  }
+  int bad = ferror(fp);
+  fclose(fp);
+  return bad ? -1 : 0;
+}
+
+/* ---- MapChunkHit2Entry, SfxArray.cpp:2609-2654 ---------------------------------------------------- */
+static const k4o_entry* map_chunk_hit2entry(const k4o_index* ix, uint64_t ofs) {
+  int64_t lo = 0, hi = (int64_t)ix->n_entries - 1;
+  while (hi >= lo) {
+    int64_t mid = (hi + lo) / 2;
+    const k4o_entry* e = &ix->entries[mid];
+    uint32_t blk = e->fblock_id & 0xff;
+    if (blk > 1) { hi = mid - 1; continue; }
+    if (blk < 1) { lo = mid + 1; continue; }
+    if (e->start_ofs <= ofs && e->end_ofs >= ofs) return e;
+    if (e->start_ofs > ofs) hi = mid - 1;
+    else lo = mid + 1;
+  }
+  return NULL; /* ofs sits on an EOS separator */
+}
+
+/* ---- ReverseComplement, SeqTrans.cpp:497-545 (N/InDel/Undef stay; anything else stops complementing) */
+void k4o_revcomp(uint8_t* s, int len) {
+  if (len < 1) return;
+  for (int i = 0; i < len; i++) {
+    uint8_t b = s[i], flg = b & 0x18;
+    b &= ~0x18;
+    if (b <= K4O_T) s[i] = (uint8_t)((3 - b) | flg);
+    else if (b == K4O_N || b == 5 || b == 6) continue;
+    else break;
+  }
+  for (int i = 0, j = len - 1; i < j; i++, j--) { uint8_t t = s[i]; s[i] = s[j]; s[j] = t; }
+}
+
+/* probe vs suffix over len bases: target EOS => probe < target.  CmpProbeTarg, SfxArray.cpp:2508-2525 */
+static int cmp_probe_targ(const uint8_t* probe, const uint8_t* targ, int len) {
+  for (int i = 0; i < len; i++) {
+    uint8_t t = targ[i] & 0x0f;
+    if (t == K4O_EOS) return -1;
+    uint8_t p = probe[i] & 0x0f;
+    if (p > t) return 1;
+    if (p < t) return -1;
+  }
+  return 0;
+}
+
+/* ---- LocateFirstExact, SfxArray.cpp:7938-8058: returns index+1 of the lowest matching suffix, 0 if none.
+ * (The k-mer memo fast path :7959-7964 returns the same value by construction, :8123-8224.) */
+int64_t k4o_locate_first_exact(const k4o_index* ix, const uint8_t* probe, int probe_len, int64_t lo, int64_t hi,
+                               k4o_counters* ctr) {
+  if (ctr) ctr->n_lookup++;
+  do {
+    int64_t mid = (lo + hi) / 2;
+    int c = cmp_probe_targ(probe, ix->seq + k4o_sa_at(ix, mid), probe_len);
+    if (ctr) ctr->n_probe++;
+    if (c == 0) {
+      if (mid == 0 || lo == mid) return mid + 1;
+      int64_t mark = mid;
+      for (;;) { /* narrow to the lowest matching index */
+        if (c == 0) {
+          mark = mid;
+          if (mark == 0) return 1;
+          hi = mid - 1;
+        }
+        mid = (lo + hi) / 2;
+        c = cmp_probe_targ(probe, ix->seq + k4o_sa_at(ix, mid), probe_len);
+        if (ctr) ctr->n_probe++;
+        if (c == 0) continue;
+        lo = mid + 1;
+        if (lo == mark) return mark + 1;
+      }
+    }
+    if (c < 0) {
+      if (mid == 0) break;
+      hi = mid - 1;
+    } else
+      lo = mid + 1;
+  } while (hi >= lo);
+  return 0;
+}
+
+/* ---- dedupe set for TargSeqIDs: per strand pass, SfxArray.cpp:5845,5946,6037-6055 ---------------- */
+typedef struct { uint64_t* slot; uint32_t cap; uint32_t* used; uint32_t n_used; } idset; /* slot = id+1, 0 = empty */
+static void idset_init(idset* s) {
+  s->cap = 1u << 12;
+  s->slot = (uint64_t*)calloc(s->cap, sizeof(uint64_t));
+  s->used = (uint32_t*)malloc(sizeof(uint32_t) * s->cap);
+  s->n_used = 0;
+}
+static void idset_clear(idset* s) {
+  for (uint32_t i = 0; i < s->n_used; i++) s->slot[s->used[i]] = 0;
+  s->n_used = 0;
+}
+static void idset_free(idset* s) { free(s->slot); free(s->used); }
+static int idset_insert(idset* s, uint32_t id) { /* 1 if new */
+  if (s->n_used * 2 >= s->cap) { /* grow */
+    uint32_t ncap = s->cap * 2;
+    uint64_t* nslot = (uint64_t*)calloc(ncap, sizeof(uint64_t));
+    uint32_t* nused = (uint32_t*)malloc(sizeof(uint32_t) * ncap);
+    uint32_t nn = 0;
+    for (uint32_t i = 0; i < s->n_used; i++) {
+      uint64_t v = s->slot[s->used[i]];
+      uint32_t h = ((uint32_t)v * 2654435761u) & (ncap - 1);
+      while (nslot[h]) h = (h + 1) & (ncap - 1);
+      nslot[h] = v;
+      nused[nn++] = h;
+    }
+    free(s->slot); free(s->used);
+    s->slot = nslot; s->used = nused; s->cap = ncap; s->n_used = nn;
+  }
+  uint64_t v = (uint64_t)id + 1;
+  uint32_t h = ((uint32_t)v * 2654435761u) & (s->cap - 1);
+  while (s->slot[h]) {
+    if (s->slot[h] == v) return 0;
+    h = (h + 1) & (s->cap - 1);
+  }
+  s->slot[h] = v;
+  s->used[s->n_used++] = h;
+  return 1;
+}
+
+static void store_hit(k4o_hit* h, const k4o_entry* e, int64_t left, char strand, int probe_len, int mm) {
+  memset(h, 0, sizeof(*h));
+  h->chrom_id = e->entry_id;
+  h->match_loci = (uint32_t)((uint64_t)left - e->start_ofs);
+  h->match_len = (uint16_t)probe_len;
+  h->strand = (uint8_t)strand;
+  h->mismatches = (uint8_t)mm;
+}
+
+/* ---- LocateCoreMultiples, SfxArray.cpp:5806-6369 (MinChimericLen == 0 branch) --------------------- */
+int k4o_locate_core_multiples(const k4o_index* ix, int max_tot_mm, int core_len, int core_delta, int max_slides,
+                              int mm_delta, int strand, int* p_inst, int* p_low, int* p_nxt, uint8_t* probe,
+                              int probe_len, int max_hits, k4o_hit* hits, k4o_counters* ctr) {
+  if (ix->n == 0) return -1;
+  /* :5889-5895 carried-in state that cannot improve */
+  if (*p_inst > max_hits && *p_low == 0) return K4O_HR_HITINSTS;
+  if (*p_inst >= 1 && *p_low == 0 && (*p_nxt - *p_low) < mm_delta) return K4O_HR_MMDELTA;
+
+  int inst, low, nxt;
+  if (*p_inst <= 0 || *p_low < 0 || *p_nxt < 0) { /* :5902-5907 */
+    inst = *p_inst = 0;
+    low = *p_low = max_tot_mm + mm_delta + 1;
+    nxt = *p_nxt = low;
+  } else {
+    inst = *p_inst; low = *p_low; nxt = *p_nxt;
+  }
+  int cur_hit = inst < max_hits ? inst : -1; /* pCurHit, :5915-5918 */
+  const int max_iter = ix->max_iter;
+  const int64_t n = (int64_t)ix->n;
+  char cur_strand = '+';
+  if (strand == K4O_STRAND_CRICK) { k4o_revcomp(probe, probe_len); cur_strand = '-'; }
+  idset ids;
+  idset_init(&ids);
+
+  do {
+    int cur_delta = core_delta;
+    int slides = 0;
+    uint32_t n_nodes = 0;
+    idset_clear(&ids);
+    for (int ofs = 0; slides < max_slides && ofs <= probe_len - core_len && cur_delta > core_len / 3 &&
+                      n_nodes < K4O_MAX_IDENT_NODES;
+         slides++, ofs += cur_delta) {
+      if (ofs + core_len + cur_delta > probe_len) cur_delta = probe_len - (ofs + core_len); /* :5956 */
+      int64_t t = k4o_locate_first_exact(ix, probe + ofs, core_len, 0, n - 1, ctr);
+      if (t == 0) continue;
+      t -= 1;
+      int iter = 0, first = 1;
+      while (!max_iter || iter < max_iter) {
+        if (n_nodes >= K4O_MAX_IDENT_NODES) break;
+        if (!first) { /* :5978-6019 step to the next suffix while it still starts with the core */
+          if (t + 1 >= n || k4o_sa_at(ix, t + 1) + core_len > n) break;
+          if (cmp_probe_targ(probe + ofs, ix->seq + k4o_sa_at(ix, t + 1), core_len) != 0) break;
+          t += 1;
+        }
+        first = 0;
+        int64_t pos = k4o_sa_at(ix, t);
+        if (pos < (int64_t)(uint32_t)ofs) continue; /* :6023 */
+        int64_t left = pos - ofs;
+        const k4o_entry* e = map_chunk_hit2entry(ix, (uint64_t)left);
+        if (e == NULL || (uint64_t)left + (uint32_t)probe_len - 1 > e->end_ofs) continue; /* :6033 */
+        uint32_t targ_id = (uint32_t)(1 + pos - (uint32_t)ofs); /* :6037, truncation is deliberate (Q7) */
+        if (!idset_insert(&ids, targ_id)) continue;
+        n_nodes++;
+        iter++;
+        /* :6190-6261 full-read Hamming extension with the two early-outs */
+        if (ctr) ctr->n_cand++;
+        const uint8_t* tb = ix->seq + left;
+        int mm = 0, i;
+        for (i = 0; i < probe_len; i++) {
+          uint8_t tv = tb[i] & 0x0f, pv = probe[i] & 0x0f;
+          if (tv == K4O_EOS) break;
+          if (pv == tv) continue;
+          if (++mm > max_tot_mm) break;
+          if (mm >= nxt) break;
+        }
+        if (i != probe_len) continue;
+        if (mm < low) { /* :6264-6284 new best */
+          cur_hit = 0;
+          inst = 1;
+          nxt = low;
+          low = mm;
+          store_hit(&hits[0], e, left, cur_strand, probe_len, mm);
+        } else if (mm == low) { /* :6286-6306 another instance of the best */
+          inst += 1;
+          if (cur_hit != -1 && inst <= max_hits) {
+            cur_hit += 1;
+            if (cur_hit < max_hits) store_hit(&hits[cur_hit], e, left, cur_strand, probe_len, mm);
+          }
+        } else if (mm < nxt) /* :6308-6311 */
+          nxt = mm;
+        if (inst > max_hits && low == 0) break; /* :6313 */
+      }
+      if (inst > max_hits && low == 0) { strand = 3; break; } /* :6316-6320 eALSnone */
+    }
+    if (cur_strand == '+' && strand == K4O_STRAND_BOTH) { /* :6323-6334 */
+      k4o_revcomp(probe, probe_len);
+      cur_strand = '-';
+      strand = K4O_STRAND_CRICK;
+    } else
+      strand = 3;
+  } while (!(inst > max_hits && low == 0) && strand != 3);
+  idset_free(&ids);
+  if (cur_strand == '-') k4o_revcomp(probe, probe_len); /* :6338-6342 restore */
+
+  /* :6345-6368 */
+  if (*p_low == low && *p_inst == inst) {
+    if (*p_nxt > nxt) {
+      *p_nxt = nxt;
+      if (nxt - *p_low < mm_delta) return K4O_HR_MMDELTA;
+      return K4O_HR_RMMDELTA;
+    }
+    return K4O_HR_NONE;
+  }
+  *p_low = low; *p_inst = inst; *p_nxt = nxt;
+  if (inst >= 1 && (nxt - low) < mm_delta) return K4O_HR_MMDELTA;
+  if (inst > max_hits) return K4O_HR_HITINSTS;
+  return K4O_HR_HITS;
+}
+
+/* ---- AlignReads, SfxArray.cpp:7838-7933 (microInDelLen = MaxSpliceJunctLen = MinChimericLen = 0) -- */
+int k4o_align_reads(const k4o_index* ix, int tot_mm, int core_len, int core_delta, int max_slides, int min_core_len,
+                    int mm_delta, int strand, int* inst, int* low, int* nxt, uint8_t* probe, int probe_len,
+                    int max_hits, k4o_hit* hits, k4o_counters* ctr) {
+  (void)min_core_len; /* only used by the chimeric phase */
+  int rslt = 0, allow = 0;
+  if (tot_mm > 0) {
+    for (allow = 0; allow <= tot_mm; allow++) {
+      int cl = probe_len / (allow + mm_delta);
+      if (cl <= core_len) break;
+      rslt = k4o_locate_core_multiples(ix, allow, cl, cl, max_slides, mm_delta, strand, inst, low, nxt, probe,
+                                       probe_len, max_hits, hits, ctr);
+      if (rslt != 0) return rslt;
+    }
+  }
+  if (allow <= tot_mm) {
+    rslt = k4o_locate_core_multiples(ix, tot_mm, core_len, core_delta, max_slides, mm_delta, strand, inst, low, nxt,
+                                     probe, probe_len, max_hits, hits, ctr);
+    if (rslt != 0) return rslt;
+  }
+  return 0;
+}
+
+/* ---- CKAligner::LocateCoredApprox parameter derivation, KAligner.cpp:9367-9393 -------------------- */
+int k4o_min_core_len(const k4o_index* ix, int pmode, int* max_num_slides) {
+  uint64_t tot = k4o_tot_seqs_len(ix);
+  int autolen = 1;
+  while (tot >>= 2) autolen++;
+  autolen -= 1;
+  int mcl = autolen > 4 ? autolen : 4; /* cKAMinCoreLen, KAligner.h:39 */
+  int slides;
+  switch (pmode) {
+    case 2: mcl -= 2; slides = 9; break; /* ePMUltraSens */
+    case 1: mcl -= 1; slides = 8; break; /* ePMMoreSens */
+    case 0: slides = 8; break;           /* ePMdefault */
+    default: mcl += 2; slides = 6; break;
+  }
+  if (max_num_slides) *max_num_slides = slides;
+  return mcl;
+}
+
+/* KAligner.cpp:9662-9672 */
+void k4o_read_params(const k4o_kalign_params* kp, int min_core_len, int slides_per100, int read_len, int* max_tot_mm,
+                     int* core_len, int* core_delta, int* max_slides) {
+  int mm = kp->max_subs == 0 ? 0 : (int)(0.5 + (read_len * kp->max_subs) / 100.0);
+  if (kp->max_subs != 0 && mm < 1) mm = 1;
+  if (mm > 63) mm = 63; /* cMaxTotAllowedSubs */
+  int cl = read_len / (kp->min_edit_dist == 1 ? mm + 1 : mm + 2);
+  if (cl < min_core_len) cl = min_core_len;
+  int sl = (slides_per100 * read_len + 99) / 100;
+  if (sl < 1) sl = 1;
+  int cd = read_len / sl - 1;
+  if (cd < cl) cd = cl;
+  *max_tot_mm = mm; *core_len = cl; *core_delta = cd; *max_slides = sl;
+}
+
+/* ---- CKAligner::AlignRead, KAligner.cpp:9583-10105 (base space, no priority regions, MLMode default) */
+static int align_read_with(const k4o_index* ix, const k4o_kalign_params* kp, int min_core_len, int slides_per100,
+                           const uint8_t* read, int read_len, uint8_t* scratch, k4o_read_result* out, k4o_hit* hits,
+                           k4o_counters* ctr) {
+  memset(out, 0, sizeof(*out));
+  out->nar = K4O_NAR_NOHIT;
+  /* :9618-9640 unpack, count Ns */
+  int max_ns_seq = 0, ns = 0, i;
+  if (kp->max_ns) {
+    max_ns_seq = (read_len * kp->max_ns) / 100;
+    if (max_ns_seq < kp->max_ns) max_ns_seq = kp->max_ns;
+  }
+  for (i = 0; i < read_len; i++) {
+    uint8_t b = read[i] & 0x07;
+    scratch[i] = b;
+    if (b > K4O_N) break;
+    if (b == K4O_N && ++ns > max_ns_seq) break;
+  }
+  if (i != read_len) {
+    out->nar = K4O_NAR_NS;
+    out->hit_rslt = K4O_HR_SEQERRS;
+    return K4O_HR_SEQERRS;
+  }
+  int tot_mm, core_len, core_delta, slides;
+  k4o_read_params(kp, min_core_len, slides_per100, read_len, &tot_mm, &core_len, &core_delta, &slides);
+  int inst = 0, low = 0, nxt = 0;
+  int max_ml = kp->max_ml < 1 ? 1 : kp->max_ml;
+  memset(hits, 0, sizeof(k4o_hit) * (size_t)max_ml);
+  int r = k4o_align_reads(ix, tot_mm, core_len, core_delta, slides, min_core_len, kp->min_edit_dist, kp->strand, &inst,
+                          &low, &nxt, scratch, read_len, max_ml, hits, ctr);
+  if (inst > max_ml) inst = max_ml + 1; /* :9854 */
+  out->hit_rslt = r;
+  out->inst = inst; out->low_mm = low; out->nxt_mm = nxt;
+  switch (r) {
+    case K4O_HR_NONE: /* :9891-9905 */
+      out->nar = K4O_NAR_NOHIT; out->low_mm = 0; out->inst = 0; out->nxt_mm = 0; /* tsReadHit fields as AlignRead leaves them */
+      break;
+    case K4O_HR_HITS: /* :9907-10025 */
+      if (!kp->pe_mode || inst == 1) { out->nar = K4O_NAR_ACCEPTED; out->num_hits = 1; }
+      else { out->nar = K4O_NAR_MULTIALIGN; out->num_hits = inst; }
+      break;
+    case K4O_HR_MMDELTA: out->nar = K4O_NAR_MMDELTA; break;        /* :10027-10039 */
+    case K4O_HR_HITINSTS: out->nar = K4O_NAR_MULTIALIGN; break;    /* :10041-10051,10068-10079 */
+    default: break;                                                 /* eHRRMMDelta: NAR stays NL */
+  }
+  return r;
+}
+
+int k4o_align_read(const k4o_index* ix, const k4o_kalign_params* kp, const uint8_t* read, int read_len,
+                   k4o_read_result* out, k4o_hit* hits, k4o_counters* ctr) {
+  int spm = kp->max_num_slides;
+  int mcl = kp->min_core_len;
+  if (mcl <= 0 || spm <= 0) {
+    int s2;
+    int m2 = k4o_min_core_len(ix, kp->pmode, &s2);
+    if (mcl <= 0) mcl = m2;
+    if (spm <= 0) spm = s2;
+  }
+  uint8_t* scratch = (uint8_t*)malloc((size_t)read_len + 8);
+  int r = align_read_with(ix, kp, mcl, spm, read, read_len, scratch, out, hits, ctr);
+  free(scratch);
+  return r;
+}
+
+/* ---- batches over pthreads (reads are independent; KAligner.cpp:10110-10263,10370-10438) ---------- */
+typedef struct {
+  const k4o_index* ix;
+  const k4o_kalign_params* kp;
+  int mcl, spm;
+  int64_t n;
+  const uint8_t* reads; const uint64_t* offs; const uint32_t* lens;
+  k4o_read_result* out; k4o_hit* hits;
+  /* raw mode */
+  int raw, tot_mm, core_len, core_delta, slides, mm_delta, strand, max_hits;
+  int32_t *rslt, *inst, *low, *nxt;
+  int64_t next; pthread_mutex_t mtx;
+  k4o_counters ctr;
+} batch_job;
+
+static void* batch_worker(void* arg) {
+  batch_job* j = (batch_job*)arg;
+  k4o_counters c = { 0, 0, 0 };
+  uint8_t* scratch = (uint8_t*)malloc(1 << 16);
+  const int64_t chunk = 256;
+  for (;;) {
+    pthread_mutex_lock(&j->mtx);
+    int64_t b = j->next;
+    j->next += chunk;
+    pthread_mutex_unlock(&j->mtx);
+    if (b >= j->n) break;
+    int64_t e = b + chunk < j->n ? b + chunk : j->n;
+    for (int64_t i = b; i < e; i++) {
+      const uint8_t* rd = j->reads + j->offs[i];
+      int len = (int)j->lens[i];
+      if (j->raw) {
+        int mh = j->max_hits;
+        k4o_hit* h = j->hits + (size_t)i * mh;
+        memset(h, 0, sizeof(k4o_hit) * (size_t)mh);
+        memcpy(scratch, rd, (size_t)len);
+        int in = 0, lo = 0, nx = 0;
+        j->rslt[i] = k4o_align_reads(j->ix, j->tot_mm, j->core_len, j->core_delta, j->slides, 0, j->mm_delta,
+                                     j->strand, &in, &lo, &nx, scratch, len, mh, h, &c);
+        j->inst[i] = in; j->low[i] = lo; j->nxt[i] = nx;
+      } else {
+        int mh = j->kp->max_ml < 1 ? 1 : j->kp->max_ml;
+        align_read_with(j->ix, j->kp, j->mcl, j->spm, rd, len, scratch, &j->out[i], j->hits + (size_t)i * mh, &c);
+      }
+    }
+  }
+  free(scratch);
+  pthread_mutex_lock(&j->mtx);
+  j->ctr.n_lookup += c.n_lookup; j->ctr.n_probe += c.n_probe; j->ctr.n_cand += c.n_cand;
+  pthread_mutex_unlock(&j->mtx);
+  return NULL;
+}
+
+static void run_batch(batch_job* j, int nthreads, k4o_counters* ctr) {
+  pthread_mutex_init(&j->mtx, NULL);
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  pthread_t th[256];
+  for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, batch_worker, j);
+  for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  pthread_mutex_destroy(&j->mtx);
+  if (ctr) *ctr = j->ctr;
+}
+
+int k4o_align_batch(const k4o_index* ix, const k4o_kalign_params* kp, int64_t n_reads, const uint8_t* reads,
+                    const uint64_t* offs, const uint32_t* lens, k4o_read_result* out, k4o_hit* hits, int nthreads,
+                    k4o_counters* ctr) {
+  batch_job j;
+  memset(&j, 0, sizeof(j));
+  j.ix = ix; j.kp = kp; j.n = n_reads; j.reads = reads; j.offs = offs; j.lens = lens; j.out = out; j.hits = hits;
+  j.mcl = kp->min_core_len; j.spm = kp->max_num_slides;
+  if (j.mcl <= 0 || j.spm <= 0) {
+    int s2, m2 = k4o_min_core_len(ix, kp->pmode, &s2);
+    if (j.mcl <= 0) j.mcl = m2;
+    if (j.spm <= 0) j.spm = s2;
+  }
+  run_batch(&j, nthreads, ctr);
+  return 0;
+}
+
+int k4o_align_reads_batch(const k4o_index* ix, int tot_mm, int core_len, int core_delta, int max_slides,
+                          int min_core_len, int mm_delta, int strand, int max_hits, int64_t n_reads,
+                          const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int32_t* rslt,
+                          int32_t* inst, int32_t* low, int32_t* nxt, k4o_hit* hits, int nthreads, k4o_counters* ctr) {
+  (void)min_core_len;
+  batch_job j;
+  memset(&j, 0, sizeof(j));
+  j.ix = ix; j.n = n_reads; j.reads = reads; j.offs = offs; j.lens = lens; j.hits = hits;
+  j.raw = 1; j.tot_mm = tot_mm; j.core_len = core_len; j.core_delta = core_delta; j.slides = max_slides;
+  j.mm_delta = mm_delta; j.strand = strand; j.max_hits = max_hits;
+  j.rslt = rslt; j.inst = inst; j.low = low; j.nxt = nxt;
+  run_batch(&j, nthreads, ctr);
+  return 0;
+}

@@ -1,0 +1,140 @@
+/* oracle/k4oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the kit4b short-read alignment hot path, used as the parity checker in
+ * tests/, in __graft_entry__.smoke() and as bench.py's cpu_baseline ("port").  Nothing on the product
+ * path (kit4b_amd/, include/) may include, link or call this.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement against the golden vectors
+ * under tests/golden/ that were captured from the real reference library (oracle/_ref/libk4ref.so, built
+ * by oracle/Makefile from /root/reference) by tests/golden/make_golden.py; when oracle/_ref is present the
+ * same tests also compare against the live reference on fresh random inputs.
+ *
+ * Every function cites the reference file:line it restates (paths relative to /root/reference).
+ */
+#ifndef K4ORACLE_H
+#define K4ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* etSeqBase values, libkit4b/commdefs.h:76-87 */
+enum { K4O_A = 0, K4O_C = 1, K4O_G = 2, K4O_T = 3, K4O_N = 4, K4O_EOS = 7 };
+
+/* tHRslt, libkit4b/SfxArray.h:79-87 */
+enum { K4O_HR_NONE = 0, K4O_HR_HITS = 1, K4O_HR_MMDELTA = 2, K4O_HR_HITINSTS = 3, K4O_HR_RMMDELTA = 4,
+       K4O_HR_SEQERRS = 5, K4O_HR_FATAL = 6 };
+
+/* eALStrand, libkit4b/SfxArray.h:72-77 */
+enum { K4O_STRAND_BOTH = 0, K4O_STRAND_WATSON = 1, K4O_STRAND_CRICK = 2 };
+
+/* eNAR (subset reachable from AlignRead), ngskit4b/KAligner.h:136-158 */
+enum { K4O_NAR_UNALIGNED = 0, K4O_NAR_ACCEPTED = 1, K4O_NAR_NS = 2, K4O_NAR_NOHIT = 3, K4O_NAR_MMDELTA = 4,
+       K4O_NAR_MULTIALIGN = 5 };
+
+/* the fields of tsHitLoci.Seg[0] that the default path fills (libkit4b/SfxArray.h:239-260,
+ * SfxArray.cpp:6264-6307); 16 bytes, same layout as k4_hit in include/k4sfx.h */
+typedef struct {
+  uint32_t chrom_id;   /* Seg[0].ChromID: 1-based EntryID */
+  uint32_t match_loci; /* Seg[0].MatchLoci: 0-based, the reference truncates it to uint32 (SfxArray.cpp:6277) */
+  uint16_t match_len;  /* Seg[0].MatchLen = ProbeLen */
+  uint8_t strand;      /* '+' or '-' */
+  uint8_t mismatches;  /* Seg[0].Mismatches */
+  uint32_t reserved;   /* 0 */
+} k4o_hit;
+
+typedef struct {
+  uint32_t entry_id;   /* tsSfxEntry.EntryID (1..n) */
+  uint32_t fblock_id;  /* tsSfxEntry.fBlockID */
+  char name[81];       /* tsSfxEntry.szSeqName */
+  uint16_t name_hash;  /* CUtility::GenHash16 */
+  uint32_t seq_len;
+  uint64_t start_ofs;
+  uint64_t end_ofs;    /* inclusive, excludes EOS */
+} k4o_entry;
+
+typedef struct k4o_index k4o_index;
+
+/* counters used for the roofline accounting of SURVEY.md 8(d) */
+typedef struct {
+  uint64_t n_lookup; /* LocateFirstExact calls */
+  uint64_t n_probe;  /* binary-search probes (SA element + suffix compare) */
+  uint64_t n_cand;   /* candidates that reached the Hamming extension */
+} k4o_counters;
+
+/* ---- index: .sfx I/O and construction ----------------------------------------------------------- */
+k4o_index* k4o_open(const char* sfx_path, char* err, size_t errlen);          /* SfxArray.cpp:629-825,1915-1969 */
+k4o_index* k4o_build(int nseq, const char* const* names, const uint8_t* const* seqs, const uint32_t* lens,
+                     const char* dataset, int force_el_size, int nthreads);  /* SfxArray.cpp:1518-1753,9739-9834 */
+k4o_index* k4o_from_parts(uint64_t n, uint32_t el, uint8_t* seq, uint8_t* sa, uint32_t n_entries,
+                          const k4o_entry* entries, const char* dataset);    /* adopts seq/sa (not freed) */
+int k4o_write(const k4o_index* ix, const char* sfx_path);                     /* SfxArray.cpp:380-620,892-946 */
+void k4o_close(k4o_index* ix);
+
+uint64_t k4o_concat_len(const k4o_index* ix);
+uint32_t k4o_el_size(const k4o_index* ix);
+const uint8_t* k4o_seq(const k4o_index* ix);
+const uint8_t* k4o_sa_bytes(const k4o_index* ix);
+uint32_t k4o_num_entries(const k4o_index* ix);
+const k4o_entry* k4o_entries(const k4o_index* ix);
+uint64_t k4o_tot_seqs_len(const k4o_index* ix);                               /* CSfxArray::GetTotSeqsLen */
+int64_t k4o_sa_at(const k4o_index* ix, int64_t i);                            /* SfxOfsToLoci, SfxArray.cpp:49-60 */
+void k4o_set_max_iter(k4o_index* ix, int max_iter);                           /* SfxArray.cpp:1501 */
+
+/* ---- search core ---------------------------------------------------------------------------------- */
+int64_t k4o_locate_first_exact(const k4o_index* ix, const uint8_t* probe, int probe_len, int64_t lo, int64_t hi,
+                               k4o_counters* ctr);                            /* SfxArray.cpp:7938-8058 */
+int k4o_locate_core_multiples(const k4o_index* ix, int max_tot_mm, int core_len, int core_delta, int max_slides,
+                              int mm_delta, int strand, int* inst, int* low, int* nxt, uint8_t* probe,
+                              int probe_len, int max_hits, k4o_hit* hits, k4o_counters* ctr); /* :5806-6369 */
+int k4o_align_reads(const k4o_index* ix, int tot_mm, int core_len, int core_delta, int max_slides, int min_core_len,
+                    int mm_delta, int strand, int* inst, int* low, int* nxt, uint8_t* probe, int probe_len,
+                    int max_hits, k4o_hit* hits, k4o_counters* ctr);          /* SfxArray.cpp:7838-7933 */
+
+/* ---- CKAligner::AlignRead level ------------------------------------------------------------------- */
+typedef struct {
+  int max_subs;      /* -s: allowed substitutions per 100 bp (KAlignerCL.cpp:796) */
+  int min_edit_dist; /* -e: 1 or 2 (MMDelta) */
+  int max_ns;        /* -n: default 1 */
+  int pmode;         /* -m: 0 default,1 more,2 ultra,3 less (KAligner.cpp:9377-9393) */
+  int strand;        /* K4O_STRAND_* */
+  int max_ml;        /* max(MaxMLmatches, PE ? 10 : 0): MaxHits handed to AlignReads (KAligner.cpp:9604) */
+  int pe_mode;       /* 0 SE classification, 1 PE classification (KAligner.cpp:9982-10023) */
+  int min_core_len;  /* 0 = derive from the index (KAligner.cpp:9367-9393) */
+  int max_num_slides;/* 0 = derive from pmode */
+} k4o_kalign_params;
+
+typedef struct {
+  int32_t hit_rslt;  /* tHRslt returned by AlignReads (or K4O_HR_SEQERRS) */
+  int32_t inst;      /* LowHitInstances after the clamp to MaxML+1 (KAligner.cpp:9854) */
+  int32_t low_mm;
+  int32_t nxt_mm;
+  int32_t nar;       /* eNAR */
+  int32_t num_hits;  /* tsReadHit.NumHits */
+} k4o_read_result;
+
+int k4o_min_core_len(const k4o_index* ix, int pmode, int* max_num_slides);   /* KAligner.cpp:9367-9393 */
+void k4o_read_params(const k4o_kalign_params* kp, int min_core_len, int max_num_slides_per100, int read_len,
+                     int* max_tot_mm, int* core_len, int* core_delta, int* max_slides); /* KAligner.cpp:9662-9672 */
+int k4o_align_read(const k4o_index* ix, const k4o_kalign_params* kp, const uint8_t* read, int read_len,
+                   k4o_read_result* out, k4o_hit* hits, k4o_counters* ctr);  /* KAligner.cpp:9583-10105 */
+/* reads: concatenated etSeqBase bytes, read i = reads[offs[i] .. offs[i]+lens[i]); hits: n*max_ml records */
+int k4o_align_batch(const k4o_index* ix, const k4o_kalign_params* kp, int64_t n_reads, const uint8_t* reads,
+                    const uint64_t* offs, const uint32_t* lens, k4o_read_result* out, k4o_hit* hits,
+                    int nthreads, k4o_counters* ctr);                          /* KAligner.cpp:10110-10263 */
+
+/* raw AlignReads over a batch with uniform explicit parameters (the CSfxArray boundary) */
+int k4o_align_reads_batch(const k4o_index* ix, int tot_mm, int core_len, int core_delta, int max_slides,
+                          int min_core_len, int mm_delta, int strand, int max_hits, int64_t n_reads,
+                          const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int32_t* rslt,
+                          int32_t* inst, int32_t* low, int32_t* nxt, k4o_hit* hits, int nthreads,
+                          k4o_counters* ctr);
+
+void k4o_revcomp(uint8_t* seq, int len);                                      /* SeqTrans.cpp:497-545 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle_bindings import Oracle
+
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="session")
+def g1_el5_path(golden_dir, tmp_path_factory):
+    """tests/golden/g1_el5.sfx.xz unpacked to a temp file"""
+    import lzma
+
+    p = tmp_path_factory.mktemp("golden") / "g1_el5.sfx"
+    with lzma.open(os.path.join(golden_dir, "g1_el5.sfx.xz"), "rb") as f, open(p, "wb") as g:
+        g.write(f.read())
+    return str(p)

@@ -1,0 +1,271 @@
+"""ctypes bindings for the TEST-ONLY checkers under oracle/:
+
+* ``Oracle``  -> oracle/libk4oracle.so  (our plain-C restatement, always buildable)
+* ``Ref``     -> oracle/_ref/libk4ref.so (the real reference library; only where it was built)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libk4oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libk4ref.so")
+
+STRAND_BOTH, STRAND_WATSON, STRAND_CRICK = 0, 1, 2
+HR_NONE, HR_HITS, HR_MMDELTA, HR_HITINSTS, HR_RMMDELTA, HR_SEQERRS = 0, 1, 2, 3, 4, 5
+NAR_ACCEPTED, NAR_NS, NAR_NOHIT, NAR_MMDELTA, NAR_MULTIALIGN = 1, 2, 3, 4, 5
+
+# 16-byte hit record, identical in the oracle (k4o_hit) and the product (k4_hit, include/k4sfx.h)
+HIT_DTYPE = np.dtype(
+    [("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"), ("strand", "u1"), ("mismatches", "u1"),
+     ("reserved", "<u4")]
+)
+RESULT_DTYPE = np.dtype(
+    [("hit_rslt", "<i4"), ("inst", "<i4"), ("low_mm", "<i4"), ("nxt_mm", "<i4"), ("nar", "<i4"), ("num_hits", "<i4")]
+)
+
+
+class KalignParams(C.Structure):
+    _fields_ = [
+        ("max_subs", C.c_int), ("min_edit_dist", C.c_int), ("max_ns", C.c_int), ("pmode", C.c_int),
+        ("strand", C.c_int), ("max_ml", C.c_int), ("pe_mode", C.c_int), ("min_core_len", C.c_int),
+        ("max_num_slides", C.c_int),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_lookup", C.c_uint64), ("n_probe", C.c_uint64), ("n_cand", C.c_uint64)]
+
+
+class Entry(C.Structure):
+    _fields_ = [
+        ("entry_id", C.c_uint32), ("fblock_id", C.c_uint32), ("name", C.c_char * 81), ("name_hash", C.c_uint16),
+        ("seq_len", C.c_uint32), ("start_ofs", C.c_uint64), ("end_ofs", C.c_uint64),
+    ]
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _seq_args(names, seqs):
+    n = len(seqs)
+    seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+    names_a = (C.c_char_p * n)(*[nm.encode() if isinstance(nm, str) else nm for nm in names])
+    ptrs = (C.c_void_p * n)(*[s.ctypes.data for s in seqs])
+    lens = (C.c_uint32 * n)(*[len(s) for s in seqs])
+    return n, names_a, ptrs, lens, seqs
+
+
+def flatten_reads(reads):
+    """list of uint8 arrays -> (concat, offs u64, lens u32)"""
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    offs = np.zeros(len(reads), dtype=np.uint64)
+    if len(reads):
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        cat = np.ascontiguousarray(np.concatenate(reads).astype(np.uint8))
+    else:
+        cat = np.zeros(0, dtype=np.uint8)
+    return cat, offs, lens
+
+
+class Oracle:
+    """oracle/libk4oracle.so"""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+            os.path.join(ORACLE_DIR, "k4oracle.c")
+        ):
+            build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.k4o_open.restype = C.c_void_p
+        L.k4o_open.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.k4o_build.restype = C.c_void_p
+        L.k4o_build.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        L.k4o_from_parts.restype = C.c_void_p
+        L.k4o_from_parts.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p]
+        L.k4o_write.argtypes = [C.c_void_p, C.c_char_p]
+        L.k4o_close.argtypes = [C.c_void_p]
+        for f, rt in [("k4o_concat_len", C.c_uint64), ("k4o_el_size", C.c_uint32), ("k4o_seq", C.c_void_p),
+                      ("k4o_sa_bytes", C.c_void_p), ("k4o_num_entries", C.c_uint32),
+                      ("k4o_entries", C.POINTER(Entry)), ("k4o_tot_seqs_len", C.c_uint64)]:
+            getattr(L, f).restype = rt
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.k4o_sa_at.restype = C.c_int64
+        L.k4o_sa_at.argtypes = [C.c_void_p, C.c_int64]
+        L.k4o_set_max_iter.argtypes = [C.c_void_p, C.c_int]
+        L.k4o_locate_first_exact.restype = C.c_int64
+        L.k4o_locate_first_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+        L.k4o_min_core_len.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.k4o_align_batch.argtypes = [C.c_void_p, C.POINTER(KalignParams), C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Counters)]
+        L.k4o_align_reads_batch.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_int64] + [C.c_void_p] * 8 + [
+            C.c_int, C.POINTER(Counters)]
+        L.k4o_revcomp.argtypes = [C.c_void_p, C.c_int]
+        self.L = L
+
+    # -- index ------------------------------------------------------------------------------------
+    def open(self, path):
+        err = C.create_string_buffer(512)
+        h = self.L.k4o_open(path.encode(), err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return h
+
+    def build(self, names, seqs, dataset="syn", force_el=0, threads=4):
+        n, names_a, ptrs, lens, keep = _seq_args(names, seqs)
+        h = self.L.k4o_build(n, names_a, ptrs, lens, dataset.encode(), force_el, threads)
+        if not h:
+            raise RuntimeError("k4o_build failed")
+        return h
+
+    def write(self, h, path):
+        if self.L.k4o_write(h, path.encode()) != 0:
+            raise RuntimeError("k4o_write failed")
+
+    def close(self, h):
+        self.L.k4o_close(h)
+
+    def concat_len(self, h):
+        return self.L.k4o_concat_len(h)
+
+    def el_size(self, h):
+        return self.L.k4o_el_size(h)
+
+    def seq(self, h):
+        n = self.concat_len(h)
+        return np.ctypeslib.as_array(C.cast(self.L.k4o_seq(h), C.POINTER(C.c_uint8)), shape=(n,))
+
+    def sa(self, h):
+        """suffix array as int64 numpy (copy)"""
+        n, el = self.concat_len(h), self.el_size(h)
+        raw = np.ctypeslib.as_array(C.cast(self.L.k4o_sa_bytes(h), C.POINTER(C.c_uint8)), shape=(n * el,))
+        raw = raw.reshape(n, el)
+        v = raw[:, :4].copy().view("<u4").reshape(n).astype(np.int64)
+        if el == 5:
+            v |= raw[:, 4].astype(np.int64) << 32
+        return v
+
+    def entries(self, h):
+        n = self.L.k4o_num_entries(h)
+        p = self.L.k4o_entries(h)
+        return [dict(entry_id=p[i].entry_id, name=p[i].name.decode(), seq_len=p[i].seq_len,
+                     start_ofs=p[i].start_ofs, end_ofs=p[i].end_ofs) for i in range(n)]
+
+    def set_max_iter(self, h, it):
+        self.L.k4o_set_max_iter(h, it)
+
+    def min_core_len(self, h, pmode=0):
+        s = C.c_int(0)
+        m = self.L.k4o_min_core_len(h, pmode, C.byref(s))
+        return m, s.value
+
+    def locate_first_exact(self, h, probe):
+        probe = np.ascontiguousarray(probe, dtype=np.uint8)
+        return self.L.k4o_locate_first_exact(h, probe.ctypes.data, len(probe), 0, self.concat_len(h) - 1, None)
+
+    # -- alignment ----------------------------------------------------------------------------------
+    def align_reads_batch(self, h, reads, tot_mm, core_len, core_delta, max_slides, min_core_len=0, mm_delta=1,
+                          strand=STRAND_BOTH, max_hits=1, threads=4):
+        """CSfxArray::AlignReads over a batch; reads = list of arrays or (cat, offs, lens)."""
+        cat, offs, lens = reads if isinstance(reads, tuple) else flatten_reads(reads)
+        n = len(lens)
+        rslt = np.zeros(n, np.int32); inst = np.zeros(n, np.int32); low = np.zeros(n, np.int32)
+        nxt = np.zeros(n, np.int32)
+        hits = np.zeros((n, max_hits), dtype=HIT_DTYPE)
+        ctr = Counters()
+        self.L.k4o_align_reads_batch(h, tot_mm, core_len, core_delta, max_slides, min_core_len, mm_delta, strand,
+                                     max_hits, n, cat.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                                     rslt.ctypes.data, inst.ctypes.data, low.ctypes.data, nxt.ctypes.data,
+                                     hits.ctypes.data, threads, C.byref(ctr))
+        return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits,
+                    counters=dict(n_lookup=ctr.n_lookup, n_probe=ctr.n_probe, n_cand=ctr.n_cand))
+
+    def kalign_batch(self, h, reads, max_subs=5, min_edit_dist=1, max_ns=1, pmode=0, strand=STRAND_BOTH, max_ml=1,
+                     pe_mode=0, min_core_len=0, max_num_slides=0, threads=4):
+        """CKAligner::AlignRead over a batch."""
+        cat, offs, lens = reads if isinstance(reads, tuple) else flatten_reads(reads)
+        n = len(lens)
+        kp = KalignParams(max_subs, min_edit_dist, max_ns, pmode, strand, max_ml, pe_mode, min_core_len,
+                          max_num_slides)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        hits = np.zeros((n, max(1, max_ml)), dtype=HIT_DTYPE)
+        ctr = Counters()
+        self.L.k4o_align_batch(h, C.byref(kp), n, cat.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                               out.ctypes.data, hits.ctypes.data, threads, C.byref(ctr))
+        return dict(out=out, hits=hits,
+                    counters=dict(n_lookup=ctr.n_lookup, n_probe=ctr.n_probe, n_cand=ctr.n_cand))
+
+
+class _RefHit(C.Structure):
+    _fields_ = [("chrom_id", C.c_uint32), ("match_loci", C.c_uint64), ("match_len", C.c_uint16),
+                ("strand", C.c_uint8), ("mismatches", C.c_uint8)]
+
+
+def ref_available():
+    return os.path.exists(REF_SO)
+
+
+class Ref:
+    """oracle/_ref/libk4ref.so -- the real reference (CSfxArray) behind oracle/ref_harness.cpp."""
+
+    def __init__(self):
+        L = C.CDLL(REF_SO)
+        L.k4ref_open.restype = C.c_void_p
+        L.k4ref_open.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.k4ref_close.argtypes = [C.c_void_p]
+        L.k4ref_tot_seqs_len.restype = C.c_uint64
+        L.k4ref_tot_seqs_len.argtypes = [C.c_void_p]
+        L.k4ref_build_sfx.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_int]
+        L.k4ref_align_reads.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_int, C.c_int,
+                                                                        C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                                        C.POINTER(C.c_int), C.POINTER(_RefHit)]
+        self.L = L
+
+    def build_sfx(self, path, names, seqs, dataset="syn", threads=4):
+        n, names_a, ptrs, lens, keep = _seq_args(names, seqs)
+        r = self.L.k4ref_build_sfx(path.encode(), dataset.encode(), n, names_a, ptrs, lens, threads, 0)
+        if r < 0:
+            raise RuntimeError("k4ref_build_sfx failed %d" % r)
+
+    def open(self, path, max_iter=5000, core_kmer_len=0):
+        h = self.L.k4ref_open(path.encode(), max_iter, core_kmer_len)  # costs a fixed 2 s sleep (SfxArray.cpp:1165)
+        if not h:
+            raise RuntimeError("k4ref_open failed")
+        return h
+
+    def close(self, h):
+        self.L.k4ref_close(h)
+
+    def align_reads_batch(self, h, reads, tot_mm, core_len, core_delta, max_slides, min_core_len=0, mm_delta=1,
+                          strand=STRAND_BOTH, max_hits=1):
+        if isinstance(reads, tuple):
+            cat, offs, lens = reads
+            reads = [cat[int(o):int(o) + int(l)] for o, l in zip(offs, lens)]
+        n = len(reads)
+        rslt = np.zeros(n, np.int32); inst = np.zeros(n, np.int32); low = np.zeros(n, np.int32)
+        nxt = np.zeros(n, np.int32)
+        hits = np.zeros((n, max_hits), dtype=HIT_DTYPE)
+        rh = (_RefHit * max_hits)()
+        for i, rd in enumerate(reads):
+            buf = np.ascontiguousarray(rd, dtype=np.uint8).copy()
+            a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+            rslt[i] = self.L.k4ref_align_reads(h, tot_mm, core_len, core_delta, max_slides, min_core_len, mm_delta,
+                                               strand, buf.ctypes.data, len(buf), max_hits, C.byref(a), C.byref(b),
+                                               C.byref(c), rh)
+            assert np.array_equal(buf, np.asarray(rd, dtype=np.uint8)), "reference did not restore the probe"
+            inst[i], low[i], nxt[i] = a.value, b.value, c.value
+            for k in range(max_hits):
+                hits[i, k] = (rh[k].chrom_id, rh[k].match_loci & 0xFFFFFFFF, rh[k].match_len, rh[k].strand,
+                              rh[k].mismatches, 0)
+        return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits)

@@ -1,0 +1,102 @@
+"""Seeded synthetic genomes and reads for the parity tests (numpy, CPU).
+
+Semantics follow `ngskit4b simreads` (libkit4b/SimReads.cpp:237-249: substitutions per read ~ Poisson(1)
+truncated at 8, uniform positions, substituted base != original) but not its RNG.
+Bases are etSeqBase codes: A=0 C=1 G=2 T=3 N=4.
+"""
+import numpy as np
+
+GENOME_SEED = 0x4B495434  # "KIT4"
+READS_SEED = 0x52454144   # "READ"
+
+
+def revcomp(seq):
+    s = np.asarray(seq, dtype=np.uint8)[::-1].copy()
+    acgt = s <= 3
+    s[acgt] = 3 - s[acgt]
+    return s
+
+
+def make_genome(chrom_lens, seed=GENOME_SEED, repeats=0, repeat_len=300, repeat_div=0.0, n_runs=0, n_run_len=30,
+                tandem=0):
+    """i.i.d. ACGT chromosomes; optionally plants `repeats` copies of repeat families (exact or diverged),
+    `tandem` low-complexity tandem blocks and `n_runs` runs of N."""
+    rng = np.random.default_rng(seed)
+    chroms = [rng.integers(0, 4, size=n, dtype=np.uint8) for n in chrom_lens]
+    if repeats:
+        fam = rng.integers(0, 4, size=repeat_len, dtype=np.uint8)
+        for _ in range(repeats):
+            c = int(rng.integers(0, len(chroms)))
+            if len(chroms[c]) <= repeat_len + 2:
+                continue
+            p = int(rng.integers(0, len(chroms[c]) - repeat_len))
+            copy = fam.copy()
+            if repeat_div > 0:
+                m = rng.random(repeat_len) < repeat_div
+                copy[m] = (copy[m] + rng.integers(1, 4, size=int(m.sum()))) % 4
+            if rng.random() < 0.5:
+                copy = revcomp(copy)
+            chroms[c][p:p + repeat_len] = copy
+    for _ in range(tandem):
+        c = int(rng.integers(0, len(chroms)))
+        unit = rng.integers(0, 4, size=int(rng.integers(1, 7)), dtype=np.uint8)
+        ln = int(rng.integers(150, 600))
+        if len(chroms[c]) <= ln + 2:
+            continue
+        p = int(rng.integers(0, len(chroms[c]) - ln))
+        chroms[c][p:p + ln] = np.resize(unit, ln)
+    for _ in range(n_runs):
+        c = int(rng.integers(0, len(chroms)))
+        if len(chroms[c]) <= n_run_len + 2:
+            continue
+        p = int(rng.integers(0, len(chroms[c]) - n_run_len))
+        chroms[c][p:p + n_run_len] = 4
+    names = ["chr%d" % (i + 1) for i in range(len(chroms))]
+    return names, chroms
+
+
+def make_reads(chroms, n_reads, read_len, seed=READS_SEED, sub_lambda=1.0, max_subs=8, n_prob=0.0, edge_frac=0.0,
+               random_frac=0.0, fixed_subs=None):
+    """Returns (reads list, truth array[chrom(1-based), start, strand(0 '+',1 '-'), nsubs])."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(c) for c in chroms], dtype=np.int64)
+    ok = lens >= read_len
+    w = np.where(ok, lens - read_len + 1, 0).astype(np.float64)
+    w /= w.sum()
+    reads, truth = [], np.zeros((n_reads, 4), dtype=np.int64)
+    for i in range(n_reads):
+        if random_frac and rng.random() < random_frac:
+            reads.append(rng.integers(0, 4, size=read_len, dtype=np.uint8))
+            truth[i] = (0, 0, 0, -1)
+            continue
+        c = int(rng.choice(len(chroms), p=w))
+        if edge_frac and rng.random() < edge_frac:  # hug a chromosome end
+            start = 0 if rng.random() < 0.5 else int(lens[c] - read_len)
+            start = min(max(start + int(rng.integers(-2, 3)), 0), int(lens[c] - read_len))
+        else:
+            start = int(rng.integers(0, lens[c] - read_len + 1))
+        rd = chroms[c][start:start + read_len].copy()
+        if fixed_subs is not None:
+            ns = int(fixed_subs)
+        else:
+            ns = int(min(rng.poisson(sub_lambda), max_subs)) if sub_lambda > 0 else 0
+        if ns:
+            pos = rng.choice(read_len, size=ns, replace=False)
+            for p in pos:
+                if rd[p] <= 3:
+                    rd[p] = (rd[p] + int(rng.integers(1, 4))) % 4
+        strand = int(rng.integers(0, 2))
+        if strand:
+            rd = revcomp(rd)
+        if n_prob and rng.random() < n_prob:
+            k = int(rng.integers(1, 4))
+            rd[rng.choice(read_len, size=k, replace=False)] = 4
+        reads.append(rd)
+        truth[i] = (c + 1, start, strand, ns)
+    return reads, truth
+
+
+def golden_genome():
+    """The genome behind tests/golden/g1.sfx (tests/golden/make_golden.py)."""
+    return make_genome([60000, 40000, 25000, 300, 120], repeats=40, repeat_len=250, repeat_div=0.01, n_runs=6,
+                       tandem=6)
