@@ -1,0 +1,192 @@
+/* include/k4sfx.h -- C ABI of libk4sfx.so: the MI355X-native replacement for the kit4b kalign hot path
+ * (seed lookup in the CSfxArray suffix-array index + mismatch-bounded full-read extension).
+ *
+ * The reference has no FFI layer: the boundary it exposes for this path is the C++ class CSfxArray
+ * (libkit4b/SfxArray.h:524-1023) as called by CKAligner (ngskit4b/KAligner.cpp).  Each entry point below
+ * names the reference method(s) it replaces.  Plain pointers and sizes only; no torch / HIP types.
+ * The C++ facade that keeps the CSfxArray method names on top of this ABI is include/k4_sfxarray.hpp;
+ * the binding a kit4b maintainer would add is shown in INTEGRATION.md.
+ *
+ * Result conventions (same as the reference):
+ *   < 0          teBSFrsltCodes  (libkit4b/ErrorCodes.h:15-97), text via k4_last_error()
+ *   0..4         tHRslt          (libkit4b/SfxArray.h:79-87) for per-read alignment results
+ * There is NO CPU fallback: every compute entry point runs hand-written HIP kernels on gfx950 and fails
+ * with K4_ERR_NO_DEVICE when no GPU is usable.
+ */
+#ifndef K4SFX_H
+#define K4SFX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define K4_ABI_VERSION 1
+
+/* teBSFrsltCodes values used by this library (libkit4b/ErrorCodes.h:15-97) */
+enum {
+  K4_OK = 0,               /* eBSFSuccess */
+  K4_ERR_PARAMS = -100,    /* eBSFerrParams */
+  K4_ERR_MEM = -95,        /* eBSFerrMem */
+  K4_ERR_NOT_SFX = -94,    /* eBSFerrNotBioseq */
+  K4_ERR_OPEN_FILE = -90,  /* eBSFerrOpnFile */
+  K4_ERR_CREATE_FILE = -89,/* eBSFerrCreateFile */
+  K4_ERR_FILE_VER = -86,   /* eBSFerrFileVer */
+  K4_ERR_FILE_ACCESS = -85,/* eBSFerrFileAccess */
+  K4_ERR_ENTRY = -51,      /* eBSFerrEntry */
+  K4_ERR_INTERNAL = -1,    /* eBSFerrInternal */
+  K4_ERR_NO_DEVICE = -2,   /* (new) no usable gfx950 device / HIP runtime error */
+  K4_ERR_UNSUPPORTED = -3  /* (new) feature outside the hot-path scope (bisulfite, colourspace, ...) */
+};
+
+/* tHRslt, libkit4b/SfxArray.h:79-87 */
+enum { K4_HR_NONE = 0, K4_HR_HITS = 1, K4_HR_MMDELTA = 2, K4_HR_HITINSTS = 3, K4_HR_RMMDELTA = 4,
+       K4_HR_SEQERRS = 5, K4_HR_FATAL = 6 };
+/* eALStrand, libkit4b/SfxArray.h:72-77 */
+enum { K4_STRAND_BOTH = 0, K4_STRAND_WATSON = 1, K4_STRAND_CRICK = 2 };
+/* eNAR values AlignRead can assign, ngskit4b/KAligner.h:136-158 */
+enum { K4_NAR_UNALIGNED = 0, K4_NAR_ACCEPTED = 1, K4_NAR_NS = 2, K4_NAR_NOHIT = 3, K4_NAR_MMDELTA = 4,
+       K4_NAR_MULTIALIGN = 5 };
+
+typedef struct k4_index k4_index; /* opaque: the HBM-resident index (replaces a loaded CSfxArray) */
+
+/* What the default alignment path stores in tsHitLoci.Seg[0] (libkit4b/SfxArray.h:239-260, filled at
+ * SfxArray.cpp:6264-6307).  16 bytes. */
+typedef struct {
+  uint32_t chrom_id;   /* Seg[0].ChromID: 1-based tsSfxEntry.EntryID */
+  uint32_t match_loci; /* Seg[0].MatchLoci: 0-based in the chromosome (the reference truncates to uint32) */
+  uint16_t match_len;  /* Seg[0].MatchLen == probe length */
+  uint8_t strand;      /* Seg[0].Strand: '+' or '-' */
+  uint8_t mismatches;  /* Seg[0].Mismatches == Seg[0].TrimMismatches */
+  uint32_t reserved;   /* 0 */
+} k4_hit;
+
+/* tsSfxEntry (libkit4b/SfxArray.h:98-106) without packing */
+typedef struct {
+  uint32_t entry_id;
+  uint32_t fblock_id;
+  char name[81];
+  uint16_t name_hash;
+  uint32_t seq_len;
+  uint64_t start_ofs;
+  uint64_t end_ofs;
+} k4_entry;
+
+typedef struct {
+  uint64_t concat_len;   /* tsSfxBlock.ConcatSeqLen */
+  uint64_t tot_seqs_len; /* CSfxArray::GetTotSeqsLen, SfxArray.h:970 */
+  uint32_t sfx_el_size;  /* 4 | 5 */
+  uint32_t n_entries;    /* CSfxArray::GetNumEntries, SfxArray.h:958 */
+  uint32_t kmer_k;       /* length of the direct-address k-mer -> SA-interval table */
+  uint32_t n_exc_blocks; /* 64-base blocks holding a non-ACGT symbol (N / EOS) */
+  uint64_t device_bytes; /* HBM held by this index */
+  int32_t device;        /* HIP device ordinal */
+  int32_t max_iter;      /* CSfxArray::GetMaxIter */
+  char dataset[81];      /* CSfxArray::GetDatasetName */
+} k4_info_t;
+
+/* The arguments of CSfxArray::AlignReads (libkit4b/SfxArray.h:614-634) that the default path uses.
+ * MinChimericLen, microInDelLen and MaxSpliceJunctLen are fixed at 0 (those phases are out of scope). */
+typedef struct {
+  int32_t tot_mm;          /* TotMM */
+  int32_t core_len;        /* CoreLen */
+  int32_t core_delta;      /* CoreDelta */
+  int32_t max_core_slides; /* MaxNumCoreSlides */
+  int32_t min_core_len;    /* MinCoreLen (only used by the chimeric phase in the reference; kept for parity of the call) */
+  int32_t mm_delta;        /* MMDelta */
+  int32_t strand;          /* Align2Strand: K4_STRAND_* */
+  int32_t max_hits;        /* MaxHits */
+} k4_align_params;
+
+/* What CKAligner::AlignRead derives per read and how it classifies (ngskit4b/KAligner.cpp:9583-10105) */
+typedef struct {
+  int32_t max_subs;       /* -s per 100 bp (pPars->MaxSubs) */
+  int32_t min_edit_dist;  /* -e (pPars->MinEditDist) 1|2 */
+  int32_t max_ns;         /* -n (m_MaxNs), default 1 */
+  int32_t pmode;          /* -m 0 default,1 more,2 ultra,3 less sensitive (KAligner.cpp:9377-9393) */
+  int32_t strand;         /* K4_STRAND_* */
+  int32_t max_ml;         /* max(m_MaxMLmatches, PE ? cMaxMLPEmatches : 0) (KAligner.cpp:9604) */
+  int32_t pe_mode;        /* 0: SE classification, 1: PE classification (KAligner.cpp:9982-10023) */
+  int32_t min_core_len;   /* 0: derive as LocateCoredApprox does (KAligner.cpp:9367-9393) */
+  int32_t max_num_slides; /* 0: derive from pmode */
+} k4_kalign_params;
+
+typedef struct {
+  int32_t hit_rslt; /* tHRslt from AlignReads (K4_HR_SEQERRS when the read has too many Ns) */
+  int32_t inst;     /* tsReadHit.LowHitInstances */
+  int32_t low_mm;   /* tsReadHit.LowMMCnt */
+  int32_t nxt_mm;   /* tsReadHit.NxtLowMMCnt */
+  int32_t nar;      /* tsReadHit.NAR */
+  int32_t num_hits; /* tsReadHit.NumHits */
+} k4_read_result;
+
+/* run-time tallies for the roofline accounting; cumulative until k4_reset_counters */
+typedef struct {
+  uint64_t n_reads;    /* reads processed */
+  uint64_t n_lookup;   /* seed lookups (one per LocateFirstExact the reference would have made) */
+  uint64_t n_probe;    /* suffix-array probes actually issued (SA element + packed-reference window) */
+  uint64_t n_cand;     /* candidates that reached the Hamming extension */
+  uint64_t n_slow;     /* reads routed to the exact general kernel (N, separators, many candidates) */
+  uint64_t n_bases;    /* read bases in */
+} k4_counters;
+
+/* ---- index life cycle ------------------------------------------------------------------------------
+ * k4_open               <- CSfxArray::Open(path) + SetTargBlock(1)   SfxArray.h:528,957 (SfxArray.cpp:969,1982)
+ * k4_open_host          <- same, from an in-memory block (CSfxArray::Open(bBisulfite,bColorspace) in-memory mode, SfxArray.h:533)
+ * k4_open_device        <- same, adopting a 1-byte/base sequence and a suffix array already resident in HBM
+ * k4_close              <- CSfxArray::Close/Reset                    SfxArray.h:527,548
+ * kmer_k: 0 = choose from the index size; device: HIP ordinal. */
+int k4_open(const char* sfx_path, int device, int kmer_k, k4_index** out);
+int k4_open_host(uint64_t concat_len, uint32_t sfx_el_size, const uint8_t* seq, const uint8_t* sa,
+                 uint32_t n_entries, const k4_entry* entries, const char* dataset, int device, int kmer_k,
+                 k4_index** out);
+int k4_open_device(uint64_t concat_len, uint32_t sfx_el_size, const void* d_seq, void* d_sa, int adopt_sa,
+                   uint32_t n_entries, const k4_entry* entries, const char* dataset, int device, int kmer_k,
+                   k4_index** out);
+void k4_close(k4_index* ix);
+const char* k4_last_error(const k4_index* ix);            /* <- CErrorCodes::GetErrMsg, ErrorCodes.h:99-113 */
+const char* k4_global_error(void);                        /* error text when no index handle exists yet */
+int k4_info(const k4_index* ix, k4_info_t* out);          /* <- GetNumEntries/GetTotSeqsLen/GetSfxHeader */
+int k4_get_entry(const k4_index* ix, uint32_t entry_id, k4_entry* out); /* <- GetIdentName/GetSeqLen, SfxArray.h:967-969 */
+int k4_get_ident(const k4_index* ix, const char* name);   /* <- CSfxArray::GetIdent, SfxArray.h:968 */
+int k4_set_max_iter(k4_index* ix, int max_iter);          /* <- CSfxArray::SetMaxIter, SfxArray.h:556 */
+int k4_get_seq(const k4_index* ix, uint32_t entry_id, uint32_t loci, uint8_t* out, uint32_t len); /* <- GetSeq, SfxArray.h:996 */
+int k4_write_sfx(const k4_index* ix, const char* sfx_path); /* <- CSfxArray::Finalise/Flush2Disk, SfxArray.cpp:892 */
+
+/* ---- suffix-array construction on the GPU -----------------------------------
+ * <- CSfxArray::AddEntry + Finalise -> QSortSeq (SfxArray.cpp:1518,1758,9739): same suffix order
+ * (A<C<G<T<N<EOS, compare stops after the first EOS), ties broken by offset.
+ * d_seq: concat_len bytes in HBM (bases + one EOS per entry); d_sa: concat_len*sfx_el_size bytes in HBM, filled. */
+int k4_build_sa_device(uint64_t concat_len, uint32_t sfx_el_size, const void* d_seq, void* d_sa, int device);
+
+/* ---- the hot path -------------------------------------------------------------------------------------
+ * k4_align_reads_batch  <- CSfxArray::AlignReads for n_reads fresh reads (In/Out ints start at 0 as in
+ *                          KAligner.cpp:9609-9611,9678-9680), uniform parameters.   SfxArray.h:614 (SfxArray.cpp:7838)
+ * k4_kalign_batch       <- CKAligner::AlignRead for n_reads reads.                  KAligner.cpp:9583
+ * reads: concatenated etSeqBase bytes (A0 C1 G2 T3 N4; bits 3..7 ignored); read i = reads[offs[i] .. offs[i]+lens[i]).
+ * hits: n_reads * max_hits records; slots beyond min(inst,max_hits) are zero.
+ * *_dev variants take DEVICE pointers for every array and a hipStream_t (as void*); they enqueue only
+ * (no host synchronisation) once the workspace has been sized by k4_reserve(). */
+int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len, int32_t max_hits);
+int k4_align_reads_batch(k4_index* ix, const k4_align_params* p, int64_t n_reads, const uint8_t* reads,
+                         const uint64_t* offs, const uint32_t* lens, int32_t* rslt, int32_t* inst, int32_t* low,
+                         int32_t* nxt, k4_hit* hits);
+int k4_align_reads_batch_dev(k4_index* ix, const k4_align_params* p, int64_t n_reads, int32_t max_read_len,
+                             const void* d_reads, const void* d_offs, const void* d_lens, void* d_rslt, void* d_inst,
+                             void* d_low, void* d_nxt, void* d_hits, void* stream);
+int k4_kalign_batch(k4_index* ix, const k4_kalign_params* p, int64_t n_reads, const uint8_t* reads,
+                    const uint64_t* offs, const uint32_t* lens, k4_read_result* out, k4_hit* hits);
+int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n_reads, int32_t max_read_len,
+                        const void* d_reads, const void* d_offs, const void* d_lens, void* d_out, void* d_hits,
+                        void* stream);
+int k4_min_core_len(const k4_index* ix, int pmode, int* max_num_slides); /* <- LocateCoredApprox, KAligner.cpp:9367-9393 */
+
+int k4_get_counters(k4_index* ix, k4_counters* out); /* synchronises the device */
+int k4_reset_counters(k4_index* ix);
+int k4_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

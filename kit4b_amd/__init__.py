@@ -1,0 +1,282 @@
+"""kit4b_amd -- MI355X-native kit4b kalign hot path (seed lookup + mismatch-bounded extension).
+
+This package is a thin ctypes binding over the C ABI of ``kit4b_amd/libk4sfx.so`` (include/k4sfx.h), which holds
+the hand-written HIP kernels for gfx950.  It exists for the tests and bench.py; the product boundary is the C ABI
+and the C++ ``CSfxArray`` facade in include/k4_sfxarray.hpp.  There is no CPU fallback: importing works anywhere,
+every compute call needs the library and a GPU and raises ``K4Error`` otherwise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libk4sfx.so")
+
+STRAND_BOTH, STRAND_WATSON, STRAND_CRICK = 0, 1, 2
+HR_NONE, HR_HITS, HR_MMDELTA, HR_HITINSTS, HR_RMMDELTA, HR_SEQERRS = 0, 1, 2, 3, 4, 5
+NAR_ACCEPTED, NAR_NS, NAR_NOHIT, NAR_MMDELTA, NAR_MULTIALIGN = 1, 2, 3, 4, 5
+
+HIT_DTYPE = np.dtype(
+    [("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"), ("strand", "u1"), ("mismatches", "u1"),
+     ("reserved", "<u4")]
+)
+RESULT_DTYPE = np.dtype(
+    [("hit_rslt", "<i4"), ("inst", "<i4"), ("low_mm", "<i4"), ("nxt_mm", "<i4"), ("nar", "<i4"), ("num_hits", "<i4")]
+)
+
+
+class K4Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("k4sfx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Entry(C.Structure):
+    _fields_ = [("entry_id", C.c_uint32), ("fblock_id", C.c_uint32), ("name", C.c_char * 81),
+                ("name_hash", C.c_uint16), ("seq_len", C.c_uint32), ("start_ofs", C.c_uint64),
+                ("end_ofs", C.c_uint64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("concat_len", C.c_uint64), ("tot_seqs_len", C.c_uint64), ("sfx_el_size", C.c_uint32),
+                ("n_entries", C.c_uint32), ("kmer_k", C.c_uint32), ("n_exc_blocks", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("device", C.c_int32), ("max_iter", C.c_int32),
+                ("dataset", C.c_char * 81)]
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("tot_mm", C.c_int32), ("core_len", C.c_int32), ("core_delta", C.c_int32),
+                ("max_core_slides", C.c_int32), ("min_core_len", C.c_int32), ("mm_delta", C.c_int32),
+                ("strand", C.c_int32), ("max_hits", C.c_int32)]
+
+
+class KalignParams(C.Structure):
+    _fields_ = [("max_subs", C.c_int32), ("min_edit_dist", C.c_int32), ("max_ns", C.c_int32), ("pmode", C.c_int32),
+                ("strand", C.c_int32), ("max_ml", C.c_int32), ("pe_mode", C.c_int32), ("min_core_len", C.c_int32),
+                ("max_num_slides", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_lookup", C.c_uint64), ("n_probe", C.c_uint64), ("n_cand", C.c_uint64),
+                ("n_slow", C.c_uint64), ("n_bases", C.c_uint64)]
+
+
+_lib = None
+
+# every symbol include/k4sfx.h declares
+ABI_SYMBOLS = [
+    "k4_open", "k4_open_host", "k4_open_device", "k4_close", "k4_last_error", "k4_global_error", "k4_info",
+    "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
+    "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
+    "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version",
+]
+
+
+def build(verbose=False):
+    """Compile libk4sfx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(PKG_DIR, "csrc"), "-j4"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+
+
+def lib():
+    """The loaded C ABI; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise K4Error(-2, "%s is missing: run kit4b_amd.build() / make -C kit4b_amd/csrc" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
+    L.k4_open.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.k4_open_host.argtypes = [u64, u32, vp, vp, u32, C.POINTER(Entry), C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.k4_open_device.argtypes = [u64, u32, vp, vp, i32, u32, C.POINTER(Entry), C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.k4_close.argtypes = [vp]
+    L.k4_close.restype = None
+    L.k4_last_error.argtypes = [vp]
+    L.k4_last_error.restype = C.c_char_p
+    L.k4_global_error.restype = C.c_char_p
+    L.k4_info.argtypes = [vp, C.POINTER(Info)]
+    L.k4_get_entry.argtypes = [vp, u32, C.POINTER(Entry)]
+    L.k4_get_ident.argtypes = [vp, C.c_char_p]
+    L.k4_set_max_iter.argtypes = [vp, i32]
+    L.k4_get_seq.argtypes = [vp, u32, u32, vp, u32]
+    L.k4_write_sfx.argtypes = [vp, C.c_char_p]
+    L.k4_build_sa_device.argtypes = [u64, u32, vp, vp, i32]
+    L.k4_reserve.argtypes = [vp, i64, C.c_int32, C.c_int32]
+    L.k4_align_reads_batch.argtypes = [vp, C.POINTER(AlignParams), i64] + [vp] * 8
+    L.k4_align_reads_batch_dev.argtypes = [vp, C.POINTER(AlignParams), i64, C.c_int32] + [vp] * 9
+    L.k4_kalign_batch.argtypes = [vp, C.POINTER(KalignParams), i64] + [vp] * 5
+    L.k4_kalign_batch_dev.argtypes = [vp, C.POINTER(KalignParams), i64, C.c_int32] + [vp] * 6
+    L.k4_min_core_len.argtypes = [vp, i32, C.POINTER(C.c_int)]
+    L.k4_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.k4_reset_counters.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _flatten(reads):
+    if isinstance(reads, tuple):
+        cat, offs, lens = reads
+        return (np.ascontiguousarray(cat, dtype=np.uint8), np.ascontiguousarray(offs, dtype=np.uint64),
+                np.ascontiguousarray(lens, dtype=np.uint32))
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    offs = np.zeros(len(reads), dtype=np.uint64)
+    if len(reads):
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        cat = np.ascontiguousarray(np.concatenate(reads).astype(np.uint8))
+    else:
+        cat = np.zeros(0, dtype=np.uint8)
+    return cat, offs, lens
+
+
+def make_entries(names, lens):
+    """tsSfxEntry table for sequences concatenated with one EOS after each (CSfxArray::AddEntry, SfxArray.cpp:1735-1750)."""
+    arr = (Entry * len(names))()
+    ofs = 0
+    for i, (nm, ln) in enumerate(zip(names, lens)):
+        arr[i].entry_id = i + 1
+        arr[i].fblock_id = 1
+        arr[i].name = nm.encode() if isinstance(nm, str) else nm
+        arr[i].seq_len = int(ln)
+        arr[i].start_ofs = ofs
+        arr[i].end_ofs = ofs + int(ln) - 1
+        ofs += int(ln) + 1
+    return arr
+
+
+class SfxIndex:
+    """HBM-resident index: the counterpart of an opened CSfxArray (libkit4b/SfxArray.h:524)."""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+        self._keep = []
+
+    # -- construction -----------------------------------------------------------------------------------------
+    @staticmethod
+    def _check_open(rc, h):
+        if rc != 0:
+            raise K4Error(rc, lib().k4_global_error().decode())
+        return SfxIndex(h.value)
+
+    @classmethod
+    def open(cls, path, device=0, kmer_k=0):
+        h = C.c_void_p()
+        return cls._check_open(lib().k4_open(path.encode(), device, kmer_k, C.byref(h)), h)
+
+    @classmethod
+    def from_host(cls, seq, sa_bytes, el_size, entries, dataset="syn", device=0, kmer_k=0):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        sa_bytes = np.ascontiguousarray(sa_bytes, dtype=np.uint8)
+        h = C.c_void_p()
+        rc = lib().k4_open_host(len(seq), el_size, seq.ctypes.data, sa_bytes.ctypes.data, len(entries), entries,
+                                dataset.encode(), device, kmer_k, C.byref(h))
+        return cls._check_open(rc, h)
+
+    @classmethod
+    def from_device(cls, concat_len, el_size, d_seq_ptr, d_sa_ptr, entries, dataset="syn", device=0, kmer_k=0,
+                    adopt_sa=True, keep=()):
+        h = C.c_void_p()
+        rc = lib().k4_open_device(concat_len, el_size, d_seq_ptr, d_sa_ptr, 1 if adopt_sa else 0, len(entries),
+                                  entries, dataset.encode(), device, kmer_k, C.byref(h))
+        ix = cls._check_open(rc, h)
+        ix._keep = list(keep)  # tensors whose storage the index adopted
+        return ix
+
+    def close(self):
+        if self.h:
+            lib().k4_close(self.h)
+            self.h = C.c_void_p()
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise K4Error(rc, lib().k4_last_error(self.h).decode())
+        return rc
+
+    # -- accessors ----------------------------------------------------------------------------------------------
+    def info(self):
+        o = Info()
+        self._ck(lib().k4_info(self.h, C.byref(o)))
+        return {f[0]: (getattr(o, f[0]).decode() if f[0] == "dataset" else getattr(o, f[0])) for f in Info._fields_}
+
+    def entry(self, entry_id):
+        e = Entry()
+        self._ck(lib().k4_get_entry(self.h, entry_id, C.byref(e)))
+        return dict(entry_id=e.entry_id, name=e.name.decode(), seq_len=e.seq_len, start_ofs=e.start_ofs,
+                    end_ofs=e.end_ofs)
+
+    def get_ident(self, name):
+        return lib().k4_get_ident(self.h, name.encode())
+
+    def set_max_iter(self, it):
+        return lib().k4_set_max_iter(self.h, it)
+
+    def get_seq(self, entry_id, loci, length):
+        out = np.zeros(length, dtype=np.uint8)
+        n = lib().k4_get_seq(self.h, entry_id, loci, out.ctypes.data, length)
+        return out[:n]
+
+    def write_sfx(self, path):
+        self._ck(lib().k4_write_sfx(self.h, path.encode()))
+
+    def min_core_len(self, pmode=0):
+        s = C.c_int(0)
+        m = self._ck(lib().k4_min_core_len(self.h, pmode, C.byref(s)))
+        return m, s.value
+
+    def counters(self):
+        c = Counters()
+        self._ck(lib().k4_get_counters(self.h, C.byref(c)))
+        return {f[0]: getattr(c, f[0]) for f in Counters._fields_}
+
+    def reset_counters(self):
+        self._ck(lib().k4_reset_counters(self.h))
+
+    def reserve(self, max_reads, max_read_len, max_hits):
+        self._ck(lib().k4_reserve(self.h, max_reads, max_read_len, max_hits))
+
+    # -- the hot path (host buffers) ----------------------------------------------------------------------------
+    def align_reads_batch(self, reads, tot_mm, core_len, core_delta, max_slides, min_core_len=0, mm_delta=1,
+                          strand=STRAND_BOTH, max_hits=1):
+        """CSfxArray::AlignReads (libkit4b/SfxArray.h:614) for a batch of fresh reads."""
+        cat, offs, lens = _flatten(reads)
+        n = len(lens)
+        p = AlignParams(tot_mm, core_len, core_delta, max_slides, min_core_len, mm_delta, strand, max_hits)
+        rslt = np.zeros(n, np.int32); inst = np.zeros(n, np.int32); low = np.zeros(n, np.int32)
+        nxt = np.zeros(n, np.int32)
+        hits = np.zeros((n, max_hits), dtype=HIT_DTYPE)
+        self._ck(lib().k4_align_reads_batch(self.h, C.byref(p), n, cat.ctypes.data, offs.ctypes.data,
+                                            lens.ctypes.data, rslt.ctypes.data, inst.ctypes.data, low.ctypes.data,
+                                            nxt.ctypes.data, hits.ctypes.data))
+        return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits)
+
+    def kalign_batch(self, reads, max_subs=5, min_edit_dist=1, max_ns=1, pmode=0, strand=STRAND_BOTH, max_ml=1,
+                     pe_mode=0, min_core_len=0, max_num_slides=0):
+        """CKAligner::AlignRead (ngskit4b/KAligner.cpp:9583) for a batch."""
+        cat, offs, lens = _flatten(reads)
+        n = len(lens)
+        p = KalignParams(max_subs, min_edit_dist, max_ns, pmode, strand, max_ml, pe_mode, min_core_len,
+                         max_num_slides)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        hits = np.zeros((n, max(1, max_ml)), dtype=HIT_DTYPE)
+        self._ck(lib().k4_kalign_batch(self.h, C.byref(p), n, cat.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                                       out.ctypes.data, hits.ctypes.data))
+        return dict(out=out, hits=hits)
+
+    # -- the hot path (device buffers; pointers are ints, e.g. torch.Tensor.data_ptr()) -------------------------
+    def kalign_batch_dev(self, params, n, max_read_len, d_reads, d_offs, d_lens, d_out, d_hits, stream=0):
+        self._ck(lib().k4_kalign_batch_dev(self.h, C.byref(params), n, max_read_len, d_reads, d_offs, d_lens, d_out,
+                                           d_hits, stream))
+
+    def align_reads_batch_dev(self, params, n, max_read_len, d_reads, d_offs, d_lens, d_rslt, d_inst, d_low, d_nxt,
+                              d_hits, stream=0):
+        self._ck(lib().k4_align_reads_batch_dev(self.h, C.byref(params), n, max_read_len, d_reads, d_offs, d_lens,
+                                                d_rslt, d_inst, d_low, d_nxt, d_hits, stream))
+
+
+def build_sa_device(concat_len, el_size, d_seq_ptr, d_sa_ptr, device=0):
+    """GPU suffix sort (CSfxArray::Finalise -> QSortSeq, SfxArray.cpp:1758,9739)."""
+    rc = lib().k4_build_sa_device(concat_len, el_size, d_seq_ptr, d_sa_ptr, device)
+    if rc != 0:
+        raise K4Error(rc, lib().k4_global_error().decode())

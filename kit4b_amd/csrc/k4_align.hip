@@ -1,0 +1,886 @@
+// kit4b_amd/csrc/k4_align.hip -- the hot path: batched CSfxArray::AlignReads / CKAligner::AlignRead on gfx950.
+//
+// Reference semantics reproduced (bit-identical results are the contract):
+//   CSfxArray::AlignReads           libkit4b/SfxArray.cpp:7838-7933   phase escalation
+//   CSfxArray::LocateCoreMultiples  libkit4b/SfxArray.cpp:5806-6369   cores -> SA run -> dedupe -> Hamming extension -> fold
+//   CSfxArray::LocateFirstExact     libkit4b/SfxArray.cpp:7938-8058   lowest SA index whose suffix starts with the core
+//   CKAligner::AlignRead            ngskit4b/KAligner.cpp:9583-10105  per-read parameters + NAR classification
+//
+// Kernels:
+//   k4k_pack_reads   etSeqBase bytes -> 2-bit words (forward and reverse complement), per-read N / symbol flags
+//   k4k_align_fast   one lane per read.  Seed lookup = one k-mer table fetch + a short lower-bound search whose every
+//                    probe fetches the whole read-aligned reference window, so the same registers give the core
+//                    comparison (ordering) and the Hamming distance (XOR + popcount).  Reads that meet anything the
+//                    2-bit form cannot express (N, a separator in a window) or more than K4_DEDUP_CAP candidates in
+//                    one strand pass are handed to ...
+//   k4k_align_slow   ... the general kernel: a literal lane-per-read restatement over exact 4-bit symbols with a
+//                    hash-set dedupe in HBM scratch.
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include "k4_device.h"
+
+#define K4_NEED_SLOW (-100)
+#define K4_RF_HAS_N 1u
+#define K4_RF_INVALID 2u
+#define K4_RF_TOOLONG 4u
+
+struct K4AlignArgs {
+  K4DevIndex ix;
+  const uint8_t* reads;
+  const uint64_t* offs;
+  const uint32_t* lens;
+  int64_t n_reads;
+  int64_t cap_reads;  // row pitch of `packed`
+  int32_t mode;       // 0: AlignReads with uniform parameters, 1: CKAligner::AlignRead
+  k4_align_params ap;
+  k4_kalign_params kp;  // min_core_len / max_num_slides already resolved
+  int32_t* rslt;
+  int32_t* inst;
+  int32_t* low;
+  int32_t* nxt;
+  k4_read_result* rr;
+  k4_hit* hits;
+  int32_t max_hits;
+  const uint64_t* packed;
+  uint32_t* rflags;
+  uint32_t* slow_list;
+  uint32_t* ctl;
+  unsigned long long* counters;
+  uint8_t* slow_probe;
+  uint64_t* slow_hash;
+  uint32_t* slow_gen;
+  uint32_t slow_hash_cap;
+  int32_t nw;
+};
+
+struct K4ReadParams {
+  int tot_mm, core_len, core_delta, max_slides, mm_delta, strand, max_hits;
+};
+
+struct K4State {
+  int inst, low, nxt, cur_hit;
+};
+
+// CKAligner::AlignRead parameter derivation, ngskit4b/KAligner.cpp:9662-9672
+K4_DEV K4ReadParams k4d_read_params(const K4AlignArgs& a, int len) {
+  K4ReadParams p;
+  if (a.mode == 0) {
+    p.tot_mm = a.ap.tot_mm; p.core_len = a.ap.core_len; p.core_delta = a.ap.core_delta;
+    p.max_slides = a.ap.max_core_slides; p.mm_delta = a.ap.mm_delta; p.strand = a.ap.strand;
+    p.max_hits = a.ap.max_hits;
+    return p;
+  }
+  int mm = a.kp.max_subs == 0 ? 0 : (int)(0.5 + (len * a.kp.max_subs) / 100.0);
+  if (a.kp.max_subs != 0 && mm < 1) mm = 1;
+  if (mm > 63) mm = 63;  // cMaxTotAllowedSubs, KAligner.h:38
+  int cl = len / (a.kp.min_edit_dist == 1 ? mm + 1 : mm + 2);
+  if (cl < a.kp.min_core_len) cl = a.kp.min_core_len;
+  int sl = (a.kp.max_num_slides * len + 99) / 100;
+  if (sl < 1) sl = 1;
+  int cd = len / sl - 1;
+  if (cd < cl) cd = cl;
+  p.tot_mm = mm; p.core_len = cl; p.core_delta = cd; p.max_slides = sl;
+  p.mm_delta = a.kp.min_edit_dist; p.strand = a.kp.strand; p.max_hits = a.kp.max_ml < 1 ? 1 : a.kp.max_ml;
+  return p;
+}
+
+K4_DEV void k4d_store_hit(k4_hit* h, uint32_t chrom_id, uint32_t loci, int len, char strand, int mm) {
+  uint4 v;
+  v.x = chrom_id;
+  v.y = loci;
+  v.z = (uint32_t)(len & 0xFFFF) | ((uint32_t)(uint8_t)strand << 16) | ((uint32_t)(mm & 0xFF) << 24);
+  v.w = 0;
+  *reinterpret_cast<uint4*>(h) = v;
+}
+
+// fold of one accepted candidate into (LowMMCnt, NxtLowMMCnt, LowHitInstances, pHits), SfxArray.cpp:6264-6312
+K4_DEV void k4d_fold(K4State& st, int mm, k4_hit* hits, int max_hits, uint32_t chrom_id, uint32_t loci, int len,
+                     char strand) {
+  if (mm < st.low) {
+    st.cur_hit = 0;
+    st.inst = 1;
+    st.nxt = st.low;
+    st.low = mm;
+    k4d_store_hit(&hits[0], chrom_id, loci, len, strand, mm);
+  } else if (mm == st.low) {
+    st.inst += 1;
+    if (st.cur_hit != -1 && st.inst <= max_hits) {
+      st.cur_hit += 1;
+      if (st.cur_hit < max_hits) k4d_store_hit(&hits[st.cur_hit], chrom_id, loci, len, strand, mm);
+    }
+  } else if (mm < st.nxt)
+    st.nxt = mm;
+}
+
+// result code of one LocateCoreMultiples call, SfxArray.cpp:6345-6368 (p_* = values on entry, after initialisation)
+K4_DEV int k4d_lcm_result(int p_inst, int p_low, int* p_nxt, const K4State& st, int mm_delta, int max_hits,
+                          int* o_inst, int* o_low) {
+  if (p_low == st.low && p_inst == st.inst) {
+    if (*p_nxt > st.nxt) {
+      *p_nxt = st.nxt;
+      if (st.nxt - p_low < mm_delta) return K4_HR_MMDELTA;
+      return K4_HR_RMMDELTA;
+    }
+    return K4_HR_NONE;
+  }
+  *o_low = st.low; *o_inst = st.inst; *p_nxt = st.nxt;
+  if (st.inst >= 1 && (st.nxt - st.low) < mm_delta) return K4_HR_MMDELTA;
+  if (st.inst > max_hits) return K4_HR_HITINSTS;
+  return K4_HR_HITS;
+}
+
+// writes the per-read outputs; zeroes hit slots that do not hold a reported instance
+K4_DEV void k4d_finalize(const K4AlignArgs& a, int64_t i, int len, const K4ReadParams& rp, int rslt, int inst,
+                         int low, int nxt) {
+  k4_hit* hits = a.hits + i * a.max_hits;
+  int nvalid = (rslt == K4_HR_HITS || rslt == K4_HR_MMDELTA || rslt == K4_HR_HITINSTS) ? min(inst, rp.max_hits) : 0;
+  for (int q = nvalid; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&hits[q]) = make_uint4(0, 0, 0, 0);
+  if (a.mode == 0) {
+    a.rslt[i] = rslt; a.inst[i] = inst; a.low[i] = low; a.nxt[i] = nxt;
+    return;
+  }
+  // CKAligner::AlignRead classification, KAligner.cpp:9854,9890-10079 (SE default MLMode / PE)
+  k4_read_result r;
+  if (inst > rp.max_hits) inst = rp.max_hits + 1;
+  r.hit_rslt = rslt; r.inst = inst; r.low_mm = low; r.nxt_mm = nxt; r.nar = K4_NAR_NOHIT; r.num_hits = 0;
+  switch (rslt) {
+    case K4_HR_NONE: r.inst = 0; r.low_mm = 0; r.nxt_mm = 0; break;
+    case K4_HR_HITS:
+      if (!a.kp.pe_mode || inst == 1) { r.nar = K4_NAR_ACCEPTED; r.num_hits = 1; }
+      else { r.nar = K4_NAR_MULTIALIGN; r.num_hits = inst; }
+      break;
+    case K4_HR_MMDELTA: r.nar = K4_NAR_MMDELTA; break;
+    case K4_HR_HITINSTS: r.nar = K4_NAR_MULTIALIGN; break;
+    default: break;
+  }
+  (void)len;
+  a.rr[i] = r;
+}
+
+K4_DEV void k4d_push_slow(const K4AlignArgs& a, int64_t i) {
+  uint32_t slot = atomicAdd(&a.ctl[0], 1u);
+  a.slow_list[slot] = (uint32_t)i;
+}
+
+// ==== read packing =================================================================================================
+// thread t = read * nw + w builds forward word w and reverse-complement word w (32 bases each, MSB-first)
+__global__ void __launch_bounds__(256) k4k_pack_reads(K4AlignArgs a, uint64_t* __restrict__ packed) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t i = t / a.nw;
+  int w = (int)(t - i * a.nw);
+  if (i >= a.n_reads) return;
+  int len = (int)a.lens[i];
+  const uint8_t* src = a.reads + a.offs[i];
+  uint64_t fw = 0, rc = 0;
+  uint32_t nN = 0, fl = 0;
+  if (len > K4_MAX_FAST_READ_LEN || len < 1) {
+    fl |= K4_RF_TOOLONG;
+    if (w == 0) {  // the general kernel needs the N count / symbol check too
+      for (int j = 0; j < len; j++) {
+        uint32_t b = src[j] & 7;
+        if (b == 4) nN++; else if (b > 4) fl |= K4_RF_INVALID;
+      }
+    }
+  } else {
+    for (int j = 0; j < 32; j++) {
+      int q = w * 32 + j;
+      uint32_t b = 0, c = 0;
+      if (q < len) {
+        b = src[q] & 7;
+        if (b == 4) { nN++; b = 0; } else if (b > 4) { fl |= K4_RF_INVALID; b = 0; }
+        c = src[len - 1 - q] & 7;
+        c = c > 3 ? 0 : 3 - c;
+      }
+      fw = (fw << 2) | b;
+      rc = (rc << 2) | c;
+    }
+  }
+  if (nN) fl |= K4_RF_HAS_N;
+  packed[(int64_t)(0 * a.nw + w) * a.cap_reads + i] = fw;
+  packed[(int64_t)(1 * a.nw + w) * a.cap_reads + i] = rc;
+  if (fl) atomicOr(&a.rflags[i], fl);             // low byte: flags (OR), bits 8..: number of N (ADD); disjoint fields
+  if (nN) atomicAdd(&a.rflags[i], nN << 8);
+}
+
+// ==== fast kernel ==================================================================================================
+template <int NCH>
+struct K4Lane {
+  const uint64_t* rd;  // LDS: word (s*NW + c) of this lane's read at rd[(s*NW + c) * 256]
+  uint32_t* ded;       // LDS: dedupe slot q at ded[q * 256]
+  static constexpr int NW = NCH + 1;
+  K4_DEV uint64_t word(int s, int c) const { return rd[(s * NW + c) * 256]; }
+  K4_DEV uint64_t chunk_at(int s, int o) const {  // 32 bases of strand s starting at base o
+    int w = o >> 5, sh = 2 * (o & 31);
+    uint64_t hi = word(s, w);
+    if (!sh) return hi;
+    return (hi << sh) | (word(s, w + 1) >> (64 - sh));
+  }
+};
+
+struct K4Probe {
+  int cmp;   // core vs suffix: -1 probe<target, 0 match, 1 probe>target
+  int mm;    // Hamming distance of the whole read against the read-aligned window
+  bool exc;  // window touches a non-ACGT symbol
+};
+
+// One suffix-array probe: the suffix at p is where core (offset o, length cl) of strand s would sit, so the read would
+// sit at left = p - o.  Fetch the window [left, left+len) once; derive both the core ordering and the distance.
+template <int NCH>
+K4_DEV K4Probe k4d_probe(const K4DevIndex& ix, const K4Lane<NCH>& ln, int s, int o, int cl, int len, uint64_t p) {
+  K4Probe r;
+  int64_t left = (int64_t)p - o;
+  r.exc = k4d_any_exc(ix, left, left + len);
+  r.cmp = 0;
+  r.mm = 0;
+  const uint32_t* wp = ix.ref2 + (left >> 4);
+  uint32_t sh = (uint32_t)(left & 15) * 2;
+  uint32_t wv[2 * NCH + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * NCH + 1; j++) wv[j] = (32 * (j / 2) < len + 32) ? wp[j] : 0u;
+  bool decided = false;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if (32 * c < len) {
+      uint64_t hi = ((uint64_t)wv[2 * c] << 32) | wv[2 * c + 1];
+      uint64_t refc = sh ? (hi << sh) | (wv[2 * c + 2] >> (32 - sh)) : hi;
+      uint64_t rdc = ln.word(s, c);
+      uint64_t x = rdc ^ refc;
+      r.mm += (int)k4d_mm_count(x & k4d_range_mask(0, len - 32 * c));
+      uint64_t cm = k4d_range_mask(o - 32 * c, o + cl - 32 * c);
+      if (!decided && (x & cm)) {
+        r.cmp = (rdc & cm) < (refc & cm) ? -1 : 1;
+        decided = true;
+      }
+    }
+  }
+  return r;
+}
+
+// One LocateCoreMultiples call for one read (SfxArray.cpp:5806-6369), fast form.  Returns tHRslt or K4_NEED_SLOW.
+template <int EL, int NCH>
+K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, int allow_mm, int cl, int core_delta,
+                        const K4ReadParams& rp, int* p_inst, int* p_low, int* p_nxt, k4_hit* hits,
+                        uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand) {
+  const K4DevIndex& ix = a.ix;
+  if (*p_inst > rp.max_hits && *p_low == 0) return K4_HR_HITINSTS;  // :5889-5895 (unreachable for fresh reads)
+  if (*p_inst >= 1 && *p_low == 0 && (*p_nxt - *p_low) < rp.mm_delta) return K4_HR_MMDELTA;
+  K4State st;
+  if (*p_inst <= 0 || *p_low < 0 || *p_nxt < 0) {
+    st.inst = *p_inst = 0;
+    st.low = *p_low = allow_mm + rp.mm_delta + 1;
+    st.nxt = *p_nxt = st.low;
+  } else {
+    st.inst = *p_inst; st.low = *p_low; st.nxt = *p_nxt;
+  }
+  st.cur_hit = st.inst < rp.max_hits ? st.inst : -1;
+  const int max_iter = ix.max_iter;
+  const int64_t n = (int64_t)ix.n;
+  const int kk = min((int)ix.k, cl);
+  const int tshift = 2 * ((int)ix.k - kk);
+  int s = rp.strand == K4_STRAND_CRICK ? 1 : 0;
+  const int s_end = rp.strand == K4_STRAND_WATSON ? 0 : 1;
+  bool stop = false;
+  for (; s <= s_end && !stop; s++) {
+    const char strand_c = s ? '-' : '+';
+    int n_ded = 0;
+    int cur_delta = core_delta;
+    int slides = 0;
+    for (int o = 0; slides < rp.max_slides && o <= len - cl && cur_delta > cl / 3; slides++, o += cur_delta) {
+      if (o + cl + cur_delta > len) cur_delta = len - (o + cl);
+      n_lookup++;
+      // ---- seed lookup: k-mer table interval, then lower bound inside it -------------------------------------
+      uint64_t code = ln.chunk_at(s, o) >> (64 - 2 * kk);
+      int64_t lo = (int64_t)k4d_ktab_at(ix, code << tshift);
+      int64_t hi = (int64_t)k4d_ktab_at(ix, (code + 1) << tshift) - 1;
+      int64_t found = -1;
+      uint64_t fpos = 0;
+      int fmm = 0;
+      while (lo <= hi) {
+        int64_t mid = (lo + hi) >> 1;
+        uint64_t p = k4d_sa_at<EL>(ix, (uint64_t)mid);
+        K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p);
+        n_probe++;
+        if (pr.exc) return K4_NEED_SLOW;
+        if (pr.cmp > 0) lo = mid + 1;
+        else {
+          if (pr.cmp == 0) { found = mid; fpos = p; fmm = pr.mm; }
+          hi = mid - 1;
+        }
+      }
+      if (found != lo) continue;  // no suffix starts with this core
+      // ---- walk the run of equal cores in SA order, :5971-6321 ---------------------------------------------------
+      int64_t idx = found;
+      uint64_t p = fpos;
+      int mm = fmm;
+      int iter = 0;
+      bool first = true;
+      while (!max_iter || iter < max_iter) {
+        if (!first) {
+          if (idx + 1 >= n) break;
+          uint64_t p2 = k4d_sa_at<EL>(ix, (uint64_t)idx + 1);
+          if ((int64_t)p2 + cl > n) break;
+          K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p2);
+          n_probe++;
+          if (pr.exc) return K4_NEED_SLOW;
+          if (pr.cmp != 0) break;
+          idx += 1; p = p2; mm = pr.mm;
+        }
+        first = false;
+        if (p < (uint64_t)o) continue;
+        uint64_t left = p - (uint64_t)o;
+        int e = k4d_map_entry(ix, left);
+        if (e < 0 || left + (uint64_t)len - 1 > ix.ent_end[e]) continue;
+        uint32_t targ_id = (uint32_t)(1 + p - (uint32_t)o);  // :6037 (truncation is the reference's)
+        bool dup = false;
+        for (int q = 0; q < n_ded; q++) dup |= (ln.ded[q * 256] == targ_id);
+        if (dup) continue;
+        if (n_ded >= K4_DEDUP_CAP) return K4_NEED_SLOW;
+        ln.ded[n_ded * 256] = targ_id;
+        n_ded++;
+        iter++;
+        n_cand++;
+        if (mm > allow_mm || mm >= st.nxt) continue;  // the two early-outs of :6200-6261
+        k4d_fold(st, mm, hits, rp.max_hits, ix.ent_id[e], (uint32_t)(left - ix.ent_start[e]), len, strand_c);
+        if (st.inst > rp.max_hits && st.low == 0) break;
+      }
+      if (st.inst > rp.max_hits && st.low == 0) { stop = true; break; }
+    }
+  }
+  return k4d_lcm_result(*p_inst, *p_low, p_nxt, st, rp.mm_delta, rp.max_hits, p_inst, p_low);
+}
+
+template <int EL, int NCH>
+__global__ void __launch_bounds__(256) k4k_align_fast(K4AlignArgs a) {
+  extern __shared__ uint64_t lds[];
+  constexpr int NW = NCH + 1;
+  const int tid = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  uint32_t n_lookup = 0, n_probe = 0, n_cand = 0, n_slow = 0, n_bases = 0;
+  if (i < a.n_reads) {
+    K4Lane<NCH> ln;
+    ln.rd = lds + tid;
+    ln.ded = reinterpret_cast<uint32_t*>(lds + 2 * NW * 256) + tid;
+    uint64_t* mine = lds + tid;
+#pragma unroll
+    for (int w = 0; w < 2 * NW; w++) mine[w * 256] = (w % NW) < a.nw ? a.packed[(int64_t)((w / NW) * a.nw + (w % NW)) * a.cap_reads + i] : 0ull;
+    const uint32_t fl = a.rflags[i];
+    const int len = (int)a.lens[i];
+    n_bases = (uint32_t)len;
+    const K4ReadParams rp = k4d_read_params(a, len);
+    bool slow = (fl & (K4_RF_HAS_N | K4_RF_TOOLONG | K4_RF_INVALID)) != 0 || len > 32 * NCH;
+    if (a.mode == 1) {  // AlignRead: too many Ns / a symbol above N -> NAR Ns, KAligner.cpp:9618-9640
+      int max_ns = 0;
+      if (a.kp.max_ns) max_ns = max((len * a.kp.max_ns) / 100, a.kp.max_ns);
+      if ((fl & K4_RF_INVALID) || (int)(fl >> 8) > max_ns) {
+        k4_read_result r = {K4_HR_SEQERRS, 0, 0, 0, K4_NAR_NS, 0};
+        a.rr[i] = r;
+        for (int q = 0; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&a.hits[i * a.max_hits + q]) = make_uint4(0, 0, 0, 0);
+        slow = false;
+        goto done;
+      }
+    }
+    if (rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits) slow = true;  // let the general kernel decide
+    if (!slow) {
+      k4_hit* hits = a.hits + i * a.max_hits;
+      int inst = 0, low = 0, nxt = 0, rslt = 0, allow = 0;
+      if (rp.tot_mm > 0) {  // AlignReads phase escalation, SfxArray.cpp:7867-7881
+        for (allow = 0; allow <= rp.tot_mm; allow++) {
+          int cl = len / (allow + rp.mm_delta);
+          if (cl <= rp.core_len) break;
+          rslt = k4d_lcm_fast<EL, NCH>(a, ln, len, allow, cl, cl, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
+          if (rslt != 0) break;
+        }
+      }
+      if (rslt == 0 && allow <= rp.tot_mm)  // final phase, :7885-7891
+        rslt = k4d_lcm_fast<EL, NCH>(a, ln, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, &low, &nxt, hits,
+                                     n_lookup, n_probe, n_cand);
+      if (rslt == K4_NEED_SLOW) slow = true;
+      else k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
+    }
+    if (slow) {
+      k4d_push_slow(a, i);
+      n_slow = 1;
+      n_lookup = n_probe = n_cand = 0;  // the general kernel recounts this read
+    }
+  }
+done:
+  // per-wave tallies -> one atomic per counter per wave
+  {
+    unsigned long long v[6] = {i < a.n_reads ? 1ull : 0ull, n_lookup, n_probe, n_cand, n_slow, n_bases};
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      unsigned long long x = v[q];
+      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+      if ((tid & 63) == 0 && x) atomicAdd(&a.counters[q], x);
+    }
+  }
+}
+
+// ==== general kernel =================================================================================================
+struct K4Slow {
+  uint8_t* probe;   // this lane's probe bytes (mutable: reverse-complemented in place like the reference)
+  uint64_t* hash;   // (generation << 32 | TargSeqID) open addressing
+  uint32_t cap;     // power of two
+  uint32_t gen;
+};
+
+// CmpProbeTarg, SfxArray.cpp:2508-2525, on exact symbols
+K4_DEV int k4d_cmp_slow(const K4DevIndex& ix, const uint8_t* probe, uint64_t pos, int len) {
+  for (int j = 0; j < len; j++) {
+    uint32_t t = pos + j < ix.n ? k4d_ref_base(ix, pos + j) : 7u;
+    if (t == 7) return -1;
+    uint32_t p = probe[j] & 0x0f;
+    if (p > t) return 1;
+    if (p < t) return -1;
+  }
+  return 0;
+}
+
+K4_DEV void k4d_revcomp_slow(uint8_t* s, int len) {  // CSeqTrans::ReverseComplement, SeqTrans.cpp:497-545
+  for (int j = 0; j < len; j++) {
+    uint8_t b = s[j];
+    if (b <= 3) s[j] = 3 - b;
+    else if (b == 4 || b == 5 || b == 6) continue;
+    else break;
+  }
+  for (int x = 0, y = len - 1; x < y; x++, y--) { uint8_t t = s[x]; s[x] = s[y]; s[y] = t; }
+}
+
+// LocateFirstExact (SfxArray.cpp:7938-8058): index+1 of the lowest matching suffix or 0
+template <int EL>
+K4_DEV int64_t k4d_first_exact_slow(const K4DevIndex& ix, const uint8_t* core, int cl, uint32_t& n_probe) {
+  int64_t lo = 0, hi = (int64_t)ix.n - 1;
+  int kk = min((int)ix.k, cl);
+  bool acgt = true;
+  uint64_t code = 0;
+  for (int j = 0; j < kk; j++) {
+    uint32_t b = core[j] & 0x0f;
+    if (b > 3) { acgt = false; break; }
+    code = (code << 2) | b;
+  }
+  if (acgt) {
+    int sh = 2 * ((int)ix.k - kk);
+    lo = (int64_t)k4d_ktab_at(ix, code << sh);
+    hi = (int64_t)k4d_ktab_at(ix, (code + 1) << sh) - 1;
+  }
+  int64_t found = -1;
+  while (lo <= hi) {
+    int64_t mid = (lo + hi) >> 1;
+    int c = k4d_cmp_slow(ix, core, k4d_sa_at<EL>(ix, (uint64_t)mid), cl);
+    n_probe++;
+    if (c > 0) lo = mid + 1;
+    else {
+      if (c == 0) found = mid;
+      hi = mid - 1;
+    }
+  }
+  return found == lo ? found + 1 : 0;
+}
+
+K4_DEV bool k4d_hash_insert(K4Slow& sc, uint32_t id) {  // true when id is new in this strand pass
+  uint64_t key = ((uint64_t)sc.gen << 32) | id;
+  uint32_t h = (id * 2654435761u) & (sc.cap - 1);
+  for (;;) {
+    uint64_t v = sc.hash[h];
+    if ((uint32_t)(v >> 32) != sc.gen) { sc.hash[h] = key; return true; }
+    if (v == key) return false;
+    h = (h + 1) & (sc.cap - 1);
+  }
+}
+
+template <int EL>
+K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm, int cl, int core_delta,
+                        const K4ReadParams& rp, int* p_inst, int* p_low, int* p_nxt, k4_hit* hits,
+                        uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand) {
+  const K4DevIndex& ix = a.ix;
+  if (*p_inst > rp.max_hits && *p_low == 0) return K4_HR_HITINSTS;
+  if (*p_inst >= 1 && *p_low == 0 && (*p_nxt - *p_low) < rp.mm_delta) return K4_HR_MMDELTA;
+  K4State st;
+  if (*p_inst <= 0 || *p_low < 0 || *p_nxt < 0) {
+    st.inst = *p_inst = 0;
+    st.low = *p_low = allow_mm + rp.mm_delta + 1;
+    st.nxt = *p_nxt = st.low;
+  } else {
+    st.inst = *p_inst; st.low = *p_low; st.nxt = *p_nxt;
+  }
+  st.cur_hit = st.inst < rp.max_hits ? st.inst : -1;
+  const int max_iter = ix.max_iter;
+  const int64_t n = (int64_t)ix.n;
+  int strand = rp.strand;
+  char cur_strand = '+';
+  uint8_t* probe = sc.probe;
+  if (strand == K4_STRAND_CRICK) { k4d_revcomp_slow(probe, len); cur_strand = '-'; }
+  do {
+    int cur_delta = core_delta;
+    int slides = 0;
+    uint32_t n_nodes = 0;
+    sc.gen++;
+    // cMaxNumIdentNodes (SfxArray.h:15); additionally bounded by the scratch table so an insert always terminates
+    const uint32_t node_cap = min((uint32_t)K4_MAX_IDENT_NODES, sc.cap / 2 - 1);
+    for (int o = 0; slides < rp.max_slides && o <= len - cl && cur_delta > cl / 3 && n_nodes < node_cap;
+         slides++, o += cur_delta) {
+      if (o + cl + cur_delta > len) cur_delta = len - (o + cl);
+      n_lookup++;
+      int64_t t = k4d_first_exact_slow<EL>(ix, probe + o, cl, n_probe);
+      if (t == 0) continue;
+      t -= 1;
+      int iter = 0;
+      bool first = true;
+      while (!max_iter || iter < max_iter) {
+        if (n_nodes >= node_cap) break;
+        if (!first) {
+          if (t + 1 >= n) break;
+          uint64_t p2 = k4d_sa_at<EL>(ix, (uint64_t)t + 1);
+          if ((int64_t)p2 + cl > n) break;
+          n_probe++;
+          if (k4d_cmp_slow(ix, probe + o, p2, cl) != 0) break;
+          t += 1;
+        }
+        first = false;
+        uint64_t pos = k4d_sa_at<EL>(ix, (uint64_t)t);
+        if (pos < (uint64_t)o) continue;
+        uint64_t left = pos - (uint64_t)o;
+        int e = k4d_map_entry(ix, left);
+        if (e < 0 || left + (uint64_t)len - 1 > ix.ent_end[e]) continue;
+        uint32_t targ_id = (uint32_t)(1 + pos - (uint32_t)o);
+        if (!k4d_hash_insert(sc, targ_id)) continue;
+        n_nodes++;
+        iter++;
+        n_cand++;
+        int mm = 0, j;
+        for (j = 0; j < len; j++) {  // :6200-6261
+          uint32_t tv = k4d_ref_base(ix, left + j), pv = probe[j] & 0x0f;
+          if (tv == 7) break;
+          if (pv == tv) continue;
+          if (++mm > allow_mm) break;
+          if (mm >= st.nxt) break;
+        }
+        if (j != len) continue;
+        k4d_fold(st, mm, hits, rp.max_hits, ix.ent_id[e], (uint32_t)(left - ix.ent_start[e]), len, cur_strand);
+        if (st.inst > rp.max_hits && st.low == 0) break;
+      }
+      if (st.inst > rp.max_hits && st.low == 0) { strand = 3; break; }
+    }
+    if (cur_strand == '+' && strand == K4_STRAND_BOTH) {
+      k4d_revcomp_slow(probe, len);
+      cur_strand = '-';
+      strand = K4_STRAND_CRICK;
+    } else
+      strand = 3;
+  } while (!(st.inst > rp.max_hits && st.low == 0) && strand != 3);
+  if (cur_strand == '-') k4d_revcomp_slow(probe, len);
+  return k4d_lcm_result(*p_inst, *p_low, p_nxt, st, rp.mm_delta, rp.max_hits, p_inst, p_low);
+}
+
+// persistent lanes pull read ids from the slow list until it is drained (every lane reaches the exit test)
+template <int EL>
+__global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_lanes) {
+  const uint32_t lane = blockIdx.x * 64 + threadIdx.x;
+  uint32_t n_lookup = 0, n_probe = 0, n_cand = 0;
+  if (lane < n_lanes) {
+    K4Slow sc;
+    sc.probe = a.slow_probe + (size_t)lane * K4_MAX_READ_LEN;
+    sc.hash = a.slow_hash + (size_t)lane * a.slow_hash_cap;
+    sc.cap = a.slow_hash_cap;
+    sc.gen = a.slow_gen[lane];
+    const uint32_t total = a.ctl[0];
+    for (;;) {
+      uint32_t q = atomicAdd(&a.ctl[1], 1u);
+      if (q >= total) break;
+      const int64_t i = a.slow_list[q];
+      const int len = (int)a.lens[i];
+      const K4ReadParams rp = k4d_read_params(a, len);
+      k4_hit* hits = a.hits + i * a.max_hits;
+      int inst = 0, low = 0, nxt = 0, rslt = 0, allow = 0;
+      if (len < 1 || len > K4_MAX_READ_LEN || rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits) {
+        k4d_finalize(a, i, len, rp, a.mode == 0 ? K4_ERR_PARAMS : K4_HR_FATAL, 0, 0, 0);
+        continue;
+      }
+      const uint8_t* src = a.reads + a.offs[i];
+      for (int j = 0; j < len; j++) sc.probe[j] = src[j] & 7;
+      if (rp.tot_mm > 0) {
+        for (allow = 0; allow <= rp.tot_mm; allow++) {
+          int cl = len / (allow + rp.mm_delta);
+          if (cl <= rp.core_len) break;
+          rslt = k4d_lcm_slow<EL>(a, sc, len, allow, cl, cl, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
+          if (rslt != 0) break;
+        }
+      }
+      if (rslt == 0 && allow <= rp.tot_mm)
+        rslt = k4d_lcm_slow<EL>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, &low, &nxt, hits,
+                                n_lookup, n_probe, n_cand);
+      k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
+    }
+    a.slow_gen[lane] = sc.gen;
+  }
+  unsigned long long v[3] = {n_lookup, n_probe, n_cand};
+  for (int q = 0; q < 3; q++) {
+    unsigned long long x = v[q];
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+    if (threadIdx.x == 0 && x) atomicAdd(&a.counters[1 + q], x);
+  }
+}
+
+// ==== host side ====================================================================================================
+static uint32_t next_pow2(uint64_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+static int nch_for(int max_len) {
+  if (max_len <= 128) return 4;
+  if (max_len <= 160) return 5;
+  if (max_len <= 256) return 8;
+  return 16;
+}
+
+extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len, int32_t max_hits) {
+  if (!ix || max_reads < 0 || max_read_len < 1 || max_hits < 1) return K4_ERR_PARAMS;
+  if (max_read_len > K4_MAX_READ_LEN) return k4_fail(ix, K4_ERR_PARAMS, "read length %d exceeds %d", max_read_len, K4_MAX_READ_LEN);
+  if (max_reads >= 0xFFFFFFF0ll) return k4_fail(ix, K4_ERR_PARAMS, "at most 2^32-16 reads per batch");
+  K4_HIP(ix, hipSetDevice(ix->device));
+  K4Workspace& w = ix->ws;
+  int fast_len = std::min<int>(max_read_len, K4_MAX_FAST_READ_LEN);
+  if (max_reads > w.cap_reads || fast_len > w.cap_len) {
+    int64_t cap = std::max<int64_t>(max_reads, w.cap_reads);
+    cap = (cap + 255) / 256 * 256;
+    int len = std::max(fast_len, w.cap_len);
+    int nw = nch_for(len) + 1;
+    if (w.packed) hipFree(w.packed);
+    if (w.rflags) hipFree(w.rflags);
+    if (w.slow_list) hipFree(w.slow_list);
+    w.packed = nullptr; w.rflags = nullptr; w.slow_list = nullptr;
+    K4_HIP(ix, hipMalloc(&w.packed, (size_t)cap * 2 * nw * 8));
+    K4_HIP(ix, hipMalloc(&w.rflags, (size_t)cap * 4));
+    K4_HIP(ix, hipMalloc(&w.slow_list, (size_t)cap * 4));
+    w.cap_reads = cap;
+    w.cap_len = len;
+  }
+  if (!w.ctl) {
+    K4_HIP(ix, hipMalloc(&w.ctl, 64));
+    K4_HIP(ix, hipMemset(w.ctl, 0, 64));
+  }
+  // general-kernel scratch: sized from MaxIter (hash holds one strand pass: <= MaxIter per core, <= 1,024,000 nodes)
+  uint64_t nodes = ix->d.max_iter ? std::min<uint64_t>((uint64_t)ix->d.max_iter * 48, K4_MAX_IDENT_NODES) : K4_MAX_IDENT_NODES;
+  uint32_t hcap = next_pow2(std::max<uint64_t>(2 * nodes + 2, 1024));
+  if (!w.slow_hash || hcap > w.slow_hash_cap) {
+    if (w.slow_hash) hipFree(w.slow_hash);
+    if (w.slow_probe) hipFree(w.slow_probe);
+    w.slow_hash = nullptr; w.slow_probe = nullptr;
+    w.slow_lanes = hcap > (1u << 19) ? 256 : 1024;
+    K4_HIP(ix, hipMalloc(&w.slow_hash, (size_t)w.slow_lanes * hcap * 8 + (size_t)w.slow_lanes * 4));
+    K4_HIP(ix, hipMemset(w.slow_hash, 0, (size_t)w.slow_lanes * hcap * 8 + (size_t)w.slow_lanes * 4));
+    K4_HIP(ix, hipMalloc(&w.slow_probe, (size_t)w.slow_lanes * K4_MAX_READ_LEN));
+    w.slow_hash_cap = hcap;
+  }
+  w.cap_hits = std::max(w.cap_hits, max_hits);
+  return K4_OK;
+}
+
+template <int EL>
+static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, hipStream_t st) {
+  K4Workspace& w = ix->ws;
+  const int nch = nch_for(std::min(max_len, K4_MAX_FAST_READ_LEN));
+  a.nw = nch_for(w.cap_len) + 1;  // pitch the workspace was sized for
+  if (nch + 1 > a.nw) return k4_fail(ix, K4_ERR_INTERNAL, "workspace not reserved for read length %d", max_len);
+  a.nw = nch + 1;
+  a.cap_reads = w.cap_reads;
+  a.packed = w.packed;
+  a.rflags = w.rflags;
+  a.slow_list = w.slow_list;
+  a.ctl = w.ctl;
+  a.counters = (unsigned long long*)ix->counters;
+  a.slow_probe = w.slow_probe;
+  a.slow_hash = w.slow_hash;
+  a.slow_gen = reinterpret_cast<uint32_t*>(w.slow_hash + (size_t)w.slow_lanes * w.slow_hash_cap);
+  a.slow_hash_cap = w.slow_hash_cap;
+  if (a.n_reads == 0) return K4_OK;
+  K4_HIP(ix, hipMemsetAsync(w.rflags, 0, (size_t)a.n_reads * 4, st));
+  K4_HIP(ix, hipMemsetAsync(w.ctl, 0, 8, st));
+  int64_t pt = a.n_reads * a.nw;
+  hipLaunchKernelGGL(k4k_pack_reads, dim3((unsigned)((pt + 255) / 256)), dim3(256), 0, st, a, w.packed);
+  unsigned grid = (unsigned)((a.n_reads + 255) / 256);
+  size_t lds = (size_t)2 * (nch + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4;
+  switch (nch) {
+    case 4: hipLaunchKernelGGL((k4k_align_fast<EL, 4>), dim3(grid), dim3(256), lds, st, a); break;
+    case 5: hipLaunchKernelGGL((k4k_align_fast<EL, 5>), dim3(grid), dim3(256), lds, st, a); break;
+    case 8: hipLaunchKernelGGL((k4k_align_fast<EL, 8>), dim3(grid), dim3(256), lds, st, a); break;
+    default:
+      K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_fast<EL, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k4k_align_fast<EL, 16>), dim3(grid), dim3(256), lds, st, a);
+      break;
+  }
+  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3((w.slow_lanes + 63) / 64), dim3(64), 0, st, a, w.slow_lanes);
+  K4_HIP(ix, hipGetLastError());
+  return K4_OK;
+}
+
+static int run_dev(k4_index* ix, K4AlignArgs& a, int max_len, void* stream) {
+  K4Workspace& w = ix->ws;
+  if (a.n_reads > w.cap_reads || std::min(max_len, K4_MAX_FAST_READ_LEN) > w.cap_len || a.max_hits > w.cap_hits ||
+      !w.slow_hash)
+    return k4_fail(ix, K4_ERR_PARAMS, "k4_reserve(%lld, %d, %d) must precede the *_dev call", (long long)a.n_reads,
+                   max_len, a.max_hits);
+  a.ix = ix->d;
+  hipStream_t st = (hipStream_t)stream;
+  return ix->d.el == 4 ? launch_all<4>(ix, a, max_len, st) : launch_all<5>(ix, a, max_len, st);
+}
+
+static int check_align_params(k4_index* ix, const k4_align_params* p) {
+  if (!p) return K4_ERR_PARAMS;
+  if (p->tot_mm < 0 || p->tot_mm > 63 || p->core_len < 1 || p->core_delta < 0 || p->max_core_slides < 1 ||
+      p->mm_delta < 1 || p->strand < 0 || p->strand > 2 || p->max_hits < 1 || p->max_hits > 4096)
+    return k4_fail(ix, K4_ERR_PARAMS, "AlignReads parameters out of range");
+  return K4_OK;
+}
+
+extern "C" int k4_align_reads_batch_dev(k4_index* ix, const k4_align_params* p, int64_t n, int32_t max_len,
+                                        const void* d_reads, const void* d_offs, const void* d_lens, void* d_rslt,
+                                        void* d_inst, void* d_low, void* d_nxt, void* d_hits, void* stream) {
+  if (!ix) return K4_ERR_PARAMS;
+  int rc = check_align_params(ix, p);
+  if (rc != K4_OK) return rc;
+  if (n < 0 || (n > 0 && (!d_reads || !d_offs || !d_lens || !d_rslt || !d_inst || !d_low || !d_nxt || !d_hits)))
+    return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  K4AlignArgs a;
+  memset(&a, 0, sizeof(a));
+  a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
+  a.n_reads = n; a.mode = 0; a.ap = *p;
+  a.rslt = (int32_t*)d_rslt; a.inst = (int32_t*)d_inst; a.low = (int32_t*)d_low; a.nxt = (int32_t*)d_nxt;
+  a.hits = (k4_hit*)d_hits; a.max_hits = p->max_hits;
+  return run_dev(ix, a, max_len, stream);
+}
+
+static int resolve_kalign(k4_index* ix, const k4_kalign_params* p, k4_kalign_params* out) {
+  if (!p) return K4_ERR_PARAMS;
+  *out = *p;
+  if (p->max_subs < 0 || p->max_subs > 15 || (p->min_edit_dist != 1 && p->min_edit_dist != 2) || p->max_ns < 0 ||
+      p->strand < 0 || p->strand > 2 || p->max_ml < 1 || p->max_ml > 4096)
+    return k4_fail(ix, K4_ERR_PARAMS, "kalign parameters out of range");
+  int slides = 0;
+  int mcl = k4_min_core_len(ix, p->pmode, &slides);
+  if (out->min_core_len <= 0) out->min_core_len = mcl;
+  if (out->max_num_slides <= 0) out->max_num_slides = slides;
+  return K4_OK;
+}
+
+extern "C" int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len,
+                                   const void* d_reads, const void* d_offs, const void* d_lens, void* d_out,
+                                   void* d_hits, void* stream) {
+  if (!ix) return K4_ERR_PARAMS;
+  K4AlignArgs a;
+  memset(&a, 0, sizeof(a));
+  int rc = resolve_kalign(ix, p, &a.kp);
+  if (rc != K4_OK) return rc;
+  if (n < 0 || (n > 0 && (!d_reads || !d_offs || !d_lens || !d_out || !d_hits))) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
+  a.n_reads = n; a.mode = 1;
+  a.rr = (k4_read_result*)d_out; a.hits = (k4_hit*)d_hits; a.max_hits = a.kp.max_ml;
+  return run_dev(ix, a, max_len, stream);
+}
+
+// ---- host-pointer entry points: stage through the index's own buffers and stream -------------------------------
+static int stage_in(k4_index* ix, int64_t n, const uint8_t* reads, const uint64_t* offs, const uint32_t* lens,
+                    int max_hits, int* max_len_out, size_t out_bytes_per_read) {
+  K4Workspace& w = ix->ws;
+  uint64_t tot = 0;
+  int max_len = 1;
+  for (int64_t i = 0; i < n; i++) {
+    tot = std::max<uint64_t>(tot, offs[i] + lens[i]);
+    max_len = std::max<int>(max_len, (int)lens[i]);
+  }
+  if (max_len > K4_MAX_READ_LEN) return k4_fail(ix, K4_ERR_PARAMS, "read longer than %d bases", K4_MAX_READ_LEN);
+  *max_len_out = max_len;
+  int rc = k4_reserve(ix, n, max_len, max_hits);
+  if (rc != K4_OK) return rc;
+  if (tot + 64 > w.d_reads_cap) {
+    if (w.d_reads) hipFree(w.d_reads);
+    w.d_reads = nullptr;
+    K4_HIP(ix, hipMalloc(&w.d_reads, tot + 64));
+    w.d_reads_cap = tot + 64;
+  }
+  if (n > w.stage_reads || max_hits > w.stage_hits) {
+    int64_t cap = std::max(n, w.stage_reads);
+    int mh = std::max(max_hits, w.stage_hits);
+    for (void* p : {(void*)w.d_offs, (void*)w.d_lens, (void*)w.d_out4, (void*)w.d_hits})
+      if (p) hipFree(p);
+    w.d_offs = nullptr; w.d_lens = nullptr; w.d_out4 = nullptr; w.d_hits = nullptr;
+    K4_HIP(ix, hipMalloc(&w.d_offs, (size_t)(cap + 1) * 8));
+    K4_HIP(ix, hipMalloc(&w.d_lens, (size_t)(cap + 1) * 4));
+    K4_HIP(ix, hipMalloc(&w.d_out4, (size_t)(cap + 1) * 24));
+    K4_HIP(ix, hipMalloc(&w.d_hits, (size_t)(cap + 1) * mh * sizeof(k4_hit)));
+    w.stage_reads = cap;
+    w.stage_hits = mh;
+  }
+  (void)out_bytes_per_read;
+  if (n) {
+    K4_HIP(ix, hipMemcpyAsync(w.d_reads, reads, tot, hipMemcpyHostToDevice, ix->stream));
+    K4_HIP(ix, hipMemcpyAsync(w.d_offs, offs, (size_t)n * 8, hipMemcpyHostToDevice, ix->stream));
+    K4_HIP(ix, hipMemcpyAsync(w.d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
+  }
+  return K4_OK;
+}
+
+extern "C" int k4_align_reads_batch(k4_index* ix, const k4_align_params* p, int64_t n, const uint8_t* reads,
+                                    const uint64_t* offs, const uint32_t* lens, int32_t* rslt, int32_t* inst,
+                                    int32_t* low, int32_t* nxt, k4_hit* hits) {
+  if (!ix) return K4_ERR_PARAMS;
+  int rc = check_align_params(ix, p);
+  if (rc != K4_OK) return rc;
+  if (n < 0 || (n > 0 && (!reads || !offs || !lens || !rslt || !inst || !low || !nxt || !hits)))
+    return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  if (n == 0) return K4_OK;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  int max_len = 1;
+  rc = stage_in(ix, n, reads, offs, lens, p->max_hits, &max_len, 16);
+  if (rc != K4_OK) return rc;
+  K4Workspace& w = ix->ws;
+  int32_t* o = w.d_out4;
+  rc = k4_align_reads_batch_dev(ix, p, n, max_len, w.d_reads, w.d_offs, w.d_lens, o, o + n, o + 2 * n, o + 3 * n,
+                                w.d_hits, ix->stream);
+  if (rc != K4_OK) return rc;
+  K4_HIP(ix, hipMemcpyAsync(rslt, o, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(inst, o + n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(low, o + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(nxt, o + 3 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipStreamSynchronize(ix->stream));
+  return K4_OK;
+}
+
+extern "C" int k4_kalign_batch(k4_index* ix, const k4_kalign_params* p, int64_t n, const uint8_t* reads,
+                               const uint64_t* offs, const uint32_t* lens, k4_read_result* out, k4_hit* hits) {
+  if (!ix || !p) return K4_ERR_PARAMS;
+  if (n < 0 || (n > 0 && (!reads || !offs || !lens || !out || !hits))) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  if (p->max_ml < 1) return k4_fail(ix, K4_ERR_PARAMS, "max_ml must be >= 1");
+  if (n == 0) return K4_OK;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  int max_len = 1;
+  int rc = stage_in(ix, n, reads, offs, lens, p->max_ml, &max_len, 24);
+  if (rc != K4_OK) return rc;
+  K4Workspace& w = ix->ws;
+  rc = k4_kalign_batch_dev(ix, p, n, max_len, w.d_reads, w.d_offs, w.d_lens, w.d_out4, w.d_hits, ix->stream);
+  if (rc != K4_OK) return rc;
+  K4_HIP(ix, hipMemcpyAsync(out, w.d_out4, (size_t)n * sizeof(k4_read_result), hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_ml * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipStreamSynchronize(ix->stream));
+  return K4_OK;
+}
+
+extern "C" int k4_get_counters(k4_index* ix, k4_counters* out) {
+  if (!ix || !out) return K4_ERR_PARAMS;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  K4_HIP(ix, hipDeviceSynchronize());
+  K4_HIP(ix, hipMemcpy(out, ix->counters, sizeof(k4_counters), hipMemcpyDeviceToHost));
+  return K4_OK;
+}
+
+extern "C" int k4_reset_counters(k4_index* ix) {
+  if (!ix) return K4_ERR_PARAMS;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  K4_HIP(ix, hipDeviceSynchronize());
+  K4_HIP(ix, hipMemset(ix->counters, 0, sizeof(k4_counters)));
+  return K4_OK;
+}

@@ -1,0 +1,87 @@
+// kit4b_amd/csrc/k4_device.h -- device-side accessors of the HBM index (gfx950 only).
+#pragma once
+#include "k4_internal.h"
+
+#define K4_DEV __device__ __forceinline__
+
+// SfxOfsToLoci (libkit4b/SfxArray.cpp:49-60): element i of the 4- or 5-byte little-endian suffix array.
+template <int EL>
+K4_DEV uint64_t k4d_sa_at(const K4DevIndex& ix, uint64_t i) {
+  if (EL == 4) {
+    return reinterpret_cast<const uint32_t*>(ix.sa)[i];
+  } else {
+    uint64_t q = i * 5;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(ix.sa) + (q >> 2);
+    uint32_t sh = (uint32_t)(q & 3) * 8;
+    uint64_t v = ((uint64_t)w[1] << 32) | w[0];  // the allocation is padded so w[1] is always readable
+    return (v >> sh) & 0xFFFFFFFFFFull;
+  }
+}
+
+K4_DEV uint64_t k4d_ktab_at(const K4DevIndex& ix, uint64_t c) {
+  return ix.ktab64 ? reinterpret_cast<const uint64_t*>(ix.ktab)[c] : reinterpret_cast<const uint32_t*>(ix.ktab)[c];
+}
+
+// 32 bases [pos, pos+32) as one MSB-first 64-bit chunk.  pos may be as low as -K4_PAD_BASES.
+K4_DEV uint64_t k4d_ref_chunk(const K4DevIndex& ix, int64_t pos) {
+  int64_t w = pos >> 4;  // arithmetic shift: floor for negative pos
+  uint32_t s = (uint32_t)(pos & 15) * 2;
+  const uint32_t* p = ix.ref2 + w;
+  uint64_t hi = ((uint64_t)p[0] << 32) | p[1];
+  return s ? (hi << s) | (p[2] >> (32 - s)) : hi;
+}
+
+// any non-ACGT symbol in [start, end) ?  (end - start) must stay below 32 * 64 bases
+K4_DEV bool k4d_any_exc(const K4DevIndex& ix, int64_t start, int64_t end) {
+  if (start < 0) start = 0;
+  if (end <= start) return false;
+  uint64_t b0 = (uint64_t)start >> 6, b1 = (uint64_t)(end - 1) >> 6;
+  uint32_t wa = ix.excbm[b0 >> 5], wb = ix.excbm[b1 >> 5];
+  uint32_t ma = ~0u << (b0 & 31), mb = ~0u >> (31 - (b1 & 31));
+  if ((b0 >> 5) == (b1 >> 5)) return (wa & ma & mb) != 0;
+  return ((wa & ma) | (wb & mb)) != 0;
+}
+
+// exact symbol (etSeqBase low nibble: 0..4, 7) at pos
+K4_DEV uint32_t k4d_ref_base(const K4DevIndex& ix, uint64_t pos) {
+  uint64_t blk = pos >> 6;
+  if ((ix.excbm[blk >> 5] >> (blk & 31)) & 1) {
+    uint32_t lo = 0, hi = ix.n_exc;  // lower_bound over the sorted flagged-block list
+    while (lo < hi) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (ix.excblk[mid] < (uint32_t)blk) lo = mid + 1; else hi = mid;
+    }
+    uint32_t j = (uint32_t)(pos & 63);
+    return (ix.excnib[(uint64_t)lo * 8 + (j >> 3)] >> (4 * (j & 7))) & 0xF;
+  }
+  uint32_t w = ix.ref2[pos >> 4];
+  return (w >> (30 - 2 * (uint32_t)(pos & 15))) & 3;
+}
+
+// MapChunkHit2Entry (libkit4b/SfxArray.cpp:2609-2654): index of the entry holding concat offset ofs, -1 on a separator
+K4_DEV int k4d_map_entry(const K4DevIndex& ix, uint64_t ofs) {
+  int lo = 0, hi = (int)ix.n_entries - 1;
+  while (hi >= lo) {
+    int mid = (hi + lo) >> 1;
+    uint64_t s = ix.ent_start[mid];
+    if (s > ofs) { hi = mid - 1; continue; }
+    if (ix.ent_end[mid] >= ofs) return mid;
+    lo = mid + 1;
+  }
+  return -1;
+}
+
+// mask of the bases [lo, hi) of a 32-base MSB-first chunk (0 <= lo, hi <= 32)
+K4_DEV uint64_t k4d_range_mask(int lo, int hi) {
+  if (lo < 0) lo = 0;
+  if (hi > 32) hi = 32;
+  if (hi <= lo) return 0;
+  uint64_t a = ~0ull >> (2 * lo);                       // lo < 32 here
+  uint64_t b = hi >= 32 ? 0ull : (~0ull >> (2 * hi));
+  return a & ~b;
+}
+
+K4_DEV uint32_t k4d_mm_count(uint64_t x) {  // mismatching bases in a XOR of two chunks
+  uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
+  return (uint32_t)__popcll(y);
+}

@@ -1,0 +1,673 @@
+// kit4b_amd/csrc/k4_index.hip -- index life cycle: .sfx container I/O, upload, 2-bit packing, exception data and
+// the direct-address k-mer table.  Replaces CSfxArray::Open/SetTargBlock/Close and the accessors CKAligner uses
+// (libkit4b/SfxArray.h:524-1023; container layout SfxArray.h:95-123,191-223).
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <strings.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
+#include "k4_device.h"
+
+// ---- errors ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void k4_set_global_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+int k4_fail(k4_index* ix, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ix) ix->err = buf;
+  g_err = buf;
+  return code;
+}
+int k4_check_hip(k4_index* ix, hipError_t e, const char* what) {
+  if (e == hipSuccess) return K4_OK;
+  return k4_fail(ix, e == hipErrorOutOfMemory ? K4_ERR_MEM : K4_ERR_NO_DEVICE, "HIP error %d (%s) in %s", (int)e,
+                 hipGetErrorString(e), what);
+}
+extern "C" const char* k4_last_error(const k4_index* ix) { return ix ? ix->err.c_str() : g_err.c_str(); }
+extern "C" const char* k4_global_error(void) { return g_err.c_str(); }
+extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
+
+// ---- kernels: packing ---------------------------------------------------------------------------------------
+// One thread per 64-base block: 4 packed words + the block's exception flag; the wave's ballot is the bitmap.
+__global__ void __launch_bounds__(256) k4k_pack_ref(const uint8_t* __restrict__ seq, uint64_t n,
+                                                    uint32_t* __restrict__ ref2, uint32_t* __restrict__ excbm,
+                                                    uint64_t n_blocks) {
+  uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool exc = false;
+  if (b < n_blocks) {
+    uint64_t base = b * 64;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (base + 64 <= n) {
+      const uint4* p = reinterpret_cast<const uint4*>(seq + base);  // hipMalloc'd + 64-byte stride: aligned
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        uint4 v = p[q];
+        uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            uint32_t s = (d[k] >> (8 * j)) & 0x0f;
+            if (s > 3) { exc = true; s = 0; }
+            acc = (acc << 2) | s;
+          }
+        }
+        w[q] = acc;
+      }
+    } else {
+      for (int q = 0; q < 4; q++) {
+        uint32_t acc = 0;
+        for (int j = 0; j < 16; j++) {
+          uint64_t pos = base + q * 16 + j;
+          uint32_t s = pos < n ? (seq[pos] & 0x0f) : 0;
+          if (s > 3) { exc = true; s = 0; }
+          acc = (acc << 2) | s;
+        }
+        w[q] = acc;
+      }
+    }
+    uint4 o = {w[0], w[1], w[2], w[3]};
+    *reinterpret_cast<uint4*>(ref2 + b * 4) = o;
+  }
+  unsigned long long m = __ballot(exc);
+  if ((threadIdx.x & 63) == 0) {
+    uint64_t w0 = (uint64_t)blockIdx.x * 8 + (threadIdx.x >> 6) * 2;  // 2 bitmap words per wave
+    excbm[w0] = (uint32_t)m;
+    excbm[w0 + 1] = (uint32_t)(m >> 32);
+  }
+}
+
+// exact nibbles of the flagged blocks: one thread per (flagged block, word)
+__global__ void __launch_bounds__(256) k4k_exc_nibbles(const uint8_t* __restrict__ seq, uint64_t n,
+                                                       const uint32_t* __restrict__ excblk, uint32_t n_exc,
+                                                       uint32_t* __restrict__ excnib) {
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (uint64_t)n_exc * 8) return;
+  uint32_t r = (uint32_t)(t >> 3), q = (uint32_t)(t & 7);
+  uint64_t base = (uint64_t)excblk[r] * 64 + q * 8;
+  uint32_t acc = 0;
+  for (int j = 0; j < 8; j++) {
+    uint64_t pos = base + j;
+    uint32_t s = pos < n ? (seq[pos] & 0x0f) : 7u;  // beyond the end reads as EOS
+    acc |= s << (4 * j);
+  }
+  excnib[t] = acc;
+}
+
+// ---- kernels: k-mer table -----------------------------------------------------------------------------------
+// code of the first k bases of the suffix at pos (first base most significant); false when they hold N/EOS.
+K4_DEV bool k4d_kmer_code(const K4DevIndex& ix, uint64_t pos, uint32_t k, uint64_t* code) {
+  if (pos + k > ix.n) return false;  // would run into (at least) the final EOS
+  if (k4d_any_exc(ix, (int64_t)pos, (int64_t)pos + k)) {
+    uint64_t c = 0;
+    for (uint32_t j = 0; j < k; j++) {
+      uint32_t s = k4d_ref_base(ix, pos + j);
+      if (s > 3) return false;
+      c = (c << 2) | s;
+    }
+    *code = c;
+    return true;
+  }
+  *code = k4d_ref_chunk(ix, (int64_t)pos) >> (64 - 2 * k);
+  return true;
+}
+
+template <int EL, typename T>
+__global__ void __launch_bounds__(256) k4k_ktab_mark(K4DevIndex ix, T* __restrict__ tab) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ix.n) return;
+  uint64_t c, cp = 0;
+  bool v = k4d_kmer_code(ix, k4d_sa_at<EL>(ix, i), ix.k, &c);
+  if (!v) return;
+  bool vp = i > 0 && k4d_kmer_code(ix, k4d_sa_at<EL>(ix, i - 1), ix.k, &cp);
+  if (!vp || cp != c) tab[c] = (T)i;  // first suffix of the run of k-mer c
+}
+
+// reverse (suffix) min-scan in three passes: tab[c] = min(tab[c'], c' >= c); unset entries hold the max value.
+template <typename T>
+__global__ void __launch_bounds__(256) k4k_scan_block_min(const T* __restrict__ tab, uint64_t n, T* __restrict__ agg) {
+  __shared__ T sh[256];
+  uint64_t base = (uint64_t)blockIdx.x * 2048 + (uint64_t)threadIdx.x * 8;
+  T m = (T)~(T)0;
+  for (int j = 0; j < 8; j++)
+    if (base + j < n) m = min(m, tab[base + j]);
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = min(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) agg[blockIdx.x] = sh[0];
+}
+template <typename T>
+__global__ void __launch_bounds__(1024) k4k_scan_agg(T* __restrict__ agg, uint64_t nb) {
+  // single block; exclusive reverse min-scan of the block aggregates, processed from the top in tiles of 1024
+  __shared__ T sh[1024];
+  __shared__ T carry_s;
+  if (threadIdx.x == 0) carry_s = (T)~(T)0;
+  __syncthreads();
+  uint64_t tiles = (nb + 1023) / 1024;
+  for (uint64_t t = tiles; t-- > 0;) {
+    uint64_t i = t * 1024 + threadIdx.x;
+    T v = i < nb ? agg[i] : (T)~(T)0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {  // inclusive reverse scan (Hillis-Steele)
+      T o = threadIdx.x + s < 1024 ? sh[threadIdx.x + s] : (T)~(T)0;
+      __syncthreads();
+      sh[threadIdx.x] = min(sh[threadIdx.x], o);
+      __syncthreads();
+    }
+    T carry = carry_s;
+    T excl = threadIdx.x + 1 < 1024 ? sh[threadIdx.x + 1] : (T)~(T)0;  // strictly-right within the tile
+    T tile_min = sh[0];
+    __syncthreads();
+    if (i < nb) agg[i] = min(excl, carry);
+    if (threadIdx.x == 0) carry_s = min(carry, tile_min);
+    __syncthreads();
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k4k_scan_apply(T* __restrict__ tab, uint64_t n, const T* __restrict__ agg) {
+  __shared__ T sh[256];
+  uint64_t base = (uint64_t)blockIdx.x * 2048 + (uint64_t)threadIdx.x * 8;
+  T v[8];
+  T m = (T)~(T)0;
+  for (int j = 7; j >= 0; j--) {
+    T x = base + j < n ? tab[base + j] : (T)~(T)0;
+    m = min(m, x);
+    v[j] = m;  // min over this thread's elements j..7
+  }
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 1; s < 256; s <<= 1) {
+    T o = threadIdx.x + s < 256 ? sh[threadIdx.x + s] : (T)~(T)0;
+    __syncthreads();
+    sh[threadIdx.x] = min(sh[threadIdx.x], o);
+    __syncthreads();
+  }
+  T right = threadIdx.x + 1 < 256 ? sh[threadIdx.x + 1] : (T)~(T)0;
+  right = min(right, agg[blockIdx.x]);
+  for (int j = 0; j < 8; j++)
+    if (base + j < n) tab[base + j] = min(v[j], right);
+}
+
+__global__ void k4k_unpack_range(K4DevIndex ix, uint64_t start, uint64_t len, uint8_t* __restrict__ out) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < len) out[t] = (uint8_t)k4d_ref_base(ix, start + t);
+}
+
+// ---- host: device structures ----------------------------------------------------------------------------------
+static int choose_k(uint64_t n, int want) {
+  if (want > 0) return std::min(16, std::max(4, want));
+  int k = 1;
+  while (k < 16 && (1ull << (2 * k)) < n) k++;  // smallest k with 4^k >= n
+  return std::max(6, k);
+}
+
+template <int EL, typename T>
+static int build_ktab(k4_index* ix) {
+  uint64_t nent = (1ull << (2 * ix->d.k)) + 1;
+  T* tab = nullptr;
+  K4_HIP(ix, hipMalloc(&tab, nent * sizeof(T)));
+  ix->ktab = tab;
+  ix->device_bytes += nent * sizeof(T);
+  K4_HIP(ix, hipMemset(tab, 0xFF, nent * sizeof(T)));
+  T last = (T)ix->d.n;
+  K4_HIP(ix, hipMemcpy(tab + (nent - 1), &last, sizeof(T), hipMemcpyHostToDevice));
+  ix->d.ktab = tab;
+  uint64_t nb = (ix->d.n + 255) / 256;
+  hipLaunchKernelGGL((k4k_ktab_mark<EL, T>), dim3((unsigned)nb), dim3(256), 0, 0, ix->d, tab);
+  K4_HIP(ix, hipGetLastError());
+  uint64_t sb = (nent + 2047) / 2048;
+  T* agg = nullptr;
+  K4_HIP(ix, hipMalloc(&agg, sb * sizeof(T)));
+  hipLaunchKernelGGL((k4k_scan_block_min<T>), dim3((unsigned)sb), dim3(256), 0, 0, tab, nent, agg);
+  hipLaunchKernelGGL((k4k_scan_agg<T>), dim3(1), dim3(1024), 0, 0, agg, sb);
+  hipLaunchKernelGGL((k4k_scan_apply<T>), dim3((unsigned)sb), dim3(256), 0, 0, tab, nent, agg);
+  K4_HIP(ix, hipGetLastError());
+  K4_HIP(ix, hipDeviceSynchronize());
+  K4_HIP(ix, hipFree(agg));
+  return K4_OK;
+}
+
+// d_seq: concat_len bytes (1 byte/base) in HBM; ix->sa, entries and ix->d.{n,el} must already be set.
+int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
+  const uint64_t n = ix->d.n;
+  const uint64_t n_blocks = (n + 63) / 64;
+  const uint64_t words = n_blocks * 4;
+  const uint64_t bm_words = ((n_blocks + 255) / 256) * 8 + 8;  // the pack kernel writes whole waves
+  K4_HIP(ix, hipMalloc(&ix->ref2_alloc, (words + 2 * K4_PAD_WORDS) * 4));
+  K4_HIP(ix, hipMemset(ix->ref2_alloc, 0, (words + 2 * K4_PAD_WORDS) * 4));
+  K4_HIP(ix, hipMalloc(&ix->excbm, bm_words * 4));
+  K4_HIP(ix, hipMemset(ix->excbm, 0, bm_words * 4));
+  ix->device_bytes += (words + 2 * K4_PAD_WORDS) * 4 + bm_words * 4;
+  uint32_t* ref2 = ix->ref2_alloc + K4_PAD_WORDS;
+  hipLaunchKernelGGL(k4k_pack_ref, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, 0,
+                     (const uint8_t*)d_seq, n, ref2, ix->excbm, n_blocks);
+  K4_HIP(ix, hipGetLastError());
+  // flagged-block list on the host (bitmap is n/512 bytes)
+  std::vector<uint32_t> bm(bm_words);
+  K4_HIP(ix, hipMemcpy(bm.data(), ix->excbm, bm_words * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> blk;
+  for (uint64_t w = 0; w < bm_words; w++) {
+    uint32_t v = bm[w];
+    while (v) {
+      int b = __builtin_ctz(v);
+      v &= v - 1;
+      uint64_t id = w * 32 + b;
+      if (id < n_blocks) blk.push_back((uint32_t)id);
+    }
+  }
+  uint32_t n_exc = (uint32_t)blk.size();
+  K4_HIP(ix, hipMalloc(&ix->excblk, (size_t)(n_exc + 1) * 4));
+  K4_HIP(ix, hipMalloc(&ix->excnib, (size_t)(n_exc + 1) * 32));
+  ix->device_bytes += (uint64_t)(n_exc + 1) * 36;
+  if (n_exc) {
+    K4_HIP(ix, hipMemcpy(ix->excblk, blk.data(), (size_t)n_exc * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k4k_exc_nibbles, dim3((unsigned)(((uint64_t)n_exc * 8 + 255) / 256)), dim3(256), 0, 0,
+                       (const uint8_t*)d_seq, n, ix->excblk, n_exc, ix->excnib);
+    K4_HIP(ix, hipGetLastError());
+  }
+  // entries
+  uint32_t ne = (uint32_t)ix->entries.size();
+  std::vector<uint64_t> es(ne), ee(ne);
+  std::vector<uint32_t> ei(ne);
+  ix->tot_seqs_len = 0;
+  for (uint32_t i = 0; i < ne; i++) {
+    es[i] = ix->entries[i].start_ofs;
+    ee[i] = ix->entries[i].end_ofs;
+    ei[i] = ix->entries[i].entry_id;
+    ix->tot_seqs_len += ix->entries[i].seq_len;
+  }
+  K4_HIP(ix, hipMalloc(&ix->ent_start, (size_t)(ne + 1) * 8));
+  K4_HIP(ix, hipMalloc(&ix->ent_end, (size_t)(ne + 1) * 8));
+  K4_HIP(ix, hipMalloc(&ix->ent_id, (size_t)(ne + 1) * 4));
+  if (ne) {
+    K4_HIP(ix, hipMemcpy(ix->ent_start, es.data(), (size_t)ne * 8, hipMemcpyHostToDevice));
+    K4_HIP(ix, hipMemcpy(ix->ent_end, ee.data(), (size_t)ne * 8, hipMemcpyHostToDevice));
+    K4_HIP(ix, hipMemcpy(ix->ent_id, ei.data(), (size_t)ne * 4, hipMemcpyHostToDevice));
+  }
+  K4_HIP(ix, hipMalloc(&ix->counters, sizeof(k4_counters)));
+  K4_HIP(ix, hipMemset(ix->counters, 0, sizeof(k4_counters)));
+  ix->d.ref2 = ref2;
+  ix->d.excbm = ix->excbm;
+  ix->d.excblk = ix->excblk;
+  ix->d.excnib = ix->excnib;
+  ix->d.n_exc = n_exc;
+  ix->d.sa = ix->sa;
+  ix->d.ent_start = ix->ent_start;
+  ix->d.ent_end = ix->ent_end;
+  ix->d.ent_id = ix->ent_id;
+  ix->d.n_entries = ne;
+  ix->d.k = (uint32_t)choose_k(n, kmer_k);
+  ix->d.ktab64 = n >= 0xFFFFFFFFull ? 1 : 0;
+  ix->d.max_iter = 50000;  // cDfltMaxIter, libkit4b/SfxArray.h:12
+  int rc;
+  if (ix->d.el == 4)
+    rc = ix->d.ktab64 ? build_ktab<4, uint64_t>(ix) : build_ktab<4, uint32_t>(ix);
+  else
+    rc = ix->d.ktab64 ? build_ktab<5, uint64_t>(ix) : build_ktab<5, uint32_t>(ix);
+  if (rc != K4_OK) return rc;
+  K4_HIP(ix, hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  return K4_OK;
+}
+
+// ---- host: open / close ---------------------------------------------------------------------------------------
+static int select_device(int device) {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0) {
+    k4_set_global_error("no usable HIP device (hipGetDeviceCount: %s); libk4sfx has no CPU fallback",
+                        e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    return K4_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= cnt) {
+    k4_set_global_error("device %d out of range (0..%d)", device, cnt - 1);
+    return K4_ERR_PARAMS;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    k4_set_global_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    return K4_ERR_NO_DEVICE;
+  }
+  return K4_OK;
+}
+
+static int check_entries(uint64_t n, uint32_t ne, const k4_entry* e) {
+  uint64_t prev_end = 0;
+  for (uint32_t i = 0; i < ne; i++) {
+    if (e[i].end_ofs < e[i].start_ofs || e[i].end_ofs >= n) return 0;
+    if (i && e[i].start_ofs <= prev_end) return 0;
+    prev_end = e[i].end_ofs;
+  }
+  return 1;
+}
+
+static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void* d_seq_in, const uint8_t* h_sa,
+                       void* d_sa_in, int adopt_sa, uint32_t ne, const k4_entry* entries, const char* dataset,
+                       int device, int kmer_k, k4_index** out) {
+  if (!out) return K4_ERR_PARAMS;
+  *out = nullptr;
+  if (n == 0 || (el != 4 && el != 5) || (el == 4 && n > 0xFFFFFFFFull) || !entries || ne == 0) {
+    k4_set_global_error("bad index geometry: concat_len=%llu el=%u entries=%u", (unsigned long long)n, el, ne);
+    return K4_ERR_PARAMS;
+  }
+  if (!check_entries(n, ne, entries)) {
+    k4_set_global_error("entries table is not sorted / inside the block");
+    return K4_ERR_PARAMS;
+  }
+  int rc = select_device(device);
+  if (rc != K4_OK) return rc;
+  k4_index* ix = new k4_index;
+  ix->device = device;
+  ix->d.n = n;
+  ix->d.el = el;
+  ix->entries.assign(entries, entries + ne);
+  ix->dataset = dataset ? dataset : "";
+  auto fail = [&](int code) {
+    std::string keep = ix->err;
+    k4_close(ix);
+    k4_set_global_error("%s", keep.c_str());
+    return code;
+  };
+  // suffix array (padded so the 5-byte reader may touch 8 bytes past the end)
+  if (d_sa_in && adopt_sa) {
+    ix->sa = (uint8_t*)d_sa_in;
+    ix->owns_sa = false;
+  } else {
+    if ((rc = k4_check_hip(ix, hipMalloc(&ix->sa, n * el + 16), "hipMalloc(sa)")) != K4_OK) return fail(rc);
+    ix->device_bytes += n * el + 16;
+    hipError_t e = d_sa_in ? hipMemcpy(ix->sa, d_sa_in, n * el, hipMemcpyDeviceToDevice)
+                           : hipMemcpy(ix->sa, h_sa, n * el, hipMemcpyHostToDevice);
+    if ((rc = k4_check_hip(ix, e, "hipMemcpy(sa)")) != K4_OK) return fail(rc);
+  }
+  // sequence bytes: temporary on the device, only needed to derive the packed form
+  uint8_t* d_tmp = nullptr;
+  const void* d_seq = d_seq_in;
+  if (!d_seq) {
+    if ((rc = k4_check_hip(ix, hipMalloc(&d_tmp, n + 64), "hipMalloc(seq)")) != K4_OK) return fail(rc);
+    if ((rc = k4_check_hip(ix, hipMemcpy(d_tmp, h_seq, n, hipMemcpyHostToDevice), "hipMemcpy(seq)")) != K4_OK) {
+      hipFree(d_tmp);
+      return fail(rc);
+    }
+    d_seq = d_tmp;
+  }
+  rc = k4i_build_device_structures(ix, d_seq, kmer_k);
+  if (d_tmp) hipFree(d_tmp);
+  if (rc != K4_OK) return fail(rc);
+  *out = ix;
+  return K4_OK;
+}
+
+extern "C" int k4_open_host(uint64_t n, uint32_t el, const uint8_t* seq, const uint8_t* sa, uint32_t ne,
+                            const k4_entry* entries, const char* dataset, int device, int kmer_k, k4_index** out) {
+  if (!seq || !sa) return K4_ERR_PARAMS;
+  return open_common(n, el, seq, nullptr, sa, nullptr, 0, ne, entries, dataset, device, kmer_k, out);
+}
+
+extern "C" int k4_open_device(uint64_t n, uint32_t el, const void* d_seq, void* d_sa, int adopt_sa, uint32_t ne,
+                              const k4_entry* entries, const char* dataset, int device, int kmer_k, k4_index** out) {
+  if (!d_seq || !d_sa) return K4_ERR_PARAMS;
+  return open_common(n, el, nullptr, d_seq, nullptr, d_sa, adopt_sa, ne, entries, dataset, device, kmer_k, out);
+}
+
+// .sfx container: header 1224 B pack(4), block header 20 B pack(1), entries 111 B pack(1)
+template <typename T>
+static T rd(const uint8_t* p) {
+  T v;
+  memcpy(&v, p, sizeof(T));
+  return v;
+}
+
+extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out) {
+  if (!path || !*path || !out) return K4_ERR_PARAMS;
+  *out = nullptr;
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) {
+    k4_set_global_error("unable to open %s", path);
+    return K4_ERR_OPEN_FILE;
+  }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < 1224) {
+    close(fd);
+    k4_set_global_error("%s: too short for a suffix array file header", path);
+    return K4_ERR_NOT_SFX;
+  }
+  size_t len = (size_t)st.st_size;
+  const uint8_t* f = (const uint8_t*)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (f == MAP_FAILED) {
+    k4_set_global_error("mmap of %s failed", path);
+    return K4_ERR_FILE_ACCESS;
+  }
+  auto done = [&](int code) {
+    munmap((void*)f, len);
+    return code;
+  };
+  if (tolower(f[0]) != 's' || tolower(f[1]) != 'f' || tolower(f[2]) != 'x' || f[3] < '3' || f[3] > '5') {
+    k4_set_global_error("%s opened but invalid magic signature - not a 'kit4b index' generated suffix array file", path);
+    return done(K4_ERR_NOT_SFX);
+  }
+  uint32_t ver = rd<uint32_t>(f + 4);
+  if (ver < 4 || ver > 5) {  // v3 (36-char names, SfxArray.h:127-141) is not produced by any current kit4b
+    k4_set_global_error("%s: structure version %u is not supported (4..5)", path, ver);
+    return done(K4_ERR_FILE_VER);
+  }
+  uint32_t attr = rd<uint32_t>(f + 8);
+  if (attr & 3) {
+    k4_set_global_error("%s: bisulfite / colourspace indexes are outside the accelerated path", path);
+    return done(K4_ERR_UNSUPPORTED);
+  }
+  uint64_t entries_ofs = rd<uint64_t>(f + 20);
+  uint32_t entries_size = rd<uint32_t>(f + 28);
+  uint32_t n_blocks = rd<uint32_t>(f + 32);
+  uint64_t block_ofs = rd<uint64_t>(f + 44);
+  if (n_blocks != 1 || block_ofs + 20 > len || entries_ofs == 0 || entries_ofs + entries_size > len ||
+      entries_size < 8) {
+    k4_set_global_error("%s: inconsistent header (blocks=%u)", path, n_blocks);
+    return done(K4_ERR_FILE_ACCESS);
+  }
+  char dataset[81];
+  memcpy(dataset, f + 52, 80);
+  dataset[80] = 0;
+  const uint8_t* b = f + block_ofs;
+  uint64_t n = rd<uint64_t>(b + 8);
+  uint32_t el = rd<uint32_t>(b + 16);
+  if ((el != 4 && el != 5) || block_ofs + 20 + n + n * el > len) {
+    k4_set_global_error("%s: suffix block truncated (n=%llu el=%u)", path, (unsigned long long)n, el);
+    return done(K4_ERR_FILE_ACCESS);
+  }
+  const uint8_t* e = f + entries_ofs;
+  uint32_t ne = rd<uint32_t>(e);
+  if (8 + (uint64_t)ne * 111 > entries_size) {
+    k4_set_global_error("%s: entries block truncated", path);
+    return done(K4_ERR_FILE_ACCESS);
+  }
+  std::vector<k4_entry> ents(ne);
+  for (uint32_t i = 0; i < ne; i++) {
+    const uint8_t* p = e + 8 + (size_t)i * 111;
+    k4_entry& d = ents[i];
+    memset(&d, 0, sizeof(d));
+    d.entry_id = rd<uint32_t>(p);
+    d.fblock_id = rd<uint32_t>(p + 4);
+    memcpy(d.name, p + 8, 80);
+    d.name_hash = rd<uint16_t>(p + 89);
+    d.seq_len = rd<uint32_t>(p + 91);
+    d.start_ofs = rd<uint64_t>(p + 95);
+    d.end_ofs = rd<uint64_t>(p + 103);
+  }
+  int rc = k4_open_host(n, el, b + 20, b + 20 + n, ne, ents.data(), dataset, device, kmer_k, out);
+  return done(rc);
+}
+
+extern "C" void k4_close(k4_index* ix) {
+  if (!ix) return;
+  hipSetDevice(ix->device);
+  K4Workspace& w = ix->ws;
+  void* ptrs[] = {ix->ref2_alloc, ix->excbm, ix->excblk, ix->excnib, ix->owns_sa ? ix->sa : nullptr, ix->ktab,
+                  ix->ent_start, ix->ent_end, ix->ent_id, ix->counters, w.packed, w.rflags, w.slow_list, w.ctl,
+                  w.slow_probe, w.slow_hash, w.d_reads, w.d_offs, w.d_lens, w.d_out4, w.d_hits};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (ix->stream) hipStreamDestroy(ix->stream);
+  delete ix;
+}
+
+// ---- accessors ------------------------------------------------------------------------------------------------
+extern "C" int k4_info(const k4_index* ix, k4_info_t* o) {
+  if (!ix || !o) return K4_ERR_PARAMS;
+  memset(o, 0, sizeof(*o));
+  o->concat_len = ix->d.n;
+  o->tot_seqs_len = ix->tot_seqs_len;
+  o->sfx_el_size = ix->d.el;
+  o->n_entries = ix->d.n_entries;
+  o->kmer_k = ix->d.k;
+  o->n_exc_blocks = ix->d.n_exc;
+  o->device_bytes = ix->device_bytes;
+  o->device = ix->device;
+  o->max_iter = ix->d.max_iter;
+  strncpy(o->dataset, ix->dataset.c_str(), 80);
+  return K4_OK;
+}
+
+extern "C" int k4_get_entry(const k4_index* ix, uint32_t entry_id, k4_entry* out) {
+  if (!ix || !out) return K4_ERR_PARAMS;
+  if (entry_id < 1 || entry_id > ix->entries.size()) return K4_ERR_ENTRY;
+  *out = ix->entries[entry_id - 1];
+  return K4_OK;
+}
+
+extern "C" int k4_get_ident(const k4_index* ix, const char* name) {  // CSfxArray::GetIdent: case-insensitive
+  if (!ix || !name) return K4_ERR_PARAMS;
+  for (const k4_entry& e : ix->entries)
+    if (!strcasecmp(e.name, name)) return (int)e.entry_id;
+  return K4_ERR_ENTRY;
+}
+
+extern "C" int k4_set_max_iter(k4_index* ix, int max_iter) {  // CSfxArray::SetMaxIter, SfxArray.cpp:1501
+  if (!ix) return K4_ERR_PARAMS;
+  int prev = ix->d.max_iter;
+  ix->d.max_iter = max_iter > 0 ? max_iter : 0;
+  return prev;
+}
+
+static int unpack_to_host(const k4_index* cix, uint64_t start, uint64_t len, uint8_t* out) {
+  k4_index* ix = const_cast<k4_index*>(cix);
+  hipSetDevice(ix->device);
+  const uint64_t chunk = 64ull << 20;
+  uint8_t* d = nullptr;
+  K4_HIP(ix, hipMalloc(&d, std::min(chunk, len ? len : 1)));
+  for (uint64_t o = 0; o < len; o += chunk) {
+    uint64_t c = std::min(chunk, len - o);
+    hipLaunchKernelGGL(k4k_unpack_range, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, 0, ix->d, start + o, c, d);
+    hipError_t e = hipMemcpy(out + o, d, c, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      hipFree(d);
+      return k4_check_hip(ix, e, "unpack copy");
+    }
+  }
+  hipFree(d);
+  return K4_OK;
+}
+
+// CSfxArray::GetSeq (SfxArray.h:996): returns the number of bases written (may be shorter), 0 on error
+extern "C" int k4_get_seq(const k4_index* ix, uint32_t entry_id, uint32_t loci, uint8_t* out, uint32_t len) {
+  if (!ix || !out || entry_id < 1 || entry_id > ix->entries.size()) return 0;
+  const k4_entry& e = ix->entries[entry_id - 1];
+  if (loci >= e.seq_len) return 0;
+  if (loci + (uint64_t)len > e.seq_len) len = e.seq_len - loci;
+  if (unpack_to_host(ix, e.start_ofs + loci, len, out) != K4_OK) return 0;
+  return (int)len;
+}
+
+// CSfxArray::Flush2Disk (SfxArray.cpp:892): header, block (sequence + suffix array), entries
+extern "C" int k4_write_sfx(const k4_index* cix, const char* path) {
+  if (!cix || !path) return K4_ERR_PARAMS;
+  k4_index* ix = const_cast<k4_index*>(cix);
+  const uint64_t n = ix->d.n;
+  const uint32_t el = ix->d.el, ne = ix->d.n_entries;
+  FILE* fp = fopen(path, "wb");
+  if (!fp) return k4_fail(ix, K4_ERR_CREATE_FILE, "unable to create %s", path);
+  uint8_t hdr[1224];
+  memset(hdr, 0, sizeof(hdr));
+  memcpy(hdr, "sfx5", 4);
+  uint32_t ver = 5, attr = 0, nblocks = 1, entries_size = 8 + 111 * ne;
+  uint64_t block_ofs = 1224, block_size = 20 + n + n * el, entries_ofs = block_ofs + block_size;
+  uint64_t file_len = entries_ofs + entries_size;
+  memcpy(hdr + 4, &ver, 4); memcpy(hdr + 8, &attr, 4); memcpy(hdr + 12, &file_len, 8);
+  memcpy(hdr + 20, &entries_ofs, 8); memcpy(hdr + 28, &entries_size, 4); memcpy(hdr + 32, &nblocks, 4);
+  memcpy(hdr + 36, &block_size, 8); memcpy(hdr + 44, &block_ofs, 8);
+  strncpy((char*)hdr + 52, ix->dataset.c_str(), 80);
+  strncpy((char*)hdr + 133, "k4sfx MI355X index", 1023);
+  strncpy((char*)hdr + 1157, "k4sfx", 63);
+  fwrite(hdr, 1, sizeof(hdr), fp);
+  uint8_t bh[20];
+  uint32_t bid = 1;
+  memcpy(bh, &bid, 4); memcpy(bh + 4, &ne, 4); memcpy(bh + 8, &n, 8); memcpy(bh + 16, &el, 4);
+  fwrite(bh, 1, sizeof(bh), fp);
+  const uint64_t chunk = 256ull << 20;
+  std::vector<uint8_t> buf(std::min<uint64_t>(chunk, std::max<uint64_t>(n * el, 1)));
+  for (uint64_t o = 0; o < n; o += chunk) {
+    uint64_t c = std::min(chunk, n - o);
+    int rc = unpack_to_host(ix, o, c, buf.data());
+    if (rc != K4_OK) { fclose(fp); return rc; }
+    fwrite(buf.data(), 1, c, fp);
+  }
+  hipSetDevice(ix->device);
+  for (uint64_t o = 0; o < n * el; o += chunk) {
+    uint64_t c = std::min(chunk, n * el - o);
+    hipError_t e = hipMemcpy(buf.data(), ix->sa + o, c, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { fclose(fp); return k4_check_hip(ix, e, "sa copy"); }
+    fwrite(buf.data(), 1, c, fp);
+  }
+  uint32_t nee[2] = {ne, ne};
+  fwrite(nee, 4, 2, fp);
+  for (uint32_t i = 0; i < ne; i++) {
+    uint8_t e[111];
+    const k4_entry& s = ix->entries[i];
+    memset(e, 0, sizeof(e));
+    memcpy(e, &s.entry_id, 4); memcpy(e + 4, &s.fblock_id, 4);
+    strncpy((char*)e + 8, s.name, 80);
+    memcpy(e + 89, &s.name_hash, 2); memcpy(e + 91, &s.seq_len, 4);
+    memcpy(e + 95, &s.start_ofs, 8); memcpy(e + 103, &s.end_ofs, 8);
+    fwrite(e, 1, sizeof(e), fp);
+  }
+  int bad = ferror(fp);
+  fclose(fp);
+  return bad ? k4_fail(ix, K4_ERR_FILE_ACCESS, "write to %s failed", path) : K4_OK;
+}
+
+// LocateCoredApprox parameter derivation (ngskit4b/KAligner.cpp:9367-9393)
+extern "C" int k4_min_core_len(const k4_index* ix, int pmode, int* max_num_slides) {
+  if (!ix) return K4_ERR_PARAMS;
+  uint64_t tot = ix->tot_seqs_len;
+  int autolen = 1;
+  while (tot >>= 2) autolen++;
+  autolen -= 1;
+  int mcl = std::max(4, autolen);  // cKAMinCoreLen, KAligner.h:39
+  int slides;
+  switch (pmode) {
+    case 2: mcl -= 2; slides = 9; break;
+    case 1: mcl -= 1; slides = 8; break;
+    case 0: slides = 8; break;
+    default: mcl += 2; slides = 6; break;
+  }
+  if (max_num_slides) *max_num_slides = slides;
+  return mcl;
+}

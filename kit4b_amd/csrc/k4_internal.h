@@ -1,0 +1,104 @@
+// kit4b_amd/csrc/k4_internal.h -- shared between the translation units of libk4sfx.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/k4sfx.h"
+
+// ---- HBM layout of the index --------------------------------------------------------------------------
+// ref2      2-bit packed reference, MSB-first inside 32-bit words: base i lives in bits (30 - 2*(i & 15)) of
+//           word (i >> 4); non-ACGT symbols (N=4, EOS=7) are stored as 0 and described by the exception data.
+//           K4_PAD_WORDS zero words sit in front of base 0 and behind the last base, so a window that starts up
+//           to K4_PAD_BASES before 0 or runs past the end can be fetched without bounds tests.
+// excbm     one bit per 64-base block: set when the block holds a non-ACGT symbol.
+// excblk    sorted list of the flagged block numbers; excnib holds, for flagged block r, its 64 symbols as
+//           nibbles (8 words, symbol j in bits 4*(j&7) of word r*8 + (j>>3)) -- the exact 4-bit reference.
+// sa        the .sfx suffix array unchanged: 4- or 5-byte little-endian elements.
+// ktab      direct-address table over the first k bases: ktab[c] = number of suffixes that sort before the
+//           k-mer with code c (first base most significant); 4^k + 1 entries, 32-bit when concat_len < 2^32.
+// entries   start/end offsets and ids of the chromosomes (tsSfxEntry), sorted by start.
+#define K4_PAD_BASES 2048
+#define K4_PAD_WORDS (K4_PAD_BASES / 16)
+#define K4_MAX_FAST_READ_LEN 512   // longer reads run in the general kernel
+#define K4_MAX_READ_LEN 4096       // cMaxSeqLen is 2000 (KAligner.h:115)
+#define K4_DEDUP_CAP 8             // distinct candidates per strand pass kept by the fast kernel
+#define K4_MAX_IDENT_NODES 1024000 // cMaxNumIdentNodes, libkit4b/SfxArray.h:15
+
+struct K4DevIndex {
+  const uint32_t* ref2;   // points at the word holding base 0
+  const uint32_t* excbm;
+  const uint32_t* excblk;
+  const uint32_t* excnib;
+  const uint8_t* sa;
+  const void* ktab;
+  const uint64_t* ent_start;
+  const uint64_t* ent_end;
+  const uint32_t* ent_id;
+  uint64_t n;        // ConcatSeqLen
+  uint32_t n_exc;
+  uint32_t n_entries;
+  uint32_t el;       // 4 | 5
+  uint32_t k;        // k-mer table length
+  uint32_t ktab64;   // table entries are 64-bit
+  int32_t max_iter;
+};
+
+struct K4Workspace {
+  int64_t cap_reads = 0;
+  int32_t cap_len = 0;
+  int32_t cap_hits = 0;
+  uint64_t* packed = nullptr;    // [2 strands][nw][cap_reads]
+  uint32_t* rflags = nullptr;    // per read: bit0 has N, bit1 invalid symbol, bits 8.. count of N
+  uint32_t* slow_list = nullptr; // read ids for the general kernel
+  uint32_t* ctl = nullptr;       // [0] slow count, [1] slow head
+  uint8_t* slow_probe = nullptr; // per slow lane: probe bytes scratch
+  uint64_t* slow_hash = nullptr; // per slow lane: open-addressing table of (generation<<32 | TargSeqID)
+  uint32_t slow_lanes = 0;
+  uint32_t slow_hash_cap = 0;    // entries per lane (power of two)
+  // staging for the host-pointer entry points
+  uint8_t* d_reads = nullptr; size_t d_reads_cap = 0;
+  uint64_t* d_offs = nullptr; uint32_t* d_lens = nullptr;
+  int32_t* d_out4 = nullptr;     // rslt/inst/low/nxt or k4_read_result
+  k4_hit* d_hits = nullptr;
+  int64_t stage_reads = 0; int32_t stage_hits = 0;
+};
+
+struct k4_index {
+  int device = 0;
+  K4DevIndex d{};
+  // owning pointers
+  uint32_t* ref2_alloc = nullptr;
+  uint32_t* excbm = nullptr;
+  uint32_t* excblk = nullptr;
+  uint32_t* excnib = nullptr;
+  uint8_t* sa = nullptr;
+  bool owns_sa = true;
+  void* ktab = nullptr;
+  uint64_t* ent_start = nullptr;
+  uint64_t* ent_end = nullptr;
+  uint32_t* ent_id = nullptr;
+  uint64_t* counters = nullptr; // device k4_counters
+  std::vector<k4_entry> entries;
+  std::string dataset;
+  uint64_t tot_seqs_len = 0;
+  uint64_t device_bytes = 0;
+  std::string err;
+  K4Workspace ws;
+  hipStream_t stream = nullptr; // internal stream for the host-pointer entry points
+};
+
+void k4_set_global_error(const char* fmt, ...);
+int k4_fail(k4_index* ix, int code, const char* fmt, ...);
+int k4_check_hip(k4_index* ix, hipError_t e, const char* what);
+
+// k4_index.hip
+int k4i_build_device_structures(k4_index* ix, const void* d_seq_bytes, int kmer_k);
+// k4_sabuild.hip
+int k4i_build_sa(uint64_t n, uint32_t el, const uint8_t* d_seq, uint8_t* d_sa, int device, std::string* err);
+
+#define K4_HIP(ix, call)                                   \
+  do {                                                     \
+    int _rc = k4_check_hip((ix), (call), #call);           \
+    if (_rc != K4_OK) return _rc;                          \
+  } while (0)

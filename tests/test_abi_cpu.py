@@ -1,0 +1,69 @@
+"""CPU-side checks of the product boundary: the C-ABI library loads, exports every symbol include/k4sfx.h declares,
+and refuses to compute without a GPU (no silent fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import kit4b_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(kit4b_amd.LIB_PATH):
+        kit4b_amd.build()
+    return kit4b_amd.lib()
+
+
+def test_header_symbols_all_exported(L):
+    hdr = open(os.path.join(ROOT, "include", "k4sfx.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(k4_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(kit4b_amd.ABI_SYMBOLS), declared ^ set(kit4b_amd.ABI_SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.k4_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(kit4b_amd.AlignParams) == 32
+    assert C.sizeof(kit4b_amd.KalignParams) == 36
+    assert kit4b_amd.HIT_DTYPE.itemsize == 16
+    assert kit4b_amd.RESULT_DTYPE.itemsize == 24
+    assert C.sizeof(kit4b_amd.Counters) == 48
+
+
+def test_error_codes_follow_reference_values():
+    hdr = open(os.path.join(ROOT, "include", "k4sfx.h")).read()
+    vals = dict(re.findall(r"(K4_ERR_\w+)\s*=\s*(-?\d+)", hdr))
+    # teBSFrsltCodes (libkit4b/ErrorCodes.h:15-97): eBSFerrParams=-100, Mem=-95, NotBioseq=-94, OpnFile=-90, ...
+    assert vals["K4_ERR_PARAMS"] == "-100" and vals["K4_ERR_MEM"] == "-95" and vals["K4_ERR_NOT_SFX"] == "-94"
+    assert vals["K4_ERR_OPEN_FILE"] == "-90" and vals["K4_ERR_FILE_VER"] == "-86" and vals["K4_ERR_ENTRY"] == "-51"
+
+
+def test_open_errors_are_loud(L, golden_dir, tmp_path):
+    import torch
+
+    h = C.c_void_p()
+    assert L.k4_open(b"/nonexistent/x.sfx", 0, 0, C.byref(h)) == -90  # eBSFerrOpnFile
+    bad = tmp_path / "bad.sfx"
+    bad.write_bytes(b"nope" * 400)
+    assert L.k4_open(str(bad).encode(), 0, 0, C.byref(h)) == -94  # eBSFerrNotBioseq
+    assert b"magic" in L.k4_global_error()
+    if not torch.cuda.is_available():
+        rc = L.k4_open(os.path.join(golden_dir, "g1.sfx").encode(), 0, 0, C.byref(h))
+        assert rc == -2 and not h.value  # K4_ERR_NO_DEVICE: no CPU fallback
+        assert b"no CPU fallback" in L.k4_global_error()
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under kit4b_amd/ or include/ may mention it."""
+    for base in ("kit4b_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".so", ".o", ".pyc")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "k4oracle" not in txt and "oracle_bindings" not in txt and "libk4ref" not in txt, (dp, fn)

@@ -1,0 +1,196 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI, against
+ (1) the golden vectors captured from the real reference, (2) the CPU oracle on fresh seeded inputs,
+ (3) size-independent properties (embedded truth, .sfx round trip, suffix-array order)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "align_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def k4():
+    import kit4b_amd
+
+    kit4b_amd.lib()  # raises if the HIP extension is missing: no fallback
+    return kit4b_amd
+
+
+def check_against(res, exp, max_hits, what=""):
+    for k in ("rslt", "inst", "low", "nxt"):
+        bad = np.nonzero(res[k] != exp[k])[0]
+        assert len(bad) == 0, (what, k, bad[:8], res[k][bad[:8]], exp[k][bad[:8]])
+    for i in range(len(res["rslt"])):
+        nh = min(int(exp["inst"][i]), max_hits) if exp["rslt"][i] in (1, 2, 3) else 0
+        assert np.array_equal(res["hits"][i, :nh], exp["hits"][i, :nh]), (what, i, res["hits"][i, :nh], exp["hits"][i, :nh])
+        assert not res["hits"][i, nh:].view(np.uint8).any(), (what, i, "stale hit slots")
+
+
+@pytest.mark.parametrize("kmer_k", [0, 5, 11])
+@pytest.mark.parametrize("case", CASES)
+def test_golden_vectors_from_reference(k4, golden_dir, g1_el5_path, case, kmer_k):
+    if kmer_k and case not in ("c2_s2", "c3_pe150_el5", "maxiter3", "short60"):
+        pytest.skip("k sweep on a subset")
+    g = np.load(os.path.join(golden_dir, "align_%s.npz" % case))
+    tm, cl, cd, sl, mcl, md, strand, mh, maxiter = [int(x) for x in g["params"]]
+    ix = k4.SfxIndex.open(g1_el5_path if case.endswith("_el5") else os.path.join(golden_dir, "g1.sfx"), kmer_k=kmer_k)
+    try:
+        info = ix.info()
+        assert info["sfx_el_size"] == (5 if case.endswith("_el5") else 4) and info["concat_len"] == 125425
+        ix.set_max_iter(maxiter)
+        res = ix.align_reads_batch((g["reads"], g["offs"], g["lens"]), tm, cl, cd, sl, mcl, md, strand, mh)
+        check_against(res, g, mh, case)
+        c = ix.counters()
+        assert c["n_reads"] == len(g["lens"])
+    finally:
+        ix.close()
+
+
+def test_fresh_inputs_vs_oracle_raw_and_kalign(k4, oracle):
+    """2 Mbp genome with repeats/N runs, index built by the oracle's suffix sort, 30k reads of mixed lengths."""
+    names, chroms = synth.make_genome([900000, 600000, 400000, 99000, 1000], seed=4242, repeats=200, repeat_len=400,
+                                      repeat_div=0.005, n_runs=10, n_run_len=50, tandem=20)
+    ho = oracle.build(names, chroms, dataset="fresh", threads=8)
+    n = oracle.concat_len(ho)
+    ents = k4.make_entries(names, [len(c) for c in chroms])
+    sa_raw = np.ctypeslib.as_array(
+        __import__("ctypes").cast(oracle.L.k4o_sa_bytes(ho), __import__("ctypes").POINTER(__import__("ctypes").c_uint8)),
+        shape=(n * 4,))
+    ix = k4.SfxIndex.from_host(np.array(oracle.seq(ho)), sa_raw, 4, ents, dataset="fresh")
+    try:
+        oracle.set_max_iter(ho, 5000)
+        ix.set_max_iter(5000)
+        assert ix.min_core_len(0) == oracle.min_core_len(ho, 0)
+        for (rl, tm, cl, cd, sl, mh, md, strand, nr) in [(100, 2, 33, 33, 8, 1, 1, 0, 12000), (150, 3, 37, 37, 12, 10, 1, 0, 8000),
+                                                        (100, 5, 16, 16, 8, 3, 2, 0, 5000), (36, 1, 18, 18, 3, 2, 1, 0, 3000),
+                                                        (300, 6, 42, 42, 24, 4, 1, 0, 2000), (600, 6, 85, 85, 48, 2, 1, 0, 300)]:
+            reads, _ = synth.make_reads(chroms, nr, rl, seed=rl * 31 + tm, n_prob=0.03, edge_frac=0.05, random_frac=0.03)
+            ro = oracle.align_reads_batch(ho, reads, tm, cl, cd, sl, 0, md, strand, mh, threads=8)
+            rg = ix.align_reads_batch(reads, tm, cl, cd, sl, 0, md, strand, mh)
+            check_against(rg, ro, mh, "raw len %d" % rl)
+        # kalign level: mixed read lengths in one batch, SE and PE classification
+        reads = []
+        for rl, nr in ((100, 6000), (75, 2000), (151, 3000), (250, 800)):
+            r, _ = synth.make_reads(chroms, nr, rl, seed=rl + 5, n_prob=0.05, edge_frac=0.05, random_frac=0.03, sub_lambda=1.5)
+            reads += r
+        for kw in (dict(max_subs=2), dict(max_subs=5, max_ml=10, pe_mode=1), dict(max_subs=3, min_edit_dist=2, pmode=1),
+                   dict(max_subs=0), dict(max_subs=2, max_ns=0, strand=1)):
+            eo = oracle.kalign_batch(ho, reads, threads=8, **kw)
+            eg = ix.kalign_batch(reads, **kw)
+            mh = max(1, kw.get("max_ml", 1))
+            for f in ("hit_rslt", "inst", "low_mm", "nxt_mm", "nar", "num_hits"):
+                bad = np.nonzero(eo["out"][f] != eg["out"][f])[0]
+                assert len(bad) == 0, (kw, f, bad[:5], eo["out"][f][bad[:5]], eg["out"][f][bad[:5]])
+            for i in range(len(reads)):
+                r = eo["out"][i]
+                nh = min(int(r["inst"]), mh) if r["hit_rslt"] in (1, 2, 3) else 0
+                assert np.array_equal(eo["hits"][i, :nh], eg["hits"][i, :nh]), (kw, i)
+            assert (eg["out"]["nar"] == 2).sum() > 0 and (eg["out"]["nar"] == 1).sum() > 0
+    finally:
+        ix.close()
+        oracle.close(ho)
+
+
+def test_truth_property_iid_genome_gpu_built_index(k4, oracle):
+    """Size-independent property: on an i.i.d. genome a read is AA at its truth locus with
+    Mismatches == nsubs iff nsubs <= MaxTotMM, else NL.  Index built entirely on the GPU (suffix sort included)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(synth.GENOME_SEED)
+    lens = [3000000, 2000000, 1500000, 500000]
+    n = sum(lens) + len(lens)
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    o = 0
+    for ln in lens:
+        seq[o:o + ln] = torch.randint(0, 4, (ln,), dtype=torch.uint8, device=dev, generator=g)
+        seq[o + ln] = 7
+        o += ln + 1
+    sa = torch.empty(n, dtype=torch.int32, device=dev)
+    k4.build_sa_device(n, 4, seq.data_ptr(), sa.data_ptr())
+    names = ["chr%d" % (i + 1) for i in range(len(lens))]
+    ents = k4.make_entries(names, lens)
+    ix = k4.SfxIndex.from_device(n, 4, seq.data_ptr(), sa.data_ptr(), ents, keep=(sa,))
+    try:
+        # the GPU suffix array equals the oracle's (ties broken by offset on both sides)
+        seq_h = seq.cpu().numpy()
+        chroms = []
+        o = 0
+        for ln in lens:
+            chroms.append(seq_h[o:o + ln])
+            o += ln + 1
+        ho = oracle.build(names, chroms, threads=8)
+        assert np.array_equal(oracle.sa(ho), sa.cpu().numpy().astype(np.int64) & 0xFFFFFFFF)
+        reads, truth = synth.make_reads(chroms, 40000, 100, seed=77, sub_lambda=1.0)
+        res = ix.kalign_batch(reads, max_subs=2)
+        out, hits = res["out"], res["hits"][:, 0]
+        ok = truth[:, 3] <= 2
+        assert (out["nar"][ok] == 1).all() and (out["nar"][~ok] == 3).all()
+        assert np.array_equal(hits["chrom_id"][ok], truth[ok, 0]) and np.array_equal(hits["match_loci"][ok], truth[ok, 1])
+        assert np.array_equal(hits["mismatches"][ok], truth[ok, 3])
+        assert np.array_equal(hits["strand"][ok] == ord("-"), truth[ok, 2] == 1)
+        # and read-for-read identical to the oracle
+        eo = oracle.kalign_batch(ho, reads, max_subs=2, threads=8)
+        assert np.array_equal(eo["out"], out) and np.array_equal(eo["hits"][:, 0], hits)
+        c = ix.counters()
+        assert c["n_slow"] < 40 and c["n_lookup"] == eo["counters"]["n_lookup"] and c["n_cand"] == eo["counters"]["n_cand"]
+        oracle.close(ho)
+    finally:
+        ix.close()
+
+
+def test_gpu_suffix_sort_with_repeats_and_n(k4, oracle):
+    """Suffix order incl. deep ties (long exact repeats, tandem blocks, N runs, tiny contigs), 4- and 5-byte elements."""
+    import torch
+
+    names, chroms = synth.make_genome([200000, 120000, 3000, 40, 7], seed=11, repeats=60, repeat_len=900, repeat_div=0.0,
+                                      n_runs=8, n_run_len=200, tandem=15)
+    ho = oracle.build(names, chroms, threads=8)
+    n = oracle.concat_len(ho)
+    seq = torch.from_numpy(np.array(oracle.seq(ho))).cuda()
+    for el in (4, 5):
+        sa = torch.zeros(n * el + 16, dtype=torch.uint8, device="cuda")
+        k4.build_sa_device(n, el, seq.data_ptr(), sa.data_ptr())
+        raw = sa.cpu().numpy()[: n * el].reshape(n, el)
+        v = raw[:, :4].copy().view("<u4").reshape(n).astype(np.int64)
+        if el == 5:
+            assert not raw[:, 4].any()
+        assert np.array_equal(v, oracle.sa(ho)), el
+    oracle.close(ho)
+
+
+def test_write_sfx_roundtrip(k4, golden_dir, tmp_path):
+    """.sfx out == .sfx in for everything the format defines (block + entries byte-identical)."""
+    src = os.path.join(golden_dir, "g1.sfx")
+    ix = k4.SfxIndex.open(src)
+    out = str(tmp_path / "rt.sfx")
+    ix.write_sfx(out)
+    a, b = open(src, "rb").read(), open(out, "rb").read()
+    assert len(a) == len(b) and a[:133] == b[:133] and a[1224:] == b[1224:]
+    e = ix.entry(2)
+    assert (e["name"], e["seq_len"], e["start_ofs"]) == ("chr2", 40000, 60001)
+    assert ix.get_ident("CHR3") == 3
+    s = ix.get_seq(2, 100, 50)
+    assert bytes(s) == a[1224 + 20 + 60001 + 100: 1224 + 20 + 60001 + 150]
+    ix.close()
+
+
+def test_empty_and_degenerate_batches(k4, golden_dir):
+    ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    r = ix.align_reads_batch([], 2, 33, 33, 8)
+    assert len(r["rslt"]) == 0
+    # a read shorter than the core, a read of all N, a 1-base read: the reference semantics are "no cores fit"
+    reads = [np.zeros(20, np.uint8), np.full(100, 4, np.uint8), np.array([2], np.uint8)]
+    r = ix.align_reads_batch(reads, 2, 33, 33, 8)
+    assert list(r["rslt"]) == [0, 0, 0] and list(r["inst"]) == [0, 0, 0]
+    with pytest.raises(k4.K4Error):
+        ix.align_reads_batch(reads, 2, 0, 33, 8)
+    ix.close()
