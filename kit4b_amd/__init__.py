@@ -87,6 +87,13 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise K4Error(-2, "%s is missing: run kit4b_amd.build() / make -C kit4b_amd/csrc" % LIB_PATH)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (soname libamdhip64.so.7).  Loading torch
+    # first makes libk4sfx.so's NEEDED libamdhip64.so.7 resolve to that already-loaded copy; the other order leaves
+    # two runtimes in the process and the second one finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
     L.k4_open.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
