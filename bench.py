@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s of the kalign hot path on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): 50 M synthetic 100 bp SE reads against a 3 Gbp synthetic genome
+(24 x 125 Mbp i.i.d. ACGT), kalign parameters -s2 (<= 2 mismatches), everything else default.  One STEP = one pass of
+the hot path (read packing + seed lookup + Hamming extension + per-read classification, i.e. CKAligner::AlignRead for
+every read) over the rank's 50 M reads, inputs and outputs resident in HBM.  N > 1: every rank holds the whole index
+and its own 50 M reads (weak scaling: C4 = 400 M reads over 8 GPUs); no data-path collective, one RCCL all-reduce of
+the per-rank NAR histogram after the timed region (the "final aligned-read count/merge").
+
+Setup that is NOT timed: genome + reads synthesis on the GPU (torch RNG), suffix-array construction on the GPU
+(k4_build_sa_device), index packing + k-mer table (k4_open_device), workspace reservation.
+Extra objects in the JSON line: "roofline" (algorithmic bytes of SURVEY.md 8(d) with run-time counted lookups and
+candidates / live HIP-event duration of k4k_align_fast) and "cpu_baseline" (the CPU oracle, all host cores, on a bounded
+sample of the same reads and the same index; also used as a read-for-read parity check at full scale).
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import kit4b_amd as k4  # noqa: E402
+
+GENOME_SEED = 0x4B495434
+READS_SEED = 0x52454144 + 1
+HBM_PEAK = 8.0e12  # bytes/s, MI355X_MICROARCH.md
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def make_genome(dev, n_chrom, chrom_len):
+    g = torch.Generator(device=dev)
+    g.manual_seed(GENOME_SEED)
+    n = n_chrom * (chrom_len + 1)
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    for c in range(n_chrom):
+        o = c * (chrom_len + 1)
+        seq[o:o + chrom_len] = torch.randint(0, 4, (chrom_len,), dtype=torch.uint8, device=dev, generator=g)
+        seq[o + chrom_len] = 7  # eBaseEOS after every entry (SfxArray.cpp:1746-1750)
+    return seq
+
+
+def make_reads(seq, n_chrom, chrom_len, n_reads, read_len, seed, dev, chunk=1 << 20):
+    """simreads semantics: uniform start, strand 50/50, substitutions ~ Poisson(1) truncated at 8 at
+    distinct uniform positions, substituted base != original.  Returns reads [n, L] u8 and truth [n, 4] i64."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    reads = torch.empty((n_reads, read_len), dtype=torch.uint8, device=dev)
+    truth = torch.empty((n_reads, 4), dtype=torch.int64, device=dev)  # chrom(1-based), start, strand, nsubs
+    valid = chrom_len - read_len + 1
+    ar = torch.arange(read_len, device=dev)
+    for b in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - b)
+        u = torch.randint(0, n_chrom * valid, (m,), device=dev, generator=g)
+        c = u // valid
+        off = u - c * valid
+        start = c * (chrom_len + 1) + off
+        r = seq[start[:, None] + ar[None, :]]
+        nsubs = torch.poisson(torch.ones(m, device=dev), generator=g).clamp_(max=8).to(torch.int64)
+        score = torch.rand((m, read_len), device=dev, generator=g)
+        pos = score.topk(8, dim=1).indices  # 8 distinct uniform positions
+        use = torch.arange(8, device=dev)[None, :] < nsubs[:, None]
+        delta = torch.randint(1, 4, (m, 8), device=dev, generator=g, dtype=torch.uint8)
+        old = r.gather(1, pos)
+        new = torch.where(use, (old + delta) % 4, old)
+        r.scatter_(1, pos, new)
+        strand = torch.randint(0, 2, (m,), device=dev, generator=g)
+        rc = (3 - r).flip(1)
+        r = torch.where(strand[:, None] == 1, rc, r)
+        reads[b:b + m] = r
+        truth[b:b + m, 0] = c + 1
+        truth[b:b + m, 1] = off
+        truth[b:b + m, 2] = strand
+        truth[b:b + m, 3] = nsubs
+        del r, rc, score, pos, use, delta, old, new
+    return reads, truth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chroms", type=int, default=24)
+    ap.add_argument("--chrom-mbp", type=float, default=125.0)
+    ap.add_argument("--reads", type=int, default=50_000_000)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--max-subs", type=int, default=2)
+    ap.add_argument("--kmer-k", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL over xGMI on ROCm
+
+    chrom_len = int(args.chrom_mbp * 1e6)
+    n_chrom = args.chroms
+    L = args.read_len
+    t0 = time.time()
+    seq = make_genome(dev, n_chrom, chrom_len)
+    n = seq.numel()
+    torch.cuda.synchronize()
+    log(rank, "genome %d x %d bp = %.3f Gbp in %.1fs" % (n_chrom, chrom_len, n_chrom * chrom_len / 1e9, time.time() - t0))
+    t0 = time.time()
+    sa = torch.empty(n, dtype=torch.int32, device=dev)
+    k4.build_sa_device(n, 4, seq.data_ptr(), sa.data_ptr(), device=local_rank)
+    t_sa = time.time() - t0
+    log(rank, "suffix array (%d elements) built on the GPU in %.1fs" % (n, t_sa))
+    t0 = time.time()
+    names = ["chr%d" % (i + 1) for i in range(n_chrom)]
+    ents = k4.make_entries(names, [chrom_len] * n_chrom)
+    ix = k4.SfxIndex.from_device(n, 4, seq.data_ptr(), sa.data_ptr(), ents, dataset="syn3g", device=local_rank,
+                                 kmer_k=args.kmer_k, keep=(sa,))
+    info = ix.info()
+    ix.set_max_iter(5000)  # cDfltKASensCoreIters, KAligner.cpp:373-388
+    log(rank, "index packed: k=%d, %.1f GB in HBM, %.1fs" % (info["kmer_k"], info["device_bytes"] / 1e9, time.time() - t0))
+
+    t0 = time.time()
+    n_reads = args.reads
+    reads, truth = make_reads(seq, n_chrom, chrom_len, n_reads, L, READS_SEED + rank, dev)
+    offs = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
+    lens = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
+    out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
+    hits = torch.zeros((n_reads, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    log(rank, "%d reads x %d bp synthesised in %.1fs" % (n_reads, L, time.time() - t0))
+
+    kp = k4.KalignParams(args.max_subs, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+    ix.reserve(n_reads, L, 1)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ix.kalign_batch_dev(kp, n_reads, L, reads.data_ptr(), offs.data_ptr(), lens.data_ptr(), out.data_ptr(),
+                            hits.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ix.reset_counters()
+    ix.enable_kernel_timing(True)
+    ix.kernel_times()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fast_ms, launches = ix.kernel_times()
+    ix.enable_kernel_timing(False)
+    ctr = ix.counters()
+
+    # ---- after the timed region: the count/merge collective and the parity checks --------------------------------
+    nar_hist = torch.bincount(out[:, 4].to(torch.int64), minlength=8)[:8]
+    if world > 1:
+        dist.all_reduce(nar_hist, op=dist.ReduceOp.SUM)  # RCCL: the only collective on this path
+    nar = nar_hist.tolist()
+
+    # (1) truth property on i.i.d. genomes: AA at the truth locus with Mismatches == nsubs iff nsubs <= MaxTotMM, else NL
+    max_tot_mm = 0 if args.max_subs == 0 else max(1, int(0.5 + L * args.max_subs / 100.0))
+    ok = truth[:, 3] <= max_tot_mm
+    hv = hits.view(torch.uint8).view(n_reads, 16)
+    h_chrom = hits[:, 0].to(torch.int64)
+    h_loci = hits[:, 1].to(torch.int64) & 0xFFFFFFFF
+    h_strand = hv[:, 10].to(torch.int64)
+    h_mm = hv[:, 11].to(torch.int64)
+    good = torch.where(
+        ok,
+        (out[:, 4] == k4.NAR_ACCEPTED) & (h_chrom == truth[:, 0]) & (h_loci == truth[:, 1]) & (h_mm == truth[:, 3])
+        & ((h_strand == ord("-")) == (truth[:, 2] == 1)),
+        out[:, 4] == k4.NAR_NOHIT,
+    )
+    truth_viol = int((~good).sum().item())
+
+    # (2) CPU baseline = the oracle on all host cores over a bounded sample, same index, same reads (rank 0, N=1 only)
+    cpu = None
+    parity_sample = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_bindings import Entry as OEntry, Oracle
+
+        O = Oracle()
+        t0 = time.time()
+        seq_h = seq.cpu().numpy()
+        sa_h = sa.cpu().numpy().view(np.uint8)
+        oents = (OEntry * n_chrom)()
+        for i in range(n_chrom):
+            oents[i].entry_id = i + 1
+            oents[i].fblock_id = 1
+            oents[i].name = names[i].encode()
+            oents[i].seq_len = chrom_len
+            oents[i].start_ofs = i * (chrom_len + 1)
+            oents[i].end_ofs = i * (chrom_len + 1) + chrom_len - 1
+        ho = O.L.k4o_from_parts(n, 4, seq_h.ctypes.data, sa_h.ctypes.data, n_chrom, oents, b"syn3g")
+        O.set_max_iter(ho, 5000)
+        log(rank, "index copied to the host for the CPU baseline in %.1fs" % (time.time() - t0))
+        S = min(args.cpu_sample, n_reads)
+        cores = os.cpu_count() or 1
+        cat = reads[:S].cpu().numpy().reshape(-1)
+        o_h = (np.arange(S, dtype=np.uint64) * L)
+        l_h = np.full(S, L, dtype=np.uint32)
+        t0 = time.perf_counter()
+        ro = O.kalign_batch(ho, (cat, o_h, l_h), max_subs=args.max_subs, threads=cores)
+        t_cpu = time.perf_counter() - t0
+        cpu = {"value": S / t_cpu / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port",
+               "sample": "first %d of the %d reads, same 3 Gbp index, oracle/k4oracle.c on %d threads, %.1f s" % (S, n_reads, cores, t_cpu)}
+        g_out = out[:S].cpu().numpy()
+        g_hits = hits[:S].cpu().numpy().view(np.uint8).reshape(S, 16)
+        o_out = ro["out"].view(np.int32).reshape(S, 6)
+        o_hits = ro["hits"][:, 0].view(np.uint8).reshape(S, 16)
+        parity_sample = {"reads": S, "result_mismatches": int((g_out != o_out).any(axis=1).sum()),
+                         "hit_mismatches": int((g_hits != o_hits).any(axis=1).sum())}
+        O.close(ho)
+
+    if rank == 0:
+        total_reads = n_reads * world * args.steps
+        value = total_reads / elapsed / 1e6
+        # roofline of the dominant kernel (k4k_align_fast), SURVEY.md 8(d) algorithmic bytes, counted at run time
+        Lbits = math.ceil(math.log2(n))
+        E = 4
+        per_launch = {k: ctr[k] / max(launches, 1) for k in ("n_reads", "n_lookup", "n_probe", "n_cand", "n_slow")}
+        b_lookup = Lbits * (E + 8)
+        b_cand = E + 8 * math.ceil(L / 32)
+        alg_bytes = per_launch["n_lookup"] * b_lookup + per_launch["n_cand"] * b_cand + per_launch["n_reads"] * (L + 16)
+        k_ms = fast_ms / max(launches, 1)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        full = (n_chrom == 24 and chrom_len == 125_000_000 and n_reads == 50_000_000 and L == 100 and args.max_subs == 2)
+        line = {
+            "metric": "Mreads/sec aligned (100 bp SE vs 3 Gbp .sfx)",
+            "value": value,
+            "unit": "Mreads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("C2: %d x %d bp SE reads per GPU vs %.2f Gbp synthetic genome (%d x %d bp), kalign -s%d"
+                             % (n_reads, L, n_chrom * chrom_len / 1e9, n_chrom, chrom_len, args.max_subs))
+                + ("" if full else " [REDUCED: not the BASELINE configuration]"),
+                "reads_per_gpu": n_reads, "read_len": L, "genome_bp": n_chrom * chrom_len, "sfx_el_size": 4,
+                "kmer_table_k": info["kmer_k"], "index_hbm_gb": round(info["device_bytes"] / 1e9, 2),
+                "parallelism": "reads sharded per GPU, index replicated, RCCL all-reduce of NAR counts only",
+                "sa_build_s": round(t_sa, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+                "kernel": "k4k_align_fast", "kernel_ms": k_ms, "launches": launches,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_per_read": alg_bytes / max(per_launch["n_reads"], 1),
+                "lookups_per_read": per_launch["n_lookup"] / max(per_launch["n_reads"], 1),
+                "probes_per_read": per_launch["n_probe"] / max(per_launch["n_reads"], 1),
+                "cands_per_read": per_launch["n_cand"] / max(per_launch["n_reads"], 1),
+                "slow_path_reads_per_launch": per_launch["n_slow"],
+            },
+            "cpu_baseline": cpu,
+            "parity": {"nar_histogram": {"AA": nar[1], "EN": nar[2], "NL": nar[3], "MH": nar[4], "ML": nar[5]},
+                       "truth_property_violations_rank0": truth_viol, "oracle_sample": parity_sample},
+        }
+        print(json.dumps(line), flush=True)
+    ix.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -182,6 +182,11 @@ int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n_reads
                         void* stream);
 int k4_min_core_len(const k4_index* ix, int pmode, int* max_num_slides); /* <- LocateCoredApprox, KAligner.cpp:9367-9393 */
 
+/* kernel timing for roofline measurement: when enabled, every batch brackets the dominant kernel (k4k_align_fast) with
+ * HIP events on the stream it is launched on; k4_get_kernel_times synchronises, returns the summed duration and the
+ * number of launches since the last call, and resets. */
+int k4_enable_kernel_timing(k4_index* ix, int on);
+int k4_get_kernel_times(k4_index* ix, double* fast_kernel_ms, int32_t* launches);
 int k4_get_counters(k4_index* ix, k4_counters* out); /* synchronises the device */
 int k4_reset_counters(k4_index* ix);
 int k4_abi_version(void);

@@ -70,7 +70,8 @@ ABI_SYMBOLS = [
     "k4_open", "k4_open_host", "k4_open_device", "k4_close", "k4_last_error", "k4_global_error", "k4_info",
     "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
-    "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version",
+    "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
+    "k4_get_kernel_times",
 ]
 
 
@@ -119,6 +120,8 @@ def lib():
     L.k4_min_core_len.argtypes = [vp, i32, C.POINTER(C.c_int)]
     L.k4_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.k4_reset_counters.argtypes = [vp]
+    L.k4_enable_kernel_timing.argtypes = [vp, i32]
+    L.k4_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -239,6 +242,15 @@ class SfxIndex:
 
     def reset_counters(self):
         self._ck(lib().k4_reset_counters(self.h))
+
+    def enable_kernel_timing(self, on=True):
+        self._ck(lib().k4_enable_kernel_timing(self.h, 1 if on else 0))
+
+    def kernel_times(self):
+        """(summed k4k_align_fast milliseconds, launches) since the last call; synchronises."""
+        ms, n = C.c_double(0), C.c_int32(0)
+        self._ck(lib().k4_get_kernel_times(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def reserve(self, max_reads, max_read_len, max_hits):
         self._ck(lib().k4_reserve(self.h, max_reads, max_read_len, max_hits))

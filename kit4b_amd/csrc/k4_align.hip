@@ -702,6 +702,17 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, hipStream_t st)
   int64_t pt = a.n_reads * a.nw;
   hipLaunchKernelGGL(k4k_pack_reads, dim3((unsigned)((pt + 255) / 256)), dim3(256), 0, st, a, w.packed);
   unsigned grid = (unsigned)((a.n_reads + 255) / 256);
+  const bool timed = ix->timing && ix->ev_used < 4096;
+  if (timed) {
+    if (ix->ev_used == ix->ev0.size()) {
+      hipEvent_t e0, e1;
+      K4_HIP(ix, hipEventCreate(&e0));
+      K4_HIP(ix, hipEventCreate(&e1));
+      ix->ev0.push_back(e0);
+      ix->ev1.push_back(e1);
+    }
+    K4_HIP(ix, hipEventRecord(ix->ev0[ix->ev_used], st));
+  }
   size_t lds = (size_t)2 * (nch + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4;
   switch (nch) {
     case 4: hipLaunchKernelGGL((k4k_align_fast<EL, 4>), dim3(grid), dim3(256), lds, st, a); break;
@@ -711,6 +722,10 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, hipStream_t st)
       K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_fast<EL, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k4k_align_fast<EL, 16>), dim3(grid), dim3(256), lds, st, a);
       break;
+  }
+  if (timed) {
+    K4_HIP(ix, hipEventRecord(ix->ev1[ix->ev_used], st));
+    ix->ev_used++;
   }
   hipLaunchKernelGGL((k4k_align_slow<EL>), dim3((w.slow_lanes + 63) / 64), dim3(64), 0, st, a, w.slow_lanes);
   K4_HIP(ix, hipGetLastError());
@@ -866,6 +881,28 @@ extern "C" int k4_kalign_batch(k4_index* ix, const k4_kalign_params* p, int64_t 
   K4_HIP(ix, hipMemcpyAsync(out, w.d_out4, (size_t)n * sizeof(k4_read_result), hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_ml * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipStreamSynchronize(ix->stream));
+  return K4_OK;
+}
+
+extern "C" int k4_enable_kernel_timing(k4_index* ix, int on) {
+  if (!ix) return K4_ERR_PARAMS;
+  ix->timing = on != 0;
+  return K4_OK;
+}
+
+extern "C" int k4_get_kernel_times(k4_index* ix, double* fast_ms, int32_t* launches) {
+  if (!ix || !fast_ms || !launches) return K4_ERR_PARAMS;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  K4_HIP(ix, hipDeviceSynchronize());
+  double tot = 0;
+  for (size_t j = 0; j < ix->ev_used; j++) {
+    float ms = 0;
+    K4_HIP(ix, hipEventElapsedTime(&ms, ix->ev0[j], ix->ev1[j]));
+    tot += ms;
+  }
+  *fast_ms = tot;
+  *launches = (int32_t)ix->ev_used;
+  ix->ev_used = 0;
   return K4_OK;
 }
 

@@ -526,6 +526,8 @@ extern "C" void k4_close(k4_index* ix) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (ix->stream) hipStreamDestroy(ix->stream);
+  for (hipEvent_t e : ix->ev0) hipEventDestroy(e);
+  for (hipEvent_t e : ix->ev1) hipEventDestroy(e);
   delete ix;
 }
 

@@ -86,6 +86,9 @@ struct k4_index {
   std::string err;
   K4Workspace ws;
   hipStream_t stream = nullptr; // internal stream for the host-pointer entry points
+  bool timing = false;          // bracket k4k_align_fast with events
+  std::vector<hipEvent_t> ev0, ev1;
+  size_t ev_used = 0;
 };
 
 void k4_set_global_error(const char* fmt, ...);
