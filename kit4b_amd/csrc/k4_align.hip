@@ -7,8 +7,11 @@
 //   CKAligner::AlignRead            ngskit4b/KAligner.cpp:9583-10105  per-read parameters + NAR classification
 //
 // Kernels:
-//   k4k_pack_reads   etSeqBase bytes -> 2-bit words (forward and reverse complement), per-read N / symbol flags
-//   k4k_align_fast   one lane per read.  Seed lookup = one k-mer table fetch + a short lower-bound search whose every
+//   k4k_align_step   one launch per AlignReads phase ("step"), one lane per surviving read.  Step 0 packs the read
+//                    bytes to 2-bit words (forward + reverse complement) in LDS; a read leaves at the first phase
+//                    whose result is non-zero, the others are compacted (wave ballot + prefix popcount + one atomic
+//                    per wave) together with their packed rows into the next step's input, so every step runs with
+//                    full waves.  Seed lookup = one k-mer table fetch + a short lower-bound search whose every
 //                    probe fetches the whole read-aligned reference window, so the same registers give the core
 //                    comparison (ordering) and the Hamming distance (XOR + popcount).  Reads that meet anything the
 //                    2-bit form cannot express (N, a separator in a window) or more than K4_DEDUP_CAP candidates in
@@ -24,6 +27,10 @@
 #define K4_RF_HAS_N 1u
 #define K4_RF_INVALID 2u
 #define K4_RF_TOOLONG 4u
+#ifndef K4_STEP_WAVES
+#define K4_STEP_WAVES 4  // waves per SIMD the step kernel is register-budgeted for
+#endif
+#define K4_CTL_WORDS 72  // [0] slow count, [1] slow head, [2+t] survivors of step t
 
 struct K4AlignArgs {
   K4DevIndex ix;
@@ -31,7 +38,6 @@ struct K4AlignArgs {
   const uint64_t* offs;
   const uint32_t* lens;
   int64_t n_reads;
-  int64_t cap_reads;  // row pitch of `packed`
   int32_t mode;       // 0: AlignReads with uniform parameters, 1: CKAligner::AlignRead
   k4_align_params ap;
   k4_kalign_params kp;  // min_core_len / max_num_slides already resolved
@@ -42,9 +48,8 @@ struct K4AlignArgs {
   k4_read_result* rr;
   k4_hit* hits;
   int32_t max_hits;
-  const uint64_t* packed;
-  uint32_t* rflags;
   uint32_t* slow_list;
+  uint8_t* slow_step;  // phase ordinal at which the read left the fast path (its earlier phases are already tallied)
   uint32_t* ctl;
   unsigned long long* counters;
   uint8_t* slow_probe;
@@ -158,49 +163,10 @@ K4_DEV void k4d_finalize(const K4AlignArgs& a, int64_t i, int len, const K4ReadP
   a.rr[i] = r;
 }
 
-K4_DEV void k4d_push_slow(const K4AlignArgs& a, int64_t i) {
+K4_DEV void k4d_push_slow(const K4AlignArgs& a, int64_t i, int step) {
   uint32_t slot = atomicAdd(&a.ctl[0], 1u);
   a.slow_list[slot] = (uint32_t)i;
-}
-
-// ==== read packing =================================================================================================
-// thread t = read * nw + w builds forward word w and reverse-complement word w (32 bases each, MSB-first)
-__global__ void __launch_bounds__(256) k4k_pack_reads(K4AlignArgs a, uint64_t* __restrict__ packed) {
-  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int64_t i = t / a.nw;
-  int w = (int)(t - i * a.nw);
-  if (i >= a.n_reads) return;
-  int len = (int)a.lens[i];
-  const uint8_t* src = a.reads + a.offs[i];
-  uint64_t fw = 0, rc = 0;
-  uint32_t nN = 0, fl = 0;
-  if (len > K4_MAX_FAST_READ_LEN || len < 1) {
-    fl |= K4_RF_TOOLONG;
-    if (w == 0) {  // the general kernel needs the N count / symbol check too
-      for (int j = 0; j < len; j++) {
-        uint32_t b = src[j] & 7;
-        if (b == 4) nN++; else if (b > 4) fl |= K4_RF_INVALID;
-      }
-    }
-  } else {
-    for (int j = 0; j < 32; j++) {
-      int q = w * 32 + j;
-      uint32_t b = 0, c = 0;
-      if (q < len) {
-        b = src[q] & 7;
-        if (b == 4) { nN++; b = 0; } else if (b > 4) { fl |= K4_RF_INVALID; b = 0; }
-        c = src[len - 1 - q] & 7;
-        c = c > 3 ? 0 : 3 - c;
-      }
-      fw = (fw << 2) | b;
-      rc = (rc << 2) | c;
-    }
-  }
-  if (nN) fl |= K4_RF_HAS_N;
-  packed[(int64_t)(0 * a.nw + w) * a.cap_reads + i] = fw;
-  packed[(int64_t)(1 * a.nw + w) * a.cap_reads + i] = rc;
-  if (fl) atomicOr(&a.rflags[i], fl);             // low byte: flags (OR), bits 8..: number of N (ADD); disjoint fields
-  if (nN) atomicAdd(&a.rflags[i], nN << 8);
+  a.slow_step[slot] = (uint8_t)step;
 }
 
 // ==== fast kernel ==================================================================================================
@@ -350,69 +316,186 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
   return k4d_lcm_result(*p_inst, *p_low, p_nxt, st, rp.mm_delta, rp.max_hits, p_inst, p_low);
 }
 
-template <int EL, int NCH>
-__global__ void __launch_bounds__(256) k4k_align_fast(K4AlignArgs a) {
+// reverse the order of the 32 two-bit groups of a word
+K4_DEV uint64_t k4d_rev2(uint64_t x) {
+  uint64_t y = __brevll(x);
+  return ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);
+}
+
+// etSeqBase bytes -> this lane's LDS column: forward words [0][c], reverse-complement words [1][c], pad words zero.
+// Returns K4_RF_* flags; n_ns = number of N (the fast path cannot express N: such reads go to the general kernel).
+template <int NCH>
+K4_DEV uint32_t k4d_pack_read(const uint8_t* __restrict__ src, int len, uint64_t* col, uint32_t& n_ns) {
+  constexpr int NW = NCH + 1;
+  uint32_t fl = 0;
+  n_ns = 0;
+  const bool aligned = (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    uint64_t acc = 0;
+    if (32 * c < len) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int base = c * 32 + q * 4;
+        uint32_t d = 0;
+        if (base + 4 <= len && aligned) d = reinterpret_cast<const uint32_t*>(src)[c * 8 + q];
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (base + k < len) d |= (uint32_t)src[base + k] << (8 * k);
+        }
+        d &= 0x07070707u;
+        if (base + 4 > len) d &= len > base ? (0xFFFFFFFFu >> (8 * (4 - (len - base)))) : 0u;  // bytes past the end
+        // N / invalid detection on the four bytes at once: bit 2 set => symbol >= 4
+        const uint32_t hi4 = d & 0x04040404u;
+        if (hi4) {
+          const uint32_t inval = hi4 & ((d << 1) | (d << 2)) & 0x04040404u;  // 5,6,7: bit2 and (bit1 or bit0)
+          if (inval) fl |= K4_RF_INVALID;
+          n_ns += __popc(hi4 & ~inval);
+          d &= ~(hi4 | (hi4 >> 1) | (hi4 >> 2));  // such symbols pack as 0
+        }
+        acc = (acc << 8) | ((d & 3) << 6) | (((d >> 8) & 3) << 4) | (((d >> 16) & 3) << 2) | ((d >> 24) & 3);
+      }
+    }
+    col[c * 256] = acc;
+  }
+  col[NCH * 256] = 0;
+  if (n_ns) fl |= K4_RF_HAS_N;
+  // reverse complement from the stored forward words: rc bases [32c, 32c+32) = complement of forward bases
+  // [len-32(c+1), len-32c) in reverse order
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    uint64_t r = 0;
+    if (32 * c < len) {
+      const int o = len - 32 * (c + 1);
+      uint64_t f;
+      if (o >= 0) {
+        const int w = o >> 5, sh = 2 * (o & 31);
+        const uint64_t hi = col[w * 256];
+        f = sh ? (hi << sh) | (col[(w + 1) * 256] >> (64 - sh)) : hi;
+      } else
+        f = col[0] >> (2 * (-o));  // fewer than 32 bases left: they sit at the low end, zeros above
+      r = k4d_rev2(~f) & k4d_range_mask(0, len - 32 * c);
+    }
+    col[(NW + c) * 256] = r;
+  }
+  col[(NW + NCH) * 256] = 0;
+  return fl;
+}
+
+// One AlignReads phase per launch.  FIRST: lanes take reads j = 0..n_reads-1 and pack them; later steps take the
+// compacted survivors (ids + packed rows) of the previous step.
+template <int EL, int NCH, bool FIRST>
+__global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs a, int step, const uint32_t* __restrict__ in_ids,
+                                                      const uint64_t* __restrict__ in_rows,
+                                                      const uint32_t* __restrict__ in_count, uint32_t* __restrict__ out_ids,
+                                                      uint64_t* __restrict__ out_rows, uint32_t* __restrict__ out_count) {
   extern __shared__ uint64_t lds[];
   constexpr int NW = NCH + 1;
   const int tid = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-  uint32_t n_lookup = 0, n_probe = 0, n_cand = 0, n_slow = 0, n_bases = 0;
-  if (i < a.n_reads) {
-    K4Lane<NCH> ln;
-    ln.rd = lds + tid;
-    ln.ded = reinterpret_cast<uint32_t*>(lds + 2 * NW * 256) + tid;
-    uint64_t* mine = lds + tid;
-#pragma unroll
-    for (int w = 0; w < 2 * NW; w++) mine[w * 256] = (w % NW) < a.nw ? a.packed[(int64_t)((w / NW) * a.nw + (w % NW)) * a.cap_reads + i] : 0ull;
-    const uint32_t fl = a.rflags[i];
+  const int lane = tid & 63;
+  K4Lane<NCH> ln;
+  ln.rd = lds + tid;
+  ln.ded = reinterpret_cast<uint32_t*>(lds + 2 * NW * 256) + tid;
+  uint64_t* col = lds + tid;
+  uint32_t n_lookup = 0, n_probe = 0, n_cand = 0, n_slow = 0, n_bases = 0, n_done = 0;
+  const int64_t count = FIRST ? a.n_reads : (int64_t)*in_count;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + tid; j < count; j += stride) {
+    const int64_t i = FIRST ? j : (int64_t)in_ids[j];
     const int len = (int)a.lens[i];
-    n_bases = (uint32_t)len;
     const K4ReadParams rp = k4d_read_params(a, len);
-    bool slow = (fl & (K4_RF_HAS_N | K4_RF_TOOLONG | K4_RF_INVALID)) != 0 || len > 32 * NCH;
-    if (a.mode == 1) {  // AlignRead: too many Ns / a symbol above N -> NAR Ns, KAligner.cpp:9618-9640
-      int max_ns = 0;
-      if (a.kp.max_ns) max_ns = max((len * a.kp.max_ns) / 100, a.kp.max_ns);
-      if ((fl & K4_RF_INVALID) || (int)(fl >> 8) > max_ns) {
-        k4_read_result r = {K4_HR_SEQERRS, 0, 0, 0, K4_NAR_NS, 0};
-        a.rr[i] = r;
-        for (int q = 0; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&a.hits[i * a.max_hits + q]) = make_uint4(0, 0, 0, 0);
-        slow = false;
-        goto done;
-      }
-    }
-    if (rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits) slow = true;  // let the general kernel decide
-    if (!slow) {
-      k4_hit* hits = a.hits + i * a.max_hits;
-      int inst = 0, low = 0, nxt = 0, rslt = 0, allow = 0;
-      if (rp.tot_mm > 0) {  // AlignReads phase escalation, SfxArray.cpp:7867-7881
-        for (allow = 0; allow <= rp.tot_mm; allow++) {
-          int cl = len / (allow + rp.mm_delta);
-          if (cl <= rp.core_len) break;
-          rslt = k4d_lcm_fast<EL, NCH>(a, ln, len, allow, cl, cl, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
-          if (rslt != 0) break;
+    bool slow = false, survive = false;
+    if (FIRST) {
+      n_done++;
+      n_bases += (uint32_t)len;
+      uint32_t fl = 0, n_ns = 0;
+      if (len < 1 || len > 32 * NCH || len > K4_MAX_FAST_READ_LEN) {
+        fl = K4_RF_TOOLONG;
+        if (a.mode == 1) {  // the N rule still applies
+          const uint8_t* src = a.reads + a.offs[i];
+          for (int q = 0; q < len; q++) {
+            uint32_t b = src[q] & 7;
+            if (b == 4) n_ns++; else if (b > 4) fl |= K4_RF_INVALID;
+          }
+        }
+      } else
+        fl = k4d_pack_read<NCH>(a.reads + a.offs[i], len, col, n_ns);
+      if (a.mode == 1) {  // AlignRead: too many Ns / a symbol above N -> NAR Ns, KAligner.cpp:9618-9640
+        int max_ns = 0;
+        if (a.kp.max_ns) max_ns = max((len * a.kp.max_ns) / 100, a.kp.max_ns);
+        if ((fl & K4_RF_INVALID) || (int)n_ns > max_ns) {
+          k4_read_result r = {K4_HR_SEQERRS, 0, 0, 0, K4_NAR_NS, 0};
+          a.rr[i] = r;
+          for (int q = 0; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&a.hits[i * a.max_hits + q]) = make_uint4(0, 0, 0, 0);
+          continue;
         }
       }
-      if (rslt == 0 && allow <= rp.tot_mm)  // final phase, :7885-7891
-        rslt = k4d_lcm_fast<EL, NCH>(a, ln, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, &low, &nxt, hits,
-                                     n_lookup, n_probe, n_cand);
-      if (rslt == K4_NEED_SLOW) slow = true;
-      else k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
+      slow = fl != 0;
+    } else {
+      const uint64_t* row = in_rows + (int64_t)j * (2 * NCH);
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        col[c * 256] = row[c];
+        col[(NW + c) * 256] = row[NCH + c];
+      }
+      col[NCH * 256] = 0;
+      col[(NW + NCH) * 256] = 0;
+    }
+    if (rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits) slow = true;  // the general kernel reports it
+    if (!slow) {
+      // which AlignReads phase is this read's step-th?  (SfxArray.cpp:7867-7891)
+      int n_esc = 0;
+      if (rp.tot_mm > 0)
+        for (; n_esc <= rp.tot_mm; n_esc++)
+          if (len / (n_esc + rp.mm_delta) <= rp.core_len) break;
+      const bool has_final = rp.tot_mm > 0 ? n_esc <= rp.tot_mm : true;
+      const int n_phases = n_esc + (has_final ? 1 : 0);
+      int allow, cl, delta;
+      if (step < n_esc) { allow = step; cl = len / (step + rp.mm_delta); delta = cl; }
+      else { allow = rp.tot_mm; cl = rp.core_len; delta = rp.core_delta; }
+      k4_hit* hits = a.hits + i * a.max_hits;
+      int inst = 0, low = 0, nxt = 0;
+      const uint32_t c0 = n_lookup, c1 = n_probe, c2 = n_cand;
+      int rslt = k4d_lcm_fast<EL, NCH>(a, ln, len, allow, cl, delta, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
+      if (rslt == K4_NEED_SLOW) {  // the general kernel redoes (and tallies) this phase
+        slow = true;
+        n_lookup = c0; n_probe = c1; n_cand = c2;
+      }
+      else if (rslt != 0 || step + 1 >= n_phases) k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
+      else survive = true;
     }
     if (slow) {
-      k4d_push_slow(a, i);
-      n_slow = 1;
-      n_lookup = n_probe = n_cand = 0;  // the general kernel recounts this read
+      k4d_push_slow(a, i, step);
+      n_slow++;
+    }
+    // compaction of the survivors: one atomic per wave, slots by prefix popcount of the ballot
+    const unsigned long long m = __ballot(survive);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(out_count, (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (survive) {
+        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        out_ids[slot] = (uint32_t)i;
+        uint64_t* row = out_rows + (int64_t)slot * (2 * NCH);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+          row[c] = col[c * 256];
+          row[NCH + c] = col[(NW + c) * 256];
+        }
+      }
     }
   }
-done:
-  // per-wave tallies -> one atomic per counter per wave
+  // per-wave tallies -> one atomic per counter per wave (lookups of reads that went slow are recounted there)
   {
-    unsigned long long v[6] = {i < a.n_reads ? 1ull : 0ull, n_lookup, n_probe, n_cand, n_slow, n_bases};
+    unsigned long long v[6] = {n_done, n_lookup, n_probe, n_cand, n_slow, n_bases};
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       unsigned long long x = v[q];
       for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-      if ((tid & 63) == 0 && x) atomicAdd(&a.counters[q], x);
+      if (lane == 0 && x) atomicAdd(&a.counters[q], x);
     }
   }
 }
@@ -589,6 +672,9 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_l
       uint32_t q = atomicAdd(&a.ctl[1], 1u);
       if (q >= total) break;
       const int64_t i = a.slow_list[q];
+      const int from_phase = a.slow_step[q];
+      int phase = 0;
+      uint32_t t0, t1, t2;
       const int len = (int)a.lens[i];
       const K4ReadParams rp = k4d_read_params(a, len);
       k4_hit* hits = a.hits + i * a.max_hits;
@@ -603,13 +689,18 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_l
         for (allow = 0; allow <= rp.tot_mm; allow++) {
           int cl = len / (allow + rp.mm_delta);
           if (cl <= rp.core_len) break;
+          t0 = n_lookup; t1 = n_probe; t2 = n_cand;
           rslt = k4d_lcm_slow<EL>(a, sc, len, allow, cl, cl, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
+          if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }  // tallied by the fast path already
           if (rslt != 0) break;
         }
       }
-      if (rslt == 0 && allow <= rp.tot_mm)
+      if (rslt == 0 && allow <= rp.tot_mm) {
+        t0 = n_lookup; t1 = n_probe; t2 = n_cand;
         rslt = k4d_lcm_slow<EL>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, &low, &nxt, hits,
                                 n_lookup, n_probe, n_cand);
+        if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }
+      }
       k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
     }
     a.slow_gen[lane] = sc.gen;
@@ -647,20 +738,23 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
     int64_t cap = std::max<int64_t>(max_reads, w.cap_reads);
     cap = (cap + 255) / 256 * 256;
     int len = std::max(fast_len, w.cap_len);
-    int nw = nch_for(len) + 1;
-    if (w.packed) hipFree(w.packed);
-    if (w.rflags) hipFree(w.rflags);
-    if (w.slow_list) hipFree(w.slow_list);
-    w.packed = nullptr; w.rflags = nullptr; w.slow_list = nullptr;
-    K4_HIP(ix, hipMalloc(&w.packed, (size_t)cap * 2 * nw * 8));
-    K4_HIP(ix, hipMalloc(&w.rflags, (size_t)cap * 4));
+    int nch = nch_for(len);
+    for (void* q : {(void*)w.ids[0], (void*)w.ids[1], (void*)w.rows[0], (void*)w.rows[1], (void*)w.slow_list, (void*)w.slow_step})
+      if (q) hipFree(q);
+    w.ids[0] = w.ids[1] = nullptr; w.rows[0] = w.rows[1] = nullptr; w.slow_list = nullptr; w.slow_step = nullptr;
+    // survivors of step t (ids + packed rows, 2*nch words each) ping-pong between two buffers
+    for (int b = 0; b < 2; b++) {
+      K4_HIP(ix, hipMalloc(&w.ids[b], (size_t)cap * 4));
+      K4_HIP(ix, hipMalloc(&w.rows[b], (size_t)cap * 2 * nch * 8));
+    }
     K4_HIP(ix, hipMalloc(&w.slow_list, (size_t)cap * 4));
+    K4_HIP(ix, hipMalloc(&w.slow_step, (size_t)cap));
     w.cap_reads = cap;
     w.cap_len = len;
   }
   if (!w.ctl) {
-    K4_HIP(ix, hipMalloc(&w.ctl, 64));
-    K4_HIP(ix, hipMemset(w.ctl, 0, 64));
+    K4_HIP(ix, hipMalloc(&w.ctl, K4_CTL_WORDS * 4));
+    K4_HIP(ix, hipMemset(w.ctl, 0, K4_CTL_WORDS * 4));
   }
   // general-kernel scratch: sized from MaxIter (hash holds one strand pass: <= MaxIter per core, <= 1,024,000 nodes)
   uint64_t nodes = ix->d.max_iter ? std::min<uint64_t>((uint64_t)ix->d.max_iter * 48, K4_MAX_IDENT_NODES) : K4_MAX_IDENT_NODES;
@@ -679,29 +773,16 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
   return K4_OK;
 }
 
-template <int EL>
-static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, hipStream_t st) {
+template <int EL, int NCH>
+static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t st) {
   K4Workspace& w = ix->ws;
-  const int nch = nch_for(std::min(max_len, K4_MAX_FAST_READ_LEN));
-  a.nw = nch_for(w.cap_len) + 1;  // pitch the workspace was sized for
-  if (nch + 1 > a.nw) return k4_fail(ix, K4_ERR_INTERNAL, "workspace not reserved for read length %d", max_len);
-  a.nw = nch + 1;
-  a.cap_reads = w.cap_reads;
-  a.packed = w.packed;
-  a.rflags = w.rflags;
-  a.slow_list = w.slow_list;
-  a.ctl = w.ctl;
-  a.counters = (unsigned long long*)ix->counters;
-  a.slow_probe = w.slow_probe;
-  a.slow_hash = w.slow_hash;
-  a.slow_gen = reinterpret_cast<uint32_t*>(w.slow_hash + (size_t)w.slow_lanes * w.slow_hash_cap);
-  a.slow_hash_cap = w.slow_hash_cap;
-  if (a.n_reads == 0) return K4_OK;
-  K4_HIP(ix, hipMemsetAsync(w.rflags, 0, (size_t)a.n_reads * 4, st));
-  K4_HIP(ix, hipMemsetAsync(w.ctl, 0, 8, st));
-  int64_t pt = a.n_reads * a.nw;
-  hipLaunchKernelGGL(k4k_pack_reads, dim3((unsigned)((pt + 255) / 256)), dim3(256), 0, st, a, w.packed);
-  unsigned grid = (unsigned)((a.n_reads + 255) / 256);
+  const size_t lds = (size_t)2 * (NCH + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4;
+  if (lds > 48 * 1024) {
+    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  // grid-stride kernels: enough blocks to fill the chip at the kernel's occupancy, never more than the work
+  const unsigned full = 256 * 8;
   const bool timed = ix->timing && ix->ev_used < 4096;
   if (timed) {
     if (ix->ev_used == ix->ev0.size()) {
@@ -713,20 +794,46 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, hipStream_t st)
     }
     K4_HIP(ix, hipEventRecord(ix->ev0[ix->ev_used], st));
   }
-  size_t lds = (size_t)2 * (nch + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4;
-  switch (nch) {
-    case 4: hipLaunchKernelGGL((k4k_align_fast<EL, 4>), dim3(grid), dim3(256), lds, st, a); break;
-    case 5: hipLaunchKernelGGL((k4k_align_fast<EL, 5>), dim3(grid), dim3(256), lds, st, a); break;
-    case 8: hipLaunchKernelGGL((k4k_align_fast<EL, 8>), dim3(grid), dim3(256), lds, st, a); break;
-    default:
-      K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_fast<EL, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k4k_align_fast<EL, 16>), dim3(grid), dim3(256), lds, st, a);
-      break;
+  unsigned grid0 = (unsigned)std::min<int64_t>((a.n_reads + 255) / 256, full);
+  hipLaunchKernelGGL((k4k_align_step<EL, NCH, true>), dim3(grid0), dim3(256), lds, st, a, 0, (const uint32_t*)nullptr,
+                     (const uint64_t*)nullptr, (const uint32_t*)nullptr, w.ids[0], w.rows[0], w.ctl + 2);
+  for (int t = 1; t < n_steps; t++) {
+    const int in = (t - 1) & 1, out = t & 1;
+    hipLaunchKernelGGL((k4k_align_step<EL, NCH, false>), dim3(grid0), dim3(256), lds, st, a, t, w.ids[in], w.rows[in],
+                       w.ctl + 2 + (t - 1), w.ids[out], w.rows[out], w.ctl + 2 + t);
   }
   if (timed) {
     K4_HIP(ix, hipEventRecord(ix->ev1[ix->ev_used], st));
     ix->ev_used++;
   }
+  return K4_OK;
+}
+
+template <int EL>
+static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hipStream_t st) {
+  K4Workspace& w = ix->ws;
+  const int nch = nch_for(std::min(max_len, K4_MAX_FAST_READ_LEN));
+  if (nch > nch_for(w.cap_len)) return k4_fail(ix, K4_ERR_INTERNAL, "workspace not reserved for read length %d", max_len);
+  if (n_steps < 1 || n_steps > K4_CTL_WORDS - 4) return k4_fail(ix, K4_ERR_INTERNAL, "bad phase count %d", n_steps);
+  a.slow_list = w.slow_list;
+  a.slow_step = w.slow_step;
+  a.ctl = w.ctl;
+  a.counters = (unsigned long long*)ix->counters;
+  a.slow_probe = w.slow_probe;
+  a.slow_hash = w.slow_hash;
+  a.slow_gen = reinterpret_cast<uint32_t*>(w.slow_hash + (size_t)w.slow_lanes * w.slow_hash_cap);
+  a.slow_hash_cap = w.slow_hash_cap;
+  a.nw = nch + 1;
+  if (a.n_reads == 0) return K4_OK;
+  K4_HIP(ix, hipMemsetAsync(w.ctl, 0, K4_CTL_WORDS * 4, st));
+  int rc;
+  switch (nch) {
+    case 4: rc = launch_steps<EL, 4>(ix, a, n_steps, st); break;
+    case 5: rc = launch_steps<EL, 5>(ix, a, n_steps, st); break;
+    case 8: rc = launch_steps<EL, 8>(ix, a, n_steps, st); break;
+    default: rc = launch_steps<EL, 16>(ix, a, n_steps, st); break;
+  }
+  if (rc != K4_OK) return rc;
   hipLaunchKernelGGL((k4k_align_slow<EL>), dim3((w.slow_lanes + 63) / 64), dim3(64), 0, st, a, w.slow_lanes);
   K4_HIP(ix, hipGetLastError());
   return K4_OK;
@@ -740,7 +847,14 @@ static int run_dev(k4_index* ix, K4AlignArgs& a, int max_len, void* stream) {
                    max_len, a.max_hits);
   a.ix = ix->d;
   hipStream_t st = (hipStream_t)stream;
-  return ix->d.el == 4 ? launch_all<4>(ix, a, max_len, st) : launch_all<5>(ix, a, max_len, st);
+  // number of AlignReads phases any read can have: escalation 0..TotMM, or fewer plus the final phase (SfxArray.cpp:7867-7891)
+  int tot_mm = a.ap.tot_mm;
+  if (a.mode == 1) {
+    tot_mm = a.kp.max_subs == 0 ? 0 : std::max(1, (int)(0.5 + (max_len * a.kp.max_subs) / 100.0));
+    tot_mm = std::min(tot_mm, 63);
+  }
+  const int n_steps = tot_mm + 1;
+  return ix->d.el == 4 ? launch_all<4>(ix, a, max_len, n_steps, st) : launch_all<5>(ix, a, max_len, n_steps, st);
 }
 
 static int check_align_params(k4_index* ix, const k4_align_params* p) {

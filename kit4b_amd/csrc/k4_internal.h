@@ -48,10 +48,11 @@ struct K4Workspace {
   int64_t cap_reads = 0;
   int32_t cap_len = 0;
   int32_t cap_hits = 0;
-  uint64_t* packed = nullptr;    // [2 strands][nw][cap_reads]
-  uint32_t* rflags = nullptr;    // per read: bit0 has N, bit1 invalid symbol, bits 8.. count of N
+  uint32_t* ids[2] = {nullptr, nullptr};   // survivors of a step: read ids ...
+  uint64_t* rows[2] = {nullptr, nullptr};  // ... and their packed rows (forward + reverse-complement words)
   uint32_t* slow_list = nullptr; // read ids for the general kernel
-  uint32_t* ctl = nullptr;       // [0] slow count, [1] slow head
+  uint8_t* slow_step = nullptr;  // and the phase ordinal at which each left the fast path
+  uint32_t* ctl = nullptr;       // [0] slow count, [1] slow head, [2+t] survivor count of step t
   uint8_t* slow_probe = nullptr; // per slow lane: probe bytes scratch
   uint64_t* slow_hash = nullptr; // per slow lane: open-addressing table of (generation<<32 | TargSeqID)
   uint32_t slow_lanes = 0;
