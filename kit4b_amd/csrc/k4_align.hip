@@ -30,6 +30,9 @@
 #ifndef K4_STEP_WAVES
 #define K4_STEP_WAVES 4  // waves per SIMD the step kernel is register-budgeted for
 #endif
+#define K4_CHUNK 512         // survivor slots a wave reserves per atomic
+#define K4_NO_READ 0xFFFFFFFFu  // hole in a survivor list
+#define K4_PF 4  // k-mer table entries fetched ahead per strand pass
 #define K4_CTL_WORDS 72  // [0] slow count, [1] slow head, [2+t] survivors of step t
 
 struct K4AlignArgs {
@@ -224,7 +227,7 @@ K4_DEV K4Probe k4d_probe(const K4DevIndex& ix, const K4Lane<NCH>& ln, int s, int
 }
 
 // One LocateCoreMultiples call for one read (SfxArray.cpp:5806-6369), fast form.  Returns tHRslt or K4_NEED_SLOW.
-template <int EL, int NCH>
+template <int EL, int NCH, typename KT>
 K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, int allow_mm, int cl, int core_delta,
                         const K4ReadParams& rp, int* p_inst, int* p_low, int* p_nxt, k4_hit* hits,
                         uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand) {
@@ -252,65 +255,97 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
     int n_ded = 0;
     int cur_delta = core_delta;
     int slides = 0;
-    for (int o = 0; slides < rp.max_slides && o <= len - cl && cur_delta > cl / 3; slides++, o += cur_delta) {
-      if (o + cl + cur_delta > len) cur_delta = len - (o + cl);
-      n_lookup++;
-      // ---- seed lookup: k-mer table interval, then lower bound inside it -------------------------------------
-      uint64_t code = ln.chunk_at(s, o) >> (64 - 2 * kk);
-      int64_t lo = (int64_t)k4d_ktab_at(ix, code << tshift);
-      int64_t hi = (int64_t)k4d_ktab_at(ix, (code + 1) << tshift) - 1;
-      int64_t found = -1;
-      uint64_t fpos = 0;
-      int fmm = 0;
-      while (lo <= hi) {
-        int64_t mid = (lo + hi) >> 1;
-        uint64_t p = k4d_sa_at<EL>(ix, (uint64_t)mid);
-        K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p);
-        n_probe++;
-        if (pr.exc) return K4_NEED_SLOW;
-        if (pr.cmp > 0) lo = mid + 1;
-        else {
-          if (pr.cmp == 0) { found = mid; fpos = p; fmm = pr.mm; }
-          hi = mid - 1;
+    int o_next = 0;
+    bool more = true;
+    while (more && !stop) {
+      // The core offsets of a strand pass depend only on (len, cl, delta) (:5948-5959), so the k-mer table entries of
+      // the next K4_PF cores are fetched together before any of them is searched: one memory round trip, not K4_PF.
+      int oo[K4_PF];
+      KT lb0[K4_PF], ps0[K4_PF], lb1[K4_PF];
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < K4_PF; j++) {
+        oo[j] = 0; lb0[j] = 0; ps0[j] = 0; lb1[j] = 0;
+        if (cnt == j && slides < rp.max_slides && o_next <= len - cl && cur_delta > cl / 3) {
+          if (o_next + cl + cur_delta > len) cur_delta = len - (o_next + cl);
+          oo[j] = o_next;
+          cnt++;
+          slides++;
+          o_next += cur_delta;
         }
       }
-      if (found != lo) continue;  // no suffix starts with this core
-      // ---- walk the run of equal cores in SA order, :5971-6321 ---------------------------------------------------
-      int64_t idx = found;
-      uint64_t p = fpos;
-      int mm = fmm;
-      int iter = 0;
-      bool first = true;
-      while (!max_iter || iter < max_iter) {
-        if (!first) {
-          if (idx + 1 >= n) break;
-          uint64_t p2 = k4d_sa_at<EL>(ix, (uint64_t)idx + 1);
-          if ((int64_t)p2 + cl > n) break;
-          K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p2);
+      more = cnt == K4_PF;
+#pragma unroll
+      for (int j = 0; j < K4_PF; j++) {
+        if (j < cnt) {
+          const uint64_t code = ln.chunk_at(s, oo[j]) >> (64 - 2 * kk);
+          k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], lb1[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < K4_PF; j++) {
+        if (j >= cnt || stop) continue;
+        const int o = oo[j];
+        n_lookup++;
+        // ---- seed lookup: lower bound inside the k-mer bucket [lb0, lb1) -------------------------------------------
+        int64_t lo = (int64_t)lb0[j];
+        int64_t hi = (int64_t)lb1[j] - 1;
+        const int64_t bucket_hi = hi;
+        int64_t found = -1;
+        uint64_t fpos = 0;
+        int fmm = 0;
+        while (lo <= hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          const uint64_t p = mid == (int64_t)lb0[j] ? (uint64_t)ps0[j] : k4d_sa_at<EL>(ix, (uint64_t)mid);
+          const K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p);
           n_probe++;
           if (pr.exc) return K4_NEED_SLOW;
-          if (pr.cmp != 0) break;
-          idx += 1; p = p2; mm = pr.mm;
+          if (pr.cmp > 0) lo = mid + 1;
+          else {
+            if (pr.cmp == 0) { found = mid; fpos = p; fmm = pr.mm; }
+            hi = mid - 1;
+          }
         }
-        first = false;
-        if (p < (uint64_t)o) continue;
-        uint64_t left = p - (uint64_t)o;
-        int e = k4d_map_entry(ix, left);
-        if (e < 0 || left + (uint64_t)len - 1 > ix.ent_end[e]) continue;
-        uint32_t targ_id = (uint32_t)(1 + p - (uint32_t)o);  // :6037 (truncation is the reference's)
-        bool dup = false;
-        for (int q = 0; q < n_ded; q++) dup |= (ln.ded[q * 256] == targ_id);
-        if (dup) continue;
-        if (n_ded >= K4_DEDUP_CAP) return K4_NEED_SLOW;
-        ln.ded[n_ded * 256] = targ_id;
-        n_ded++;
-        iter++;
-        n_cand++;
-        if (mm > allow_mm || mm >= st.nxt) continue;  // the two early-outs of :6200-6261
-        k4d_fold(st, mm, hits, rp.max_hits, ix.ent_id[e], (uint32_t)(left - ix.ent_start[e]), len, strand_c);
-        if (st.inst > rp.max_hits && st.low == 0) break;
+        if (found != lo) continue;  // no suffix starts with this core
+        // ---- walk the run of equal cores in SA order, :5971-6321 -------------------------------------------------
+        int64_t idx = found;
+        uint64_t p = fpos;
+        int mm = fmm;
+        int iter = 0;
+        bool first = true;
+        while (!max_iter || iter < max_iter) {
+          if (!first) {
+            // a suffix beyond the bucket does not share the core's first kk bases: the reference's compare (:5986-6016)
+            // would end the run there, so the probe is skipped
+            if (idx >= bucket_hi || idx + 1 >= n) break;
+            const uint64_t p2 = k4d_sa_at<EL>(ix, (uint64_t)idx + 1);
+            if ((int64_t)p2 + cl > n) break;
+            const K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p2);
+            n_probe++;
+            if (pr.exc) return K4_NEED_SLOW;
+            if (pr.cmp != 0) break;
+            idx += 1; p = p2; mm = pr.mm;
+          }
+          first = false;
+          if (p < (uint64_t)o) continue;
+          const uint64_t left = p - (uint64_t)o;
+          const int e = k4d_map_entry(ix, left);
+          if (e < 0 || left + (uint64_t)len - 1 > ix.ent_end[e]) continue;
+          const uint32_t targ_id = (uint32_t)(1 + p - (uint32_t)o);  // :6037 (truncation is the reference's)
+          bool dup = false;
+          for (int q = 0; q < n_ded; q++) dup |= (ln.ded[q * 256] == targ_id);
+          if (dup) continue;
+          if (n_ded >= K4_DEDUP_CAP) return K4_NEED_SLOW;
+          ln.ded[n_ded * 256] = targ_id;
+          n_ded++;
+          iter++;
+          n_cand++;
+          if (mm > allow_mm || mm >= st.nxt) continue;  // the two early-outs of :6200-6261
+          k4d_fold(st, mm, hits, rp.max_hits, ix.ent_id[e], (uint32_t)(left - ix.ent_start[e]), len, strand_c);
+          if (st.inst > rp.max_hits && st.low == 0) break;
+        }
+        if (st.inst > rp.max_hits && st.low == 0) stop = true;
       }
-      if (st.inst > rp.max_hits && st.low == 0) { stop = true; break; }
     }
   }
   return k4d_lcm_result(*p_inst, *p_low, p_nxt, st, rp.mm_delta, rp.max_hits, p_inst, p_low);
@@ -385,7 +420,7 @@ K4_DEV uint32_t k4d_pack_read(const uint8_t* __restrict__ src, int len, uint64_t
 
 // One AlignReads phase per launch.  FIRST: lanes take reads j = 0..n_reads-1 and pack them; later steps take the
 // compacted survivors (ids + packed rows) of the previous step.
-template <int EL, int NCH, bool FIRST>
+template <int EL, int NCH, bool FIRST, typename KT>
 __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs a, int step, const uint32_t* __restrict__ in_ids,
                                                       const uint64_t* __restrict__ in_rows,
                                                       const uint32_t* __restrict__ in_count, uint32_t* __restrict__ out_ids,
@@ -401,83 +436,100 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0, n_slow = 0, n_bases = 0, n_done = 0;
   const int64_t count = FIRST ? a.n_reads : (int64_t)*in_count;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t j = (int64_t)blockIdx.x * 256 + tid; j < count; j += stride) {
-    const int64_t i = FIRST ? j : (int64_t)in_ids[j];
-    const int len = (int)a.lens[i];
-    const K4ReadParams rp = k4d_read_params(a, len);
+  // Survivor slots are reserved K4_CHUNK at a time (one atomic per chunk, not per wave iteration: a single counter
+  // word serialises at ~88 atomics/us).  ch_cur / ch_left are wave-uniform: every lane of the wave runs every
+  // iteration of this loop, inactive lanes masked, so the copies never diverge.  Unused slots hold K4_NO_READ.
+  uint32_t ch_cur = 0, ch_left = 0;
+  for (int64_t jb = (int64_t)blockIdx.x * 256 + (tid & ~63); jb < count; jb += stride) {
+    const int64_t j = jb + lane;
+    bool active = j < count;
+    int64_t i = 0;
+    if (active) {
+      i = FIRST ? j : (int64_t)in_ids[j];
+      if (!FIRST && (uint32_t)i == K4_NO_READ) active = false;
+    }
     bool slow = false, survive = false;
-    if (FIRST) {
-      n_done++;
-      n_bases += (uint32_t)len;
-      uint32_t fl = 0, n_ns = 0;
-      if (len < 1 || len > 32 * NCH || len > K4_MAX_FAST_READ_LEN) {
-        fl = K4_RF_TOOLONG;
-        if (a.mode == 1) {  // the N rule still applies
-          const uint8_t* src = a.reads + a.offs[i];
-          for (int q = 0; q < len; q++) {
-            uint32_t b = src[q] & 7;
-            if (b == 4) n_ns++; else if (b > 4) fl |= K4_RF_INVALID;
+    if (active) {
+      const int len = (int)a.lens[i];
+      const K4ReadParams rp = k4d_read_params(a, len);
+      bool skip = false;
+      if (FIRST) {
+        n_done++;
+        n_bases += (uint32_t)len;
+        uint32_t fl = 0, n_ns = 0;
+        if (len < 1 || len > 32 * NCH || len > K4_MAX_FAST_READ_LEN) {
+          fl = K4_RF_TOOLONG;
+          if (a.mode == 1) {  // the N rule still applies
+            const uint8_t* src = a.reads + a.offs[i];
+            for (int q = 0; q < len; q++) {
+              uint32_t b = src[q] & 7;
+              if (b == 4) n_ns++; else if (b > 4) fl |= K4_RF_INVALID;
+            }
+          }
+        } else
+          fl = k4d_pack_read<NCH>(a.reads + a.offs[i], len, col, n_ns);
+        if (a.mode == 1) {  // AlignRead: too many Ns / a symbol above N -> NAR Ns, KAligner.cpp:9618-9640
+          int max_ns = 0;
+          if (a.kp.max_ns) max_ns = max((len * a.kp.max_ns) / 100, a.kp.max_ns);
+          if ((fl & K4_RF_INVALID) || (int)n_ns > max_ns) {
+            k4_read_result r = {K4_HR_SEQERRS, 0, 0, 0, K4_NAR_NS, 0};
+            a.rr[i] = r;
+            for (int q = 0; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&a.hits[i * a.max_hits + q]) = make_uint4(0, 0, 0, 0);
+            skip = true;
           }
         }
-      } else
-        fl = k4d_pack_read<NCH>(a.reads + a.offs[i], len, col, n_ns);
-      if (a.mode == 1) {  // AlignRead: too many Ns / a symbol above N -> NAR Ns, KAligner.cpp:9618-9640
-        int max_ns = 0;
-        if (a.kp.max_ns) max_ns = max((len * a.kp.max_ns) / 100, a.kp.max_ns);
-        if ((fl & K4_RF_INVALID) || (int)n_ns > max_ns) {
-          k4_read_result r = {K4_HR_SEQERRS, 0, 0, 0, K4_NAR_NS, 0};
-          a.rr[i] = r;
-          for (int q = 0; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&a.hits[i * a.max_hits + q]) = make_uint4(0, 0, 0, 0);
-          continue;
-        }
-      }
-      slow = fl != 0;
-    } else {
-      const uint64_t* row = in_rows + (int64_t)j * (2 * NCH);
+        slow = fl != 0 && !skip;
+      } else {
+        const uint64_t* row = in_rows + (int64_t)j * (2 * NCH);
 #pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        col[c * 256] = row[c];
-        col[(NW + c) * 256] = row[NCH + c];
+        for (int c = 0; c < NCH; c++) {
+          col[c * 256] = row[c];
+          col[(NW + c) * 256] = row[NCH + c];
+        }
+        col[NCH * 256] = 0;
+        col[(NW + NCH) * 256] = 0;
       }
-      col[NCH * 256] = 0;
-      col[(NW + NCH) * 256] = 0;
-    }
-    if (rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits) slow = true;  // the general kernel reports it
-    if (!slow) {
-      // which AlignReads phase is this read's step-th?  (SfxArray.cpp:7867-7891)
-      int n_esc = 0;
-      if (rp.tot_mm > 0)
-        for (; n_esc <= rp.tot_mm; n_esc++)
-          if (len / (n_esc + rp.mm_delta) <= rp.core_len) break;
-      const bool has_final = rp.tot_mm > 0 ? n_esc <= rp.tot_mm : true;
-      const int n_phases = n_esc + (has_final ? 1 : 0);
-      int allow, cl, delta;
-      if (step < n_esc) { allow = step; cl = len / (step + rp.mm_delta); delta = cl; }
-      else { allow = rp.tot_mm; cl = rp.core_len; delta = rp.core_delta; }
-      k4_hit* hits = a.hits + i * a.max_hits;
-      int inst = 0, low = 0, nxt = 0;
-      const uint32_t c0 = n_lookup, c1 = n_probe, c2 = n_cand;
-      int rslt = k4d_lcm_fast<EL, NCH>(a, ln, len, allow, cl, delta, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
-      if (rslt == K4_NEED_SLOW) {  // the general kernel redoes (and tallies) this phase
-        slow = true;
-        n_lookup = c0; n_probe = c1; n_cand = c2;
+      if (!skip && (rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits)) slow = true;  // the general kernel reports it
+      if (!skip && !slow) {
+        // which AlignReads phase is this read's step-th?  (SfxArray.cpp:7867-7891)
+        int n_esc = 0;
+        if (rp.tot_mm > 0)
+          for (; n_esc <= rp.tot_mm; n_esc++)
+            if (len / (n_esc + rp.mm_delta) <= rp.core_len) break;
+        const bool has_final = rp.tot_mm > 0 ? n_esc <= rp.tot_mm : true;
+        const int n_phases = n_esc + (has_final ? 1 : 0);
+        int allow, cl, delta;
+        if (step < n_esc) { allow = step; cl = len / (step + rp.mm_delta); delta = cl; }
+        else { allow = rp.tot_mm; cl = rp.core_len; delta = rp.core_delta; }
+        k4_hit* hits = a.hits + i * a.max_hits;
+        int inst = 0, low = 0, nxt = 0;
+        const uint32_t c0 = n_lookup, c1 = n_probe, c2 = n_cand;
+        int rslt = k4d_lcm_fast<EL, NCH, KT>(a, ln, len, allow, cl, delta, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
+        if (rslt == K4_NEED_SLOW) {  // the general kernel redoes (and tallies) this phase
+          slow = true;
+          n_lookup = c0; n_probe = c1; n_cand = c2;
+        }
+        else if (rslt != 0 || step + 1 >= n_phases) k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
+        else survive = true;
       }
-      else if (rslt != 0 || step + 1 >= n_phases) k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
-      else survive = true;
+      if (slow) {
+        k4d_push_slow(a, i, step);
+        n_slow++;
+      }
     }
-    if (slow) {
-      k4d_push_slow(a, i, step);
-      n_slow++;
-    }
-    // compaction of the survivors: one atomic per wave, slots by prefix popcount of the ballot
+    // compaction of the survivors: slots by prefix popcount of the wave's ballot inside the wave's current chunk
     const unsigned long long m = __ballot(survive);
-    if (m) {
-      const int leader = __ffsll((long long)m) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(out_count, (uint32_t)__popcll(m));
-      base = __shfl(base, leader, 64);
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (cnt) {
+      if (cnt > ch_left) {
+        for (uint32_t q = lane; q < ch_left; q += 64) out_ids[ch_cur + q] = K4_NO_READ;  // retire the old chunk's tail
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(out_count, (uint32_t)K4_CHUNK);
+        ch_cur = __shfl(base, 0, 64);
+        ch_left = K4_CHUNK;
+      }
       if (survive) {
-        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t slot = ch_cur + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         out_ids[slot] = (uint32_t)i;
         uint64_t* row = out_rows + (int64_t)slot * (2 * NCH);
 #pragma unroll
@@ -486,8 +538,11 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
           row[NCH + c] = col[(NW + c) * 256];
         }
       }
+      ch_cur += cnt;
+      ch_left -= cnt;
     }
   }
+  for (uint32_t q = lane; q < ch_left; q += 64) out_ids[ch_cur + q] = K4_NO_READ;
   // per-wave tallies -> one atomic per counter per wave (lookups of reads that went slow are recounted there)
   {
     unsigned long long v[6] = {n_done, n_lookup, n_probe, n_cand, n_slow, n_bases};
@@ -544,8 +599,8 @@ K4_DEV int64_t k4d_first_exact_slow(const K4DevIndex& ix, const uint8_t* core, i
   }
   if (acgt) {
     int sh = 2 * ((int)ix.k - kk);
-    lo = (int64_t)k4d_ktab_at(ix, code << sh);
-    hi = (int64_t)k4d_ktab_at(ix, (code + 1) << sh) - 1;
+    lo = (int64_t)k4d_ktab_lb(ix, code << sh);
+    hi = (int64_t)k4d_ktab_lb(ix, (code + 1) << sh) - 1;
   }
   int64_t found = -1;
   while (lo <= hi) {
@@ -743,9 +798,11 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
       if (q) hipFree(q);
     w.ids[0] = w.ids[1] = nullptr; w.rows[0] = w.rows[1] = nullptr; w.slow_list = nullptr; w.slow_step = nullptr;
     // survivors of step t (ids + packed rows, 2*nch words each) ping-pong between two buffers
+    // every wave of the (at most 2048-block) grid may leave one partly used chunk behind
+    const size_t slots = (size_t)cap + (size_t)2048 * 4 * K4_CHUNK;
     for (int b = 0; b < 2; b++) {
-      K4_HIP(ix, hipMalloc(&w.ids[b], (size_t)cap * 4));
-      K4_HIP(ix, hipMalloc(&w.rows[b], (size_t)cap * 2 * nch * 8));
+      K4_HIP(ix, hipMalloc(&w.ids[b], slots * 4));
+      K4_HIP(ix, hipMalloc(&w.rows[b], slots * 2 * nch * 8));
     }
     K4_HIP(ix, hipMalloc(&w.slow_list, (size_t)cap * 4));
     K4_HIP(ix, hipMalloc(&w.slow_step, (size_t)cap));
@@ -773,13 +830,13 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
   return K4_OK;
 }
 
-template <int EL, int NCH>
+template <int EL, int NCH, typename KT>
 static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t st) {
   K4Workspace& w = ix->ws;
   const size_t lds = (size_t)2 * (NCH + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4;
   if (lds > 48 * 1024) {
-    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, false, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   // grid-stride kernels: enough blocks to fill the chip at the kernel's occupancy, never more than the work
   const unsigned full = 256 * 8;
@@ -795,11 +852,11 @@ static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t s
     K4_HIP(ix, hipEventRecord(ix->ev0[ix->ev_used], st));
   }
   unsigned grid0 = (unsigned)std::min<int64_t>((a.n_reads + 255) / 256, full);
-  hipLaunchKernelGGL((k4k_align_step<EL, NCH, true>), dim3(grid0), dim3(256), lds, st, a, 0, (const uint32_t*)nullptr,
+  hipLaunchKernelGGL((k4k_align_step<EL, NCH, true, KT>), dim3(grid0), dim3(256), lds, st, a, 0, (const uint32_t*)nullptr,
                      (const uint64_t*)nullptr, (const uint32_t*)nullptr, w.ids[0], w.rows[0], w.ctl + 2);
   for (int t = 1; t < n_steps; t++) {
     const int in = (t - 1) & 1, out = t & 1;
-    hipLaunchKernelGGL((k4k_align_step<EL, NCH, false>), dim3(grid0), dim3(256), lds, st, a, t, w.ids[in], w.rows[in],
+    hipLaunchKernelGGL((k4k_align_step<EL, NCH, false, KT>), dim3(grid0), dim3(256), lds, st, a, t, w.ids[in], w.rows[in],
                        w.ctl + 2 + (t - 1), w.ids[out], w.rows[out], w.ctl + 2 + t);
   }
   if (timed) {
@@ -809,7 +866,7 @@ static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t s
   return K4_OK;
 }
 
-template <int EL>
+template <int EL, typename KT>
 static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hipStream_t st) {
   K4Workspace& w = ix->ws;
   const int nch = nch_for(std::min(max_len, K4_MAX_FAST_READ_LEN));
@@ -828,10 +885,10 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
   K4_HIP(ix, hipMemsetAsync(w.ctl, 0, K4_CTL_WORDS * 4, st));
   int rc;
   switch (nch) {
-    case 4: rc = launch_steps<EL, 4>(ix, a, n_steps, st); break;
-    case 5: rc = launch_steps<EL, 5>(ix, a, n_steps, st); break;
-    case 8: rc = launch_steps<EL, 8>(ix, a, n_steps, st); break;
-    default: rc = launch_steps<EL, 16>(ix, a, n_steps, st); break;
+    case 4: rc = launch_steps<EL, 4, KT>(ix, a, n_steps, st); break;
+    case 5: rc = launch_steps<EL, 5, KT>(ix, a, n_steps, st); break;
+    case 8: rc = launch_steps<EL, 8, KT>(ix, a, n_steps, st); break;
+    default: rc = launch_steps<EL, 16, KT>(ix, a, n_steps, st); break;
   }
   if (rc != K4_OK) return rc;
   hipLaunchKernelGGL((k4k_align_slow<EL>), dim3((w.slow_lanes + 63) / 64), dim3(64), 0, st, a, w.slow_lanes);
@@ -854,7 +911,8 @@ static int run_dev(k4_index* ix, K4AlignArgs& a, int max_len, void* stream) {
     tot_mm = std::min(tot_mm, 63);
   }
   const int n_steps = tot_mm + 1;
-  return ix->d.el == 4 ? launch_all<4>(ix, a, max_len, n_steps, st) : launch_all<5>(ix, a, max_len, n_steps, st);
+  if (ix->d.el == 4) return launch_all<4, uint32_t>(ix, a, max_len, n_steps, st);
+  return ix->d.ktab64 ? launch_all<5, uint64_t>(ix, a, max_len, n_steps, st) : launch_all<5, uint32_t>(ix, a, max_len, n_steps, st);
 }
 
 static int check_align_params(k4_index* ix, const k4_align_params* p) {

@@ -18,8 +18,21 @@ K4_DEV uint64_t k4d_sa_at(const K4DevIndex& ix, uint64_t i) {
   }
 }
 
-K4_DEV uint64_t k4d_ktab_at(const K4DevIndex& ix, uint64_t c) {
-  return ix.ktab64 ? reinterpret_cast<const uint64_t*>(ix.ktab)[c] : reinterpret_cast<const uint32_t*>(ix.ktab)[c];
+// k-mer table entry c = {lb, pos0}: lb = number of suffixes sorting before k-mer c (its bucket is [lb(c), lb(c+1))),
+// pos0 = SA[lb] (offset of the bucket's first suffix, valid when the bucket is not empty).
+K4_DEV uint64_t k4d_ktab_lb(const K4DevIndex& ix, uint64_t c) {
+  return ix.ktab64 ? reinterpret_cast<const uint64_t*>(ix.ktab)[2 * c] : reinterpret_cast<const uint32_t*>(ix.ktab)[2 * c];
+}
+// bucket of the k-mer prefix range [c0, c1): lb0 = lb(c0), pos0 = pos0(c0), lb1 = lb(c1).  KT = table field type.
+template <typename KT>
+K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& lb0, KT& pos0, KT& lb1) {
+  const KT* t = reinterpret_cast<const KT*>(ix.ktab);
+  if (c1 == c0 + 1) {  // the common case (core at least k long): three adjacent fields, one fetch
+    const KT* e = t + 2 * c0;
+    lb0 = e[0]; pos0 = e[1]; lb1 = e[2];
+  } else {
+    lb0 = t[2 * c0]; pos0 = t[2 * c0 + 1]; lb1 = t[2 * c1];
+  }
 }
 
 // 32 bases [pos, pos+32) as one MSB-first 64-bit chunk.  pos may be as low as -K4_PAD_BASES.

@@ -132,20 +132,23 @@ __global__ void __launch_bounds__(256) k4k_ktab_mark(K4DevIndex ix, T* __restric
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= ix.n) return;
   uint64_t c, cp = 0;
-  bool v = k4d_kmer_code(ix, k4d_sa_at<EL>(ix, i), ix.k, &c);
+  bool v = k4d_kmer_code(ix, k4d_sa_at<EL>(ix, i), ix.k, &c);  // (the entry's pos0 field is re-read below: rare path)
   if (!v) return;
   bool vp = i > 0 && k4d_kmer_code(ix, k4d_sa_at<EL>(ix, i - 1), ix.k, &cp);
-  if (!vp || cp != c) tab[c] = (T)i;  // first suffix of the run of k-mer c
+  if (!vp || cp != c) {  // first suffix of the run of k-mer c
+    tab[2 * c] = (T)i;
+    tab[2 * c + 1] = (T)k4d_sa_at<EL>(ix, i);
+  }
 }
 
-// reverse (suffix) min-scan in three passes: tab[c] = min(tab[c'], c' >= c); unset entries hold the max value.
+// reverse (suffix) min-scan over the lb fields (stride 2) in three passes: lb[c] = min(lb[c'], c' >= c); unset = max value.
 template <typename T>
 __global__ void __launch_bounds__(256) k4k_scan_block_min(const T* __restrict__ tab, uint64_t n, T* __restrict__ agg) {
   __shared__ T sh[256];
   uint64_t base = (uint64_t)blockIdx.x * 2048 + (uint64_t)threadIdx.x * 8;
   T m = (T)~(T)0;
   for (int j = 0; j < 8; j++)
-    if (base + j < n) m = min(m, tab[base + j]);
+    if (base + j < n) m = min(m, tab[2 * (base + j)]);
   sh[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(256) k4k_scan_apply(T* __restrict__ tab, uint6
   T v[8];
   T m = (T)~(T)0;
   for (int j = 7; j >= 0; j--) {
-    T x = base + j < n ? tab[base + j] : (T)~(T)0;
+    T x = base + j < n ? tab[2 * (base + j)] : (T)~(T)0;
     m = min(m, x);
     v[j] = m;  // min over this thread's elements j..7
   }
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(256) k4k_scan_apply(T* __restrict__ tab, uint6
   T right = threadIdx.x + 1 < 256 ? sh[threadIdx.x + 1] : (T)~(T)0;
   right = min(right, agg[blockIdx.x]);
   for (int j = 0; j < 8; j++)
-    if (base + j < n) tab[base + j] = min(v[j], right);
+    if (base + j < n) tab[2 * (base + j)] = min(v[j], right);
 }
 
 __global__ void k4k_unpack_range(K4DevIndex ix, uint64_t start, uint64_t len, uint8_t* __restrict__ out) {
@@ -224,12 +227,12 @@ template <int EL, typename T>
 static int build_ktab(k4_index* ix) {
   uint64_t nent = (1ull << (2 * ix->d.k)) + 1;
   T* tab = nullptr;
-  K4_HIP(ix, hipMalloc(&tab, nent * sizeof(T)));
+  K4_HIP(ix, hipMalloc(&tab, nent * 2 * sizeof(T) + 16));
   ix->ktab = tab;
-  ix->device_bytes += nent * sizeof(T);
-  K4_HIP(ix, hipMemset(tab, 0xFF, nent * sizeof(T)));
+  ix->device_bytes += nent * 2 * sizeof(T) + 16;
+  K4_HIP(ix, hipMemset(tab, 0xFF, nent * 2 * sizeof(T) + 16));
   T last = (T)ix->d.n;
-  K4_HIP(ix, hipMemcpy(tab + (nent - 1), &last, sizeof(T), hipMemcpyHostToDevice));
+  K4_HIP(ix, hipMemcpy(tab + 2 * (nent - 1), &last, sizeof(T), hipMemcpyHostToDevice));
   ix->d.ktab = tab;
   uint64_t nb = (ix->d.n + 255) / 256;
   hipLaunchKernelGGL((k4k_ktab_mark<EL, T>), dim3((unsigned)nb), dim3(256), 0, 0, ix->d, tab);

@@ -15,8 +15,10 @@
 // excblk    sorted list of the flagged block numbers; excnib holds, for flagged block r, its 64 symbols as
 //           nibbles (8 words, symbol j in bits 4*(j&7) of word r*8 + (j>>3)) -- the exact 4-bit reference.
 // sa        the .sfx suffix array unchanged: 4- or 5-byte little-endian elements.
-// ktab      direct-address table over the first k bases: ktab[c] = number of suffixes that sort before the
-//           k-mer with code c (first base most significant); 4^k + 1 entries, 32-bit when concat_len < 2^32.
+// ktab      direct-address table over the first k bases, 4^k + 1 entries {lb, pos0} (32-bit fields when
+//           concat_len < 2^32): lb[c] = number of suffixes that sort before the k-mer with code c (first base most
+//           significant), so the bucket of c is SA[lb[c] .. lb[c+1]); pos0[c] = SA[lb[c]], the offset of the
+//           bucket's first suffix, which saves the dependent SA fetch for the first probe of a lookup.
 // entries   start/end offsets and ids of the chromosomes (tsSfxEntry), sorted by start.
 #define K4_PAD_BASES 2048
 #define K4_PAD_WORDS (K4_PAD_BASES / 16)
