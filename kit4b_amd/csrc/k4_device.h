@@ -4,6 +4,33 @@
 
 #define K4_DEV __device__ __forceinline__
 
+// gfx950 global loads of 2/3/4 dwords only need dword alignment: these types make hipcc emit one wide load where the
+// address is merely 4-byte aligned (a divergent wave pays per lane-request in the vector L1, not per byte).
+typedef uint32_t k4_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t k4_u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t k4_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint64_t k4_u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+// n consecutive dwords from a 4-byte aligned address, in as few load instructions as possible
+template <int N>
+K4_DEV void k4d_load_words(const uint32_t* __restrict__ p, uint32_t (&out)[N]) {
+  constexpr int Q = N / 4, R = N % 4;
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const k4_u32x4_a4 v = *reinterpret_cast<const k4_u32x4_a4*>(p + 4 * q);
+    out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+  }
+  if (R == 1) out[4 * Q] = p[4 * Q];
+  if (R == 2) {
+    const k4_u32x2_a4 v = *reinterpret_cast<const k4_u32x2_a4*>(p + 4 * Q);
+    out[4 * Q] = v.x; out[4 * Q + 1] = v.y;
+  }
+  if (R == 3) {
+    const k4_u32x3_a4 v = *reinterpret_cast<const k4_u32x3_a4*>(p + 4 * Q);
+    out[4 * Q] = v.x; out[4 * Q + 1] = v.y; out[4 * Q + 2] = v.z;
+  }
+}
+
 // SfxOfsToLoci (libkit4b/SfxArray.cpp:49-60): element i of the 4- or 5-byte little-endian suffix array.
 template <int EL>
 K4_DEV uint64_t k4d_sa_at(const K4DevIndex& ix, uint64_t i) {
@@ -29,7 +56,13 @@ K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& l
   const KT* t = reinterpret_cast<const KT*>(ix.ktab);
   if (c1 == c0 + 1) {  // the common case (core at least k long): three adjacent fields, one fetch
     const KT* e = t + 2 * c0;
-    lb0 = e[0]; pos0 = e[1]; lb1 = e[2];
+    if (sizeof(KT) == 4) {
+      const k4_u32x3_a4 v = *reinterpret_cast<const k4_u32x3_a4*>(e);
+      lb0 = (KT)v.x; pos0 = (KT)v.y; lb1 = (KT)v.z;
+    } else {
+      const k4_u64x2_a8 v = *reinterpret_cast<const k4_u64x2_a8*>(e);
+      lb0 = (KT)v.x; pos0 = (KT)v.y; lb1 = e[2];
+    }
   } else {
     lb0 = t[2 * c0]; pos0 = t[2 * c0 + 1]; lb1 = t[2 * c1];
   }
@@ -44,28 +77,28 @@ K4_DEV uint64_t k4d_ref_chunk(const K4DevIndex& ix, int64_t pos) {
   return s ? (hi << s) | (p[2] >> (32 - s)) : hi;
 }
 
-// any non-ACGT symbol in [start, end) ?  (end - start) must stay below 32 * 64 bases
+// any non-ACGT symbol in [start, end) ?  (end - start) must stay below 32 blocks; one 8-byte fetch
 K4_DEV bool k4d_any_exc(const K4DevIndex& ix, int64_t start, int64_t end) {
   if (start < 0) start = 0;
   if (end <= start) return false;
-  uint64_t b0 = (uint64_t)start >> 6, b1 = (uint64_t)(end - 1) >> 6;
-  uint32_t wa = ix.excbm[b0 >> 5], wb = ix.excbm[b1 >> 5];
-  uint32_t ma = ~0u << (b0 & 31), mb = ~0u >> (31 - (b1 & 31));
-  if ((b0 >> 5) == (b1 >> 5)) return (wa & ma & mb) != 0;
-  return ((wa & ma) | (wb & mb)) != 0;
+  const uint64_t b0 = (uint64_t)start >> K4_EXC_SHIFT, b1 = (uint64_t)(end - 1) >> K4_EXC_SHIFT;
+  const k4_u32x2_a4 w = *reinterpret_cast<const k4_u32x2_a4*>(ix.excbm + (b0 >> 5));
+  const uint64_t v = (((uint64_t)w.y << 32) | w.x) >> (b0 & 31);  // bit 0 = block b0 (bitmap is padded)
+  const uint32_t nb = (uint32_t)(b1 - b0) + 1;                      // 1..32 blocks
+  return (v & ((1ull << nb) - 1ull)) != 0;
 }
 
 // exact symbol (etSeqBase low nibble: 0..4, 7) at pos
 K4_DEV uint32_t k4d_ref_base(const K4DevIndex& ix, uint64_t pos) {
-  uint64_t blk = pos >> 6;
+  uint64_t blk = pos >> K4_EXC_SHIFT;
   if ((ix.excbm[blk >> 5] >> (blk & 31)) & 1) {
     uint32_t lo = 0, hi = ix.n_exc;  // lower_bound over the sorted flagged-block list
     while (lo < hi) {
       uint32_t mid = (lo + hi) >> 1;
       if (ix.excblk[mid] < (uint32_t)blk) lo = mid + 1; else hi = mid;
     }
-    uint32_t j = (uint32_t)(pos & 63);
-    return (ix.excnib[(uint64_t)lo * 8 + (j >> 3)] >> (4 * (j & 7))) & 0xF;
+    uint32_t j = (uint32_t)(pos & (K4_EXC_BLOCK - 1));
+    return (ix.excnib[(uint64_t)lo * (K4_EXC_BLOCK / 8) + (j >> 3)] >> (4 * (j & 7))) & 0xF;
   }
   uint32_t w = ix.ref2[pos >> 4];
   return (w >> (30 - 2 * (uint32_t)(pos & 15))) & 3;

@@ -42,9 +42,10 @@ extern "C" const char* k4_global_error(void) { return g_err.c_str(); }
 extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
 
 // ---- kernels: packing ---------------------------------------------------------------------------------------
-// One thread per 64-base block: 4 packed words + the block's exception flag; the wave's ballot is the bitmap.
+// One thread per 64 bases: 4 packed words + an exception flag; the wave's ballot, folded 4:1, gives the bits of the
+// wave's 16 bitmap blocks of 256 bases.
 __global__ void __launch_bounds__(256) k4k_pack_ref(const uint8_t* __restrict__ seq, uint64_t n,
-                                                    uint32_t* __restrict__ ref2, uint32_t* __restrict__ excbm,
+                                                    uint32_t* __restrict__ ref2, uint16_t* __restrict__ excbm16,
                                                     uint64_t n_blocks) {
   uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool exc = false;
@@ -86,9 +87,11 @@ __global__ void __launch_bounds__(256) k4k_pack_ref(const uint8_t* __restrict__ 
   }
   unsigned long long m = __ballot(exc);
   if ((threadIdx.x & 63) == 0) {
-    uint64_t w0 = (uint64_t)blockIdx.x * 8 + (threadIdx.x >> 6) * 2;  // 2 bitmap words per wave
-    excbm[w0] = (uint32_t)m;
-    excbm[w0 + 1] = (uint32_t)(m >> 32);
+    m |= m >> 1;
+    m |= m >> 2;  // bit 4j = any of the four 64-base flags of 256-base block j
+    uint32_t v = 0;
+    for (int j = 0; j < 16; j++) v |= (uint32_t)((m >> (4 * j)) & 1) << j;
+    excbm16[(uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = (uint16_t)v;  // a wave covers 64 * 64 = 16 * 256 bases
   }
 }
 
@@ -97,9 +100,10 @@ __global__ void __launch_bounds__(256) k4k_exc_nibbles(const uint8_t* __restrict
                                                        const uint32_t* __restrict__ excblk, uint32_t n_exc,
                                                        uint32_t* __restrict__ excnib) {
   uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (uint64_t)n_exc * 8) return;
-  uint32_t r = (uint32_t)(t >> 3), q = (uint32_t)(t & 7);
-  uint64_t base = (uint64_t)excblk[r] * 64 + q * 8;
+  const uint32_t wpb = K4_EXC_BLOCK / 8;  // words per flagged block
+  if (t >= (uint64_t)n_exc * wpb) return;
+  uint32_t r = (uint32_t)(t / wpb), q = (uint32_t)(t % wpb);
+  uint64_t base = (uint64_t)excblk[r] * K4_EXC_BLOCK + q * 8;
   uint32_t acc = 0;
   for (int j = 0; j < 8; j++) {
     uint64_t pos = base + j;
@@ -252,9 +256,10 @@ static int build_ktab(k4_index* ix) {
 // d_seq: concat_len bytes (1 byte/base) in HBM; ix->sa, entries and ix->d.{n,el} must already be set.
 int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
   const uint64_t n = ix->d.n;
-  const uint64_t n_blocks = (n + 63) / 64;
+  const uint64_t n_blocks = (n + 63) / 64;        // 64-base packing units
   const uint64_t words = n_blocks * 4;
-  const uint64_t bm_words = ((n_blocks + 255) / 256) * 8 + 8;  // the pack kernel writes whole waves
+  const uint64_t n_eblocks = (n + K4_EXC_BLOCK - 1) >> K4_EXC_SHIFT;
+  const uint64_t bm_words = ((n_blocks + 255) / 256) * 2 + 8;  // the pack kernel writes 16 bits per wave; +pad for the 8-byte fetch
   K4_HIP(ix, hipMalloc(&ix->ref2_alloc, (words + 2 * K4_PAD_WORDS) * 4));
   K4_HIP(ix, hipMemset(ix->ref2_alloc, 0, (words + 2 * K4_PAD_WORDS) * 4));
   K4_HIP(ix, hipMalloc(&ix->excbm, bm_words * 4));
@@ -262,7 +267,7 @@ int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
   ix->device_bytes += (words + 2 * K4_PAD_WORDS) * 4 + bm_words * 4;
   uint32_t* ref2 = ix->ref2_alloc + K4_PAD_WORDS;
   hipLaunchKernelGGL(k4k_pack_ref, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, 0,
-                     (const uint8_t*)d_seq, n, ref2, ix->excbm, n_blocks);
+                     (const uint8_t*)d_seq, n, ref2, (uint16_t*)ix->excbm, n_blocks);
   K4_HIP(ix, hipGetLastError());
   // flagged-block list on the host (bitmap is n/512 bytes)
   std::vector<uint32_t> bm(bm_words);
@@ -274,16 +279,16 @@ int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
       int b = __builtin_ctz(v);
       v &= v - 1;
       uint64_t id = w * 32 + b;
-      if (id < n_blocks) blk.push_back((uint32_t)id);
+      if (id < n_eblocks) blk.push_back((uint32_t)id);
     }
   }
   uint32_t n_exc = (uint32_t)blk.size();
   K4_HIP(ix, hipMalloc(&ix->excblk, (size_t)(n_exc + 1) * 4));
-  K4_HIP(ix, hipMalloc(&ix->excnib, (size_t)(n_exc + 1) * 32));
-  ix->device_bytes += (uint64_t)(n_exc + 1) * 36;
+  K4_HIP(ix, hipMalloc(&ix->excnib, (size_t)(n_exc + 1) * (K4_EXC_BLOCK / 2)));
+  ix->device_bytes += (uint64_t)(n_exc + 1) * (4 + K4_EXC_BLOCK / 2);
   if (n_exc) {
     K4_HIP(ix, hipMemcpy(ix->excblk, blk.data(), (size_t)n_exc * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k4k_exc_nibbles, dim3((unsigned)(((uint64_t)n_exc * 8 + 255) / 256)), dim3(256), 0, 0,
+    hipLaunchKernelGGL(k4k_exc_nibbles, dim3((unsigned)(((uint64_t)n_exc * (K4_EXC_BLOCK / 8) + 255) / 256)), dim3(256), 0, 0,
                        (const uint8_t*)d_seq, n, ix->excblk, n_exc, ix->excnib);
     K4_HIP(ix, hipGetLastError());
   }

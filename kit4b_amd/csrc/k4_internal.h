@@ -11,15 +11,18 @@
 //           word (i >> 4); non-ACGT symbols (N=4, EOS=7) are stored as 0 and described by the exception data.
 //           K4_PAD_WORDS zero words sit in front of base 0 and behind the last base, so a window that starts up
 //           to K4_PAD_BASES before 0 or runs past the end can be fetched without bounds tests.
-// excbm     one bit per 64-base block: set when the block holds a non-ACGT symbol.
-// excblk    sorted list of the flagged block numbers; excnib holds, for flagged block r, its 64 symbols as
-//           nibbles (8 words, symbol j in bits 4*(j&7) of word r*8 + (j>>3)) -- the exact 4-bit reference.
+// excbm     one bit per 256-base block (K4_EXC_SHIFT): set when the block holds a non-ACGT symbol.  1.5 MB for 3 Gbp,
+//           so it lives in every XCD's L2; a read window spans at most a few blocks -> one 8-byte fetch per probe.
+// excblk    sorted list of the flagged block numbers; excnib holds, for flagged block r, its 256 symbols as
+//           nibbles (32 words, symbol j in bits 4*(j&7) of word r*32 + (j>>3)) -- the exact 4-bit reference.
 // sa        the .sfx suffix array unchanged: 4- or 5-byte little-endian elements.
 // ktab      direct-address table over the first k bases, 4^k + 1 entries {lb, pos0} (32-bit fields when
 //           concat_len < 2^32): lb[c] = number of suffixes that sort before the k-mer with code c (first base most
 //           significant), so the bucket of c is SA[lb[c] .. lb[c+1]); pos0[c] = SA[lb[c]], the offset of the
 //           bucket's first suffix, which saves the dependent SA fetch for the first probe of a lookup.
 // entries   start/end offsets and ids of the chromosomes (tsSfxEntry), sorted by start.
+#define K4_EXC_SHIFT 8            // log2 of the exception-bitmap block size in bases
+#define K4_EXC_BLOCK (1 << K4_EXC_SHIFT)
 #define K4_PAD_BASES 2048
 #define K4_PAD_WORDS (K4_PAD_BASES / 16)
 #define K4_MAX_FAST_READ_LEN 512   // longer reads run in the general kernel
