@@ -179,6 +179,8 @@ template <int NCH>
 struct K4Lane {
   const uint64_t* rd;  // LDS: word (s*NW + c) of this lane's read at rd[(s*NW + c) * 256]
   uint32_t* ded;       // LDS: dedupe slot q at ded[q * 256]
+  const uint32_t* sup; // LDS (block-shared): coarse exception bitmap, K4_SUP_WORDS words
+  const uint64_t* ent; // LDS (block-shared): chromosome starts [0..K4_LDS_ENTRIES) then ends, when they fit
   static constexpr int NW = NCH + 1;
   K4_DEV uint64_t word(int s, int c) const { return rd[(s * NW + c) * 256]; }
   K4_DEV uint64_t chunk_at(int s, int o) const {  // 32 bases of strand s starting at base o
@@ -201,14 +203,25 @@ template <int NCH>
 K4_DEV K4Probe k4d_probe(const K4DevIndex& ix, const K4Lane<NCH>& ln, int s, int o, int cl, int len, uint64_t p) {
   K4Probe r;
   int64_t left = (int64_t)p - o;
-  r.exc = k4d_any_exc(ix, left, left + len);
+  {  // coarse test in LDS first; the fine bitmap in L2 is only consulted near a separator / N run
+    const int64_t st = left < 0 ? 0 : left;
+    const uint64_t b0 = (uint64_t)st >> ix.sup_shift, b1 = (uint64_t)(left + len - 1) >> ix.sup_shift;
+    const uint64_t v = (((uint64_t)ln.sup[(b0 >> 5) + 1] << 32) | ln.sup[b0 >> 5]) >> (b0 & 31);
+    r.exc = (v & ((2ull << (b1 - b0)) - 1ull)) != 0;
+    if (r.exc && ix.sup_shift != K4_EXC_SHIFT) r.exc = k4d_any_exc(ix, left, left + len);
+  }
   r.cmp = 0;
   r.mm = 0;
   const uint32_t* wp = ix.ref2 + (left >> 4);
   uint32_t sh = (uint32_t)(left & 15) * 2;
   uint32_t wv[2 * NCH + 1];
-  if (NCH <= 5 || len > 32 * (NCH / 2))
-    k4d_load_words<2 * NCH + 1>(wp, wv);  // the whole window: 3 load instructions for 100..128 bp
+  if (NCH <= 5 && len + 15 <= 32 * NCH) {  // the window spans at most 2*NCH words: two 16-byte loads for <= 113 bp
+    uint32_t even[2 * NCH];
+    k4d_load_words<2 * NCH>(wp, even);
+#pragma unroll
+    for (int j = 0; j < 2 * NCH + 1; j++) wv[j] = j < 2 * NCH ? even[j] : 0u;
+  } else if (NCH <= 5 || len > 32 * (NCH / 2))
+    k4d_load_words<2 * NCH + 1>(wp, wv);
   else {
     uint32_t half[NCH + 1];               // a short read in a long-read batch: only the words it covers
     k4d_load_words<NCH + 1>(wp, half);
@@ -344,8 +357,25 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           first = false;
           if (p < (uint64_t)o) continue;
           const uint64_t left = p - (uint64_t)o;
-          const int e = k4d_map_entry(ix, left);
-          if (e < 0 || left + (uint64_t)len - 1 > ix.ent_end[e]) continue;
+          int e;
+          uint64_t e_start, e_end;
+          if (ix.n_entries <= K4_LDS_ENTRIES) {  // MapChunkHit2Entry (SfxArray.cpp:2609-2654) over the LDS copy
+            int lo_e = 0, hi_e = (int)ix.n_entries - 1;
+            e = -1; e_start = 0; e_end = 0;
+            while (hi_e >= lo_e) {
+              const int mid_e = (hi_e + lo_e) >> 1;
+              const uint64_t sv = ln.ent[mid_e];
+              if (sv > left) { hi_e = mid_e - 1; continue; }
+              const uint64_t ev = ln.ent[K4_LDS_ENTRIES + mid_e];
+              if (ev >= left) { e = mid_e; e_start = sv; e_end = ev; break; }
+              lo_e = mid_e + 1;
+            }
+          } else {
+            e = k4d_map_entry(ix, left);
+            e_start = e >= 0 ? ix.ent_start[e] : 0;
+            e_end = e >= 0 ? ix.ent_end[e] : 0;
+          }
+          if (e < 0 || left + (uint64_t)len - 1 > e_end) continue;
           const uint32_t targ_id = (uint32_t)(1 + p - (uint32_t)o);  // :6037 (truncation is the reference's)
           bool dup = false;
           for (int q = 0; q < n_ded; q++) dup |= (ln.ded[q * 256] == targ_id);
@@ -356,7 +386,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           iter++;
           n_cand++;
           if (mm > allow_mm || mm >= st.nxt) continue;  // the two early-outs of :6200-6261
-          k4d_fold(st, mm, hits, rp.max_hits, ix.ent_id[e], (uint32_t)(left - ix.ent_start[e]), len, strand_c);
+          k4d_fold(st, mm, hits, rp.max_hits, ix.ent_id[e], (uint32_t)(left - e_start), len, strand_c);
           if (st.inst > rp.max_hits && st.low == 0) break;
         }
         if (st.inst > rp.max_hits && st.low == 0) stop = true;
@@ -452,6 +482,17 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
   K4Lane<NCH> ln;
   ln.rd = lds + tid;
   ln.ded = reinterpret_cast<uint32_t*>(lds + 2 * NW * 256) + tid;
+  uint64_t* ent_l = lds + 2 * NW * 256 + (K4_DEDUP_CAP * 256) / 2;
+  uint32_t* sup_l = reinterpret_cast<uint32_t*>(ent_l + 2 * K4_LDS_ENTRIES);
+  ln.ent = ent_l;
+  ln.sup = sup_l;
+  for (int q = tid; q < K4_SUP_WORDS; q += 256) sup_l[q] = a.ix.excsup[q];
+  if (a.ix.n_entries <= K4_LDS_ENTRIES)
+    for (int q = tid; q < (int)a.ix.n_entries; q += 256) {
+      ent_l[q] = a.ix.ent_start[q];
+      ent_l[K4_LDS_ENTRIES + q] = a.ix.ent_end[q];
+    }
+  __syncthreads();
   uint64_t* col = lds + tid;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0, n_slow = 0, n_bases = 0, n_done = 0;
   const int64_t count = FIRST ? a.n_reads : (int64_t)*in_count;
@@ -862,7 +903,8 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
 template <int EL, int NCH, typename KT>
 static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t st) {
   K4Workspace& w = ix->ws;
-  const size_t lds = (size_t)2 * (NCH + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4;
+  const size_t lds = (size_t)2 * (NCH + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4 + (size_t)2 * K4_LDS_ENTRIES * 8 +
+                     (size_t)K4_SUP_WORDS * 4 + 16;
   if (lds > 48 * 1024) {
     K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, false, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -283,6 +283,17 @@ int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
     }
   }
   uint32_t n_exc = (uint32_t)blk.size();
+  // coarse bitmap for LDS: the smallest power-of-two granularity at which the genome (plus slack for windows that
+  // run past the end) fits K4_SUP_WORDS * 32 - 64 bits
+  uint32_t sup_shift = K4_EXC_SHIFT;
+  while (((n + (1ull << 16)) >> sup_shift) + 64 > (uint64_t)K4_SUP_WORDS * 32) sup_shift++;
+  std::vector<uint32_t> sup(K4_SUP_WORDS, 0);
+  for (uint32_t id : blk) {
+    uint64_t b = (uint64_t)id >> (sup_shift - K4_EXC_SHIFT);
+    sup[b >> 5] |= 1u << (b & 31);
+  }
+  K4_HIP(ix, hipMalloc(&ix->excsup, K4_SUP_WORDS * 4));
+  K4_HIP(ix, hipMemcpy(ix->excsup, sup.data(), K4_SUP_WORDS * 4, hipMemcpyHostToDevice));
   K4_HIP(ix, hipMalloc(&ix->excblk, (size_t)(n_exc + 1) * 4));
   K4_HIP(ix, hipMalloc(&ix->excnib, (size_t)(n_exc + 1) * (K4_EXC_BLOCK / 2)));
   ix->device_bytes += (uint64_t)(n_exc + 1) * (4 + K4_EXC_BLOCK / 2);
@@ -315,6 +326,8 @@ int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
   K4_HIP(ix, hipMemset(ix->counters, 0, sizeof(k4_counters)));
   ix->d.ref2 = ref2;
   ix->d.excbm = ix->excbm;
+  ix->d.excsup = ix->excsup;
+  ix->d.sup_shift = sup_shift;
   ix->d.excblk = ix->excblk;
   ix->d.excnib = ix->excnib;
   ix->d.n_exc = n_exc;
@@ -528,7 +541,7 @@ extern "C" void k4_close(k4_index* ix) {
   if (!ix) return;
   hipSetDevice(ix->device);
   K4Workspace& w = ix->ws;
-  void* ptrs[] = {ix->ref2_alloc, ix->excbm, ix->excblk, ix->excnib, ix->owns_sa ? ix->sa : nullptr, ix->ktab,
+  void* ptrs[] = {ix->ref2_alloc, ix->excbm, ix->excsup, ix->excblk, ix->excnib, ix->owns_sa ? ix->sa : nullptr, ix->ktab,
                   ix->ent_start, ix->ent_end, ix->ent_id, ix->counters, w.ids[0], w.ids[1], w.rows[0], w.rows[1], w.slow_list, w.slow_step, w.ctl,
                   w.slow_probe, w.slow_hash, w.d_reads, w.d_offs, w.d_lens, w.d_out4, w.d_hits};
   for (void* p : ptrs)

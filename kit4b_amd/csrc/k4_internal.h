@@ -23,16 +23,19 @@
 // entries   start/end offsets and ids of the chromosomes (tsSfxEntry), sorted by start.
 #define K4_EXC_SHIFT 8            // log2 of the exception-bitmap block size in bases
 #define K4_EXC_BLOCK (1 << K4_EXC_SHIFT)
+#define K4_SUP_WORDS 1024          // LDS-resident coarse exception bitmap: 32 Kbit, one bit per 2^sup_shift bases
+#define K4_LDS_ENTRIES 128         // chromosome tables up to this size are searched in LDS
 #define K4_PAD_BASES 2048
 #define K4_PAD_WORDS (K4_PAD_BASES / 16)
 #define K4_MAX_FAST_READ_LEN 512   // longer reads run in the general kernel
 #define K4_MAX_READ_LEN 4096       // cMaxSeqLen is 2000 (KAligner.h:115)
-#define K4_DEDUP_CAP 8             // distinct candidates per strand pass kept by the fast kernel
+#define K4_DEDUP_CAP 6             // distinct candidates per strand pass kept by the fast kernel
 #define K4_MAX_IDENT_NODES 1024000 // cMaxNumIdentNodes, libkit4b/SfxArray.h:15
 
 struct K4DevIndex {
   const uint32_t* ref2;   // points at the word holding base 0
   const uint32_t* excbm;
+  const uint32_t* excsup;  // K4_SUP_WORDS words: bit b set when bases [b << sup_shift, (b+1) << sup_shift) hold an exception
   const uint32_t* excblk;
   const uint32_t* excnib;
   const uint8_t* sa;
@@ -46,6 +49,7 @@ struct K4DevIndex {
   uint32_t el;       // 4 | 5
   uint32_t k;        // k-mer table length
   uint32_t ktab64;   // table entries are 64-bit
+  uint32_t sup_shift; // log2 bases per bit of excsup (== K4_EXC_SHIFT when the whole fine bitmap fits)
   int32_t max_iter;
 };
 
@@ -76,6 +80,7 @@ struct k4_index {
   // owning pointers
   uint32_t* ref2_alloc = nullptr;
   uint32_t* excbm = nullptr;
+  uint32_t* excsup = nullptr;
   uint32_t* excblk = nullptr;
   uint32_t* excnib = nullptr;
   uint8_t* sa = nullptr;
