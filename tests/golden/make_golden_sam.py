@@ -1,0 +1,77 @@
+"""End-to-end golden outputs from the REAL reference front end (`oracle/_ref/ngskit4b`, built by `make -C oracle ngskit4b`).
+
+    python tests/golden/make_golden_sam.py
+
+For each case: the reads (FASTA, xz), the command line, the SAM the reference wrote (xz) and the NAR histogram it logged
+(ReportAlignStats, ngskit4b/KAligner.cpp:3600-3830).  Data only.  The index is tests/golden/g1.sfx.
+"""
+import json
+import lzma
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(HERE))
+import synth  # noqa: E402
+
+NGS = os.path.join(ROOT, "oracle", "_ref", "ngskit4b")
+
+CASES = {
+    # name: (kalign args, read generator)
+    "se_s2": (["-s2"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4321, n_prob=0.04, edge_frac=0.08, random_frac=0.04)[0]),
+    "se_s0": (["-s0"], lambda ch: synth.make_reads(ch, 1500, 100, seed=4322, sub_lambda=0.4, edge_frac=0.05)[0]),
+    "se_s5_e2_m1": (["-s5", "-e2", "-m1"], lambda ch: synth.make_reads(ch, 1500, 120, seed=4323, sub_lambda=2.5, n_prob=0.03)[0]),
+}
+PE_CASES = {
+    "pe_u2": (["-s2", "-U2", "-d200", "-D600"], dict(seed=99, n_prob=0.02, random_mate_frac=0.03)),
+    "pe_u1": (["-s2", "-U1", "-d200", "-D600"], dict(seed=98, n_prob=0.02, random_mate_frac=0.03, sub_lambda=2.0)),
+}
+
+
+def run(tmp, name, args, files):
+    sam = os.path.join(tmp, name + ".sam")
+    log = os.path.join(tmp, name + ".log")
+    cmd = [NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", sam, "-T", "4", "-F", log] + args + files
+    subprocess.run(cmd, check=True, capture_output=True)
+    hist = {}
+    for line in open(log):
+        m = re.search(r"\)\s+(\d+) \((\w\w)\) ", line)
+        if m:
+            hist[m.group(2)] = int(m.group(1))
+    with open(sam, "rb") as f, lzma.open(os.path.join(HERE, "sam_%s.sam.xz" % name), "wb", preset=9) as g:
+        g.write(f.read())
+    return hist
+
+
+def main():
+    names, chroms = synth.golden_genome()
+    meta = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (args, gen) in CASES.items():
+            fa = os.path.join(tmp, name + ".fa")
+            synth.write_fasta(fa, gen(chroms))
+            hist = run(tmp, name, args, ["-i", fa])
+            with open(fa, "rb") as f, lzma.open(os.path.join(HERE, "sam_%s.fa.xz" % name), "wb", preset=9) as g:
+                g.write(f.read())
+            meta[name] = dict(args=args, nar=hist)
+            print(name, hist)
+        for name, (args, kw) in PE_CASES.items():
+            pe1, pe2, _ = synth.make_pe_reads(chroms, 2000, 150, **kw)
+            f1, f2 = os.path.join(tmp, name + "_1.fa"), os.path.join(tmp, name + "_2.fa")
+            synth.write_fasta(f1, pe1)
+            synth.write_fasta(f2, pe2)
+            hist = run(tmp, name, args, ["-i", f1, "-u", f2])
+            for k, fp in (("1", f1), ("2", f2)):
+                with open(fp, "rb") as f, lzma.open(os.path.join(HERE, "sam_%s_%s.fa.xz" % (name, k)), "wb", preset=9) as g:
+                    g.write(f.read())
+            meta[name] = dict(args=args, nar=hist)
+            print(name, hist)
+    json.dump(meta, open(os.path.join(HERE, "sam_cases.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -100,3 +100,50 @@ def golden_genome():
     """The genome behind tests/golden/g1.sfx (tests/golden/make_golden.py)."""
     return make_genome([60000, 40000, 25000, 300, 120], repeats=40, repeat_len=250, repeat_div=0.01, n_runs=6,
                        tandem=6)
+
+
+BASES = "ACGTN"
+
+
+def make_pe_reads(chroms, n_pairs, read_len, seed=READS_SEED + 3, frag_min=300, frag_max=500, sub_lambda=1.0,
+                  n_prob=0.0, random_mate_frac=0.0):
+    """PE pairs as `ngskit4b simreads -p`: fragment uniform in [frag_min, frag_max], PE1 = 5' end of the fragment,
+    PE2 = reverse complement of its 3' end; fragment strand 50/50.  Returns (pe1 list, pe2 list, truth[n,5]:
+    chrom(1-based), fragment start, fragment length, strand, 0)."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(c) for c in chroms], dtype=np.int64)
+    w = np.where(lens >= frag_max, lens - frag_max + 1, 0).astype(np.float64)
+    w /= w.sum()
+    pe1, pe2, truth = [], [], np.zeros((n_pairs, 5), dtype=np.int64)
+
+    def mutate(rd):
+        ns = int(min(rng.poisson(sub_lambda), 8)) if sub_lambda > 0 else 0
+        for p_ in rng.choice(len(rd), size=ns, replace=False):
+            if rd[p_] <= 3:
+                rd[p_] = (rd[p_] + int(rng.integers(1, 4))) % 4
+        if n_prob and rng.random() < n_prob:
+            rd[rng.choice(len(rd), size=int(rng.integers(1, 3)), replace=False)] = 4
+        return rd
+
+    for i in range(n_pairs):
+        c = int(rng.choice(len(chroms), p=w))
+        flen = int(rng.integers(frag_min, frag_max + 1))
+        start = int(rng.integers(0, lens[c] - flen + 1))
+        frag = chroms[c][start:start + flen]
+        strand = int(rng.integers(0, 2))
+        if strand:
+            frag = revcomp(frag)
+        a = mutate(frag[:read_len].copy())
+        b = mutate(revcomp(frag[flen - read_len:]))
+        if random_mate_frac and rng.random() < random_mate_frac:
+            b = rng.integers(0, 4, size=read_len, dtype=np.uint8)
+        pe1.append(a)
+        pe2.append(b)
+        truth[i] = (c + 1, start, flen, strand, 0)
+    return pe1, pe2, truth
+
+
+def write_fasta(path, reads, prefix="rd"):
+    with open(path, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(">%s%06d synthetic\n%s\n" % (prefix, i + 1, "".join(BASES[b] for b in r)))
