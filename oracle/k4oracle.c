@@ -769,3 +769,256 @@ int k4o_align_reads_batch(const k4o_index* ix, int tot_mm, int core_len, int cor
   run_batch(&j, nthreads, ctr);
   return 0;
 }
+
+
+/* ==== paired ends ============================================================================================= */
+/* PEInsertSize, KAligner.cpp:2875-2918 (m_bPEcircularised false) */
+int k4o_pe_insert_size(int pair_min_len, int pair_max_len, int pair_strand, uint8_t s1, uint32_t st1, uint32_t en1,
+                       uint8_t s2, uint32_t st2, uint32_t en2) {
+  if ((pair_strand && s1 != s2) || (!pair_strand && s1 == s2)) return -1;
+  uint32_t mx = en1 > en2 ? en1 : en2, mn = st1 < st2 ? st1 : st2;
+  int frag = (int)(1 + mx - mn);
+  if (frag < 0) return -1;
+  if (frag < pair_min_len) return -6;
+  if (frag > pair_max_len) return -7;
+  return frag;
+}
+
+/* AcceptProvPE, KAligner.cpp:2799-2861 (no chromosome filters; hits are untrimmed full-length: Adj* are identities) */
+static int accept_prov_pe(const k4o_pe_params* pe, int nh1, const k4o_hit* h1, int nh2, const k4o_hit* h2) {
+  if (!(nh1 == 1 && nh2 == 1)) return 0;
+  if (h1->chrom_id != h2->chrom_id) return -2;
+  return k4o_pe_insert_size(pe->pair_min_len, pe->pair_max_len, pe->pair_strand, h1->strand, h1->match_loci,
+                            h1->match_loci + h1->match_len - 1, h2->strand, h2->match_loci,
+                            h2->match_loci + h2->match_len - 1);
+}
+
+/* AdaptiveTrim with MinTrimLen == SeqLen, SfxArray.cpp:5561-5639: mismatch count with the end-flank rule; returns
+ * SeqLen and *mms when accepted, 0 when not, <0 on parameter errors */
+static int adaptive_trim_full(int seq_len, const uint8_t* probe, const uint8_t* targ, uint32_t max_mm, uint32_t min_flank,
+                              uint32_t* mms) {
+  *mms = 0;
+  if (seq_len < 25 || seq_len > 2048 || seq_len < 15 || max_mm > (uint32_t)((15 * seq_len + 99) / 100) || min_flank > 10)
+    return -100;
+  if (min_flank == 0) min_flank = 1;
+  uint32_t max_allowed = ((uint32_t)seq_len * max_mm + 99) / 100, n = 0;
+  for (int o = 0; o < seq_len; o++) {
+    if ((probe[o] & 0x0f) != (targ[o] & 0x0f)) {
+      if (++n > max_allowed) break;
+      if ((uint32_t)o < min_flank || (uint32_t)(seq_len - o) < min_flank) { n = max_allowed + 1; break; }
+    }
+  }
+  if (n <= max_allowed) { *mms = n; return seq_len; }
+  return 0;
+}
+
+/* AlignPairedRead, SfxArray.cpp:8571-8767, MinChimericLen == 0, insert window < 1000 (linear scan :8731-8766).
+ * Returns 1 with *out filled, 0 no match, -1 bad arguments, -3 window >= 1000 (degenerate CoreLen==0 path, unsupported) */
+int k4o_align_paired_read(const k4o_index* ix, int b3prime, int antisense, uint32_t chrom_id, uint32_t start_loci,
+                          uint32_t end_loci, int min_insert, int max_insert, int max_allowed_mm, int read_len,
+                          const uint8_t* read, k4o_hit* out) {
+  memset(out, 0, sizeof(*out));
+  if (chrom_id < 1 || chrom_id > ix->n_entries) return -1;
+  const k4o_entry* e = &ix->entries[chrom_id - 1];
+  uint32_t chrom_len = e->seq_len;
+  if (chrom_len == 0) return -1;
+  if (start_loci >= end_loci || end_loci >= chrom_len) return -1;
+  if (min_insert > max_insert) return 0;
+  if (min_insert < read_len) { max_insert += read_len - min_insert; min_insert = read_len; }
+  uint32_t sp, ep;
+  if (b3prime) {
+    if ((uint32_t)(start_loci + min_insert) >= chrom_len) return 0;
+    sp = start_loci + min_insert - read_len;
+    uint32_t a = chrom_len - read_len, b = (uint32_t)(start_loci + max_insert - read_len);
+    ep = a < b ? a : b;
+  } else {
+    if (end_loci < (uint32_t)min_insert) return 0;
+    sp = end_loci <= (uint32_t)max_insert ? 0 : end_loci - max_insert;
+    ep = end_loci - min_insert;
+  }
+  if ((ep - sp) >= 1000) return -3;
+  uint8_t* rs = (uint8_t*)malloc((size_t)read_len + 1);
+  memcpy(rs, read, (size_t)read_len);
+  if (antisense) k4o_revcomp(rs, read_len);
+  const uint8_t* chrom = ix->seq + e->start_ofs;
+  int min_put_len = read_len;
+  uint32_t prev_best = (uint32_t)max_allowed_mm + 1;
+  for (uint32_t loci = sp; loci <= ep; loci++) {
+    uint32_t mms;
+    int r = adaptive_trim_full(read_len, rs, chrom + loci, (uint32_t)max_allowed_mm, 3, &mms);
+    if (r > min_put_len || (r == min_put_len && mms < prev_best)) {
+      prev_best = mms;
+      min_put_len = r;
+      out->chrom_id = chrom_id;
+      out->match_loci = loci;
+      out->match_len = (uint16_t)read_len;
+      out->strand = antisense ? '-' : '+';
+      out->mismatches = (uint8_t)mms;
+      if (mms == 0) break;
+    }
+    if (ep == 0xFFFFFFFFu) break;
+  }
+  free(rs);
+  return prev_best <= (uint32_t)max_allowed_mm ? 1 : 0;
+}
+
+typedef struct {
+  const k4o_index* ix; k4o_kalign_params kp; const k4o_pe_params* pe; int mcl, spm;
+  int64_t n; const uint8_t *r1, *r2; const uint64_t *o1, *o2; const uint32_t *l1, *l2; k4o_pe_read* out;
+  int64_t next; pthread_mutex_t mtx; int bad;
+} pe_job;
+
+static void classify_pe_se(const k4o_read_result* r, const k4o_hit* hits, k4o_pe_read* o) { /* AlignRead, PE branch */
+  memset(o, 0, sizeof(*o));
+  o->nar = r->nar; o->num_hits = r->num_hits; o->inst = r->inst; o->low_mm = r->low_mm;
+  if (r->nar == K4O_NAR_ACCEPTED) o->hit = hits[0];
+}
+
+static int try_rescue(pe_job* j, const k4o_pe_read* anchor, int anchor_is_pe1, const uint8_t* mate, int mate_len,
+                      k4o_hit* hit, int* frag) {
+  const k4o_pe_params* pe = j->pe;
+  int plus = anchor->hit.strand == '+';
+  int b3, anti;
+  if (anchor_is_pe1) { /* KAligner.cpp:3329-3335 */
+    b3 = plus;
+    anti = pe->pair_strand ? !plus : plus;
+  } else {             /* :3438-3444 */
+    b3 = plus; anti = plus;
+    if (pe->pair_strand) { b3 = !b3; anti = !anti; }
+  }
+  uint32_t st = anchor->hit.match_loci, en = anchor->hit.match_loci + anchor->hit.match_len - 1;
+  uint8_t* seq = (uint8_t*)malloc((size_t)mate_len + 1);
+  for (int i = 0; i < mate_len; i++) seq[i] = mate[i] & 0x07;
+  int r = k4o_align_paired_read(j->ix, b3, anti, anchor->hit.chrom_id, st, en, pe->pair_min_len, pe->pair_max_len,
+                                j->kp.max_subs, mate_len, seq, hit);
+  free(seq);
+  if (r == -3) j->bad = 1;
+  if (r == 1) {
+    uint32_t hs = hit->match_loci, he = hit->match_loci + hit->match_len - 1;
+    *frag = anchor_is_pe1 ? k4o_pe_insert_size(pe->pair_min_len, pe->pair_max_len, pe->pair_strand, anchor->hit.strand, st, en, hit->strand, hs, he)
+                          : k4o_pe_insert_size(pe->pair_min_len, pe->pair_max_len, pe->pair_strand, hit->strand, hs, he, anchor->hit.strand, st, en);
+    if (*frag <= 0) r = 0;
+  }
+  return r == 1;
+}
+
+static void process_pair(pe_job* j, int64_t i, uint8_t* scratch) {
+  const k4o_pe_params* pe = j->pe;
+  k4o_read_result r1, r2;
+  k4o_hit h1[10], h2[10];
+  const uint8_t* rd1 = j->r1 + j->o1[i];
+  const uint8_t* rd2 = j->r2 + j->o2[i];
+  int len1 = (int)j->l1[i], len2 = (int)j->l2[i];
+  int hr1 = align_read_with(j->ix, &j->kp, j->mcl, j->spm, rd1, len1, scratch, &r1, h1, NULL);
+  int hr2 = align_read_with(j->ix, &j->kp, j->mcl, j->spm, rd2, len2, scratch, &r2, h2, NULL);
+  k4o_pe_read* f = &j->out[2 * i];
+  k4o_pe_read* r = &j->out[2 * i + 1];
+  classify_pe_se(&r1, h1, f);
+  classify_pe_se(&r2, h2, r);
+  /* ProcCoredApprox: both multi-hit (fewer than cMaxMLPEmatches each): accept iff exactly one consistent combination */
+  if (hr1 == K4O_HR_HITS && hr2 == K4O_HR_HITS && !(f->inst == 1 && r->inst == 1) && f->inst < 10 && r->inst < 10) {
+    int multi = 0, accepted = 0;
+    k4o_hit p1, p2;
+    for (int a = 0; !(multi && !accepted) && a < f->inst; a++)
+      for (int b = 0; b < r->inst; b++)
+        if (accept_prov_pe(pe, 1, &h1[a], 1, &h2[b]) > 0) {
+          if (!multi) { p1 = h1[a]; p2 = h2[b]; multi = 1; accepted = 1; }
+          else { accepted = 0; break; }
+        }
+    if (accepted) {
+      f->hit = p1; f->nar = K4O_NAR_ACCEPTED; f->num_hits = 1;
+      r->hit = p2; r->nar = K4O_NAR_ACCEPTED; r->num_hits = 1;
+    }
+  }
+  /* ProcessPairedEnds, KAligner.cpp:3207-3585 */
+  int f_unal = f->nar == K4O_NAR_NS || f->nar == K4O_NAR_NOHIT || f->nar == K4O_NAR_UNALIGNED;
+  int r_unal = r->nar == K4O_NAR_NS || r->nar == K4O_NAR_NOHIT || r->nar == K4O_NAR_UNALIGNED;
+  if (!(f->nar == K4O_NAR_ACCEPTED || r->nar == K4O_NAR_ACCEPTED)) return;
+  const int unique_only = pe->pe_mode == 2;
+  if (unique_only && (f_unal || r_unal)) goto no_pe_strict;
+  if (f->nar == K4O_NAR_ACCEPTED && r->nar == K4O_NAR_ACCEPTED) {
+    int frag = accept_prov_pe(pe, f->num_hits, &f->hit, r->num_hits, &r->hit);
+    if (frag > 0) { f->pe_aligned = r->pe_aligned = 1; return; }
+    switch (frag) {
+      case -1: f->nar = r->nar = K4O_NAR_PESTRAND; break;
+      case -2: f->nar = r->nar = K4O_NAR_PECHROM; break;
+      case -6: f->nar = r->nar = K4O_NAR_PEINSERTMIN; break;
+      case -7: f->nar = r->nar = K4O_NAR_PEINSERTMAX; break;
+      default: break;
+    }
+    if (unique_only) goto no_pe_strict;
+  }
+  if (pe->pe_mode == 1 || pe->pe_mode == 3) {
+    k4o_hit hit;
+    int frag;
+    if (f->num_hits == 1 && !r_unal && try_rescue(j, f, 1, rd2, len2, &hit, &frag)) {
+      r->hit = hit; r->num_hits = 1; r->low_mm = hit.mismatches; r->inst = 1; r->rescued = 1;
+      f->pe_aligned = r->pe_aligned = 1;
+      f->nar = r->nar = K4O_NAR_ACCEPTED;
+      return;
+    }
+    if (r->num_hits == 1 && !f_unal && try_rescue(j, r, 0, rd1, len1, &hit, &frag)) {
+      f->hit = hit; f->low_mm = hit.mismatches; f->num_hits = 1; f->inst = 1; f->rescued = 1;
+      f->pe_aligned = r->pe_aligned = 1;
+      f->nar = r->nar = K4O_NAR_ACCEPTED;
+      return;
+    }
+  }
+  if (!(pe->pe_mode == 3 || pe->pe_mode == 4)) {
+    f->num_hits = 0; f->inst = 0; r->num_hits = 0; r->inst = 0;
+    if (f->nar == K4O_NAR_ACCEPTED) f->nar = K4O_NAR_PENOHIT;
+    if (r->nar == K4O_NAR_ACCEPTED) r->nar = K4O_NAR_PENOHIT;
+    return;
+  }
+  /* allowed to accept as SE if uniquely aligned (:3545-3584; no chromosome filter => bChromFilt == true when NumHits == 1) */
+  if (f->num_hits != 1) { f->num_hits = 0; f->inst = 0; if (f->nar == K4O_NAR_ACCEPTED) f->nar = K4O_NAR_PEUNALIGN; }
+  else f->nar = K4O_NAR_ACCEPTED;
+  if (r->num_hits != 1) { r->num_hits = 0; r->inst = 0; if (r->nar == K4O_NAR_ACCEPTED) r->nar = K4O_NAR_PEUNALIGN; }
+  else r->nar = K4O_NAR_ACCEPTED;
+  return;
+no_pe_strict:
+  f->num_hits = 0; r->num_hits = 0; f->inst = 0; r->inst = 0;
+  if (f->nar == K4O_NAR_ACCEPTED) f->nar = K4O_NAR_PENOHIT;
+  if (r->nar == K4O_NAR_ACCEPTED) r->nar = K4O_NAR_PENOHIT;
+}
+
+static void* pe_worker(void* arg) {
+  pe_job* j = (pe_job*)arg;
+  uint8_t* scratch = (uint8_t*)malloc(1 << 16);
+  for (;;) {
+    pthread_mutex_lock(&j->mtx);
+    int64_t b = j->next;
+    j->next += 64;
+    pthread_mutex_unlock(&j->mtx);
+    if (b >= j->n) break;
+    int64_t e = b + 64 < j->n ? b + 64 : j->n;
+    for (int64_t i = b; i < e; i++) process_pair(j, i, scratch);
+  }
+  free(scratch);
+  return NULL;
+}
+
+int k4o_kalign_pe_batch(const k4o_index* ix, const k4o_kalign_params* kp, const k4o_pe_params* pe, int64_t n_pairs,
+                        const uint8_t* reads1, const uint64_t* offs1, const uint32_t* lens1, const uint8_t* reads2,
+                        const uint64_t* offs2, const uint32_t* lens2, k4o_pe_read* out, int nthreads) {
+  pe_job j;
+  memset(&j, 0, sizeof(j));
+  j.ix = ix; j.kp = *kp; j.pe = pe; j.n = n_pairs;
+  j.kp.pe_mode = 1;
+  j.kp.max_ml = kp->max_ml > 10 ? kp->max_ml : 10; /* max(m_MaxMLmatches, cMaxMLPEmatches), KAligner.cpp:9604 */
+  j.r1 = reads1; j.o1 = offs1; j.l1 = lens1; j.r2 = reads2; j.o2 = offs2; j.l2 = lens2; j.out = out;
+  j.mcl = kp->min_core_len; j.spm = kp->max_num_slides;
+  if (j.mcl <= 0 || j.spm <= 0) {
+    int s2, m2 = k4o_min_core_len(ix, kp->pmode, &s2);
+    if (j.mcl <= 0) j.mcl = m2;
+    if (j.spm <= 0) j.spm = s2;
+  }
+  pthread_mutex_init(&j.mtx, NULL);
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  pthread_t th[256];
+  for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, pe_worker, &j);
+  for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  pthread_mutex_destroy(&j.mtx);
+  return j.bad ? -3 : 0;
+}

@@ -132,6 +132,39 @@ int k4o_align_reads_batch(const k4o_index* ix, int tot_mm, int core_len, int cor
                           int32_t* inst, int32_t* low, int32_t* nxt, k4o_hit* hits, int nthreads,
                           k4o_counters* ctr);
 
+/* ---- paired ends ------------------------------------------------------------------------------------------ */
+/* eNAR values the PE pass assigns, ngskit4b/KAligner.h:136-158 */
+enum { K4O_NAR_CHROMFILT = 11, K4O_NAR_PEINSERTMIN = 13, K4O_NAR_PEINSERTMAX = 14, K4O_NAR_PENOHIT = 15,
+       K4O_NAR_PESTRAND = 16, K4O_NAR_PECHROM = 17, K4O_NAR_PEUNALIGN = 18 };
+
+typedef struct {
+  int pe_mode;       /* etPEproc: 1 orphan recovery, 2 unique only, 3 orphanSE, 4 uniqueSE (KAligner.h:278-282) */
+  int pair_min_len;  /* -d */
+  int pair_max_len;  /* -D */
+  int pair_strand;   /* -E */
+} k4o_pe_params;
+
+typedef struct {     /* the tsReadHit fields that matter downstream of ProcessPairedEnds */
+  int32_t nar;
+  int32_t num_hits;
+  int32_t inst;
+  int32_t low_mm;
+  int32_t pe_aligned; /* FlgPEAligned */
+  int32_t rescued;    /* 1 when the hit came from AlignPairedRead */
+  k4o_hit hit;
+} k4o_pe_read;
+
+int k4o_pe_insert_size(int pair_min_len, int pair_max_len, int pair_strand, uint8_t pe1_strand, uint32_t pe1_start,
+                       uint32_t pe1_end, uint8_t pe2_strand, uint32_t pe2_start, uint32_t pe2_end); /* KAligner.cpp:2875-2918 */
+int k4o_align_paired_read(const k4o_index* ix, int b3prime_extend, int antisense, uint32_t chrom_id,
+                          uint32_t start_loci, uint32_t end_loci, int min_insert, int max_insert, int max_allowed_mm,
+                          int read_len, const uint8_t* read, k4o_hit* out); /* SfxArray.cpp:8571-8767 + AdaptiveTrim :5561-5639 */
+/* CKAligner PE flow for n_pairs pairs: ProcCoredApprox (KAligner.cpp:10160-10239) then ProcessPairedEnds (:3159-3596).
+ * out[2*i] = PE1, out[2*i+1] = PE2. kp->pe_mode / max_ml are forced to the PE values (1, 10). */
+int k4o_kalign_pe_batch(const k4o_index* ix, const k4o_kalign_params* kp, const k4o_pe_params* pe, int64_t n_pairs,
+                        const uint8_t* reads1, const uint64_t* offs1, const uint32_t* lens1, const uint8_t* reads2,
+                        const uint64_t* offs2, const uint32_t* lens2, k4o_pe_read* out, int nthreads);
+
 void k4o_revcomp(uint8_t* seq, int len);                                      /* SeqTrans.cpp:497-545 */
 
 #ifdef __cplusplus

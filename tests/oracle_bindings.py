@@ -38,6 +38,16 @@ class KalignParams(C.Structure):
     ]
 
 
+class PeParams(C.Structure):
+    _fields_ = [("pe_mode", C.c_int), ("pair_min_len", C.c_int), ("pair_max_len", C.c_int), ("pair_strand", C.c_int)]
+
+
+PE_READ_DTYPE = np.dtype(
+    [("nar", "<i4"), ("num_hits", "<i4"), ("inst", "<i4"), ("low_mm", "<i4"), ("pe_aligned", "<i4"), ("rescued", "<i4"),
+     ("hit", HIT_DTYPE)]
+)
+
+
 class Counters(C.Structure):
     _fields_ = [("n_lookup", C.c_uint64), ("n_probe", C.c_uint64), ("n_cand", C.c_uint64)]
 
@@ -111,6 +121,10 @@ class Oracle:
         L.k4o_align_reads_batch.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_int64] + [C.c_void_p] * 8 + [
             C.c_int, C.POINTER(Counters)]
         L.k4o_revcomp.argtypes = [C.c_void_p, C.c_int]
+        L.k4o_kalign_pe_batch.argtypes = [C.c_void_p, C.POINTER(KalignParams), C.POINTER(PeParams), C.c_int64] + [
+            C.c_void_p] * 7 + [C.c_int]
+        L.k4o_pe_insert_size.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint8, C.c_uint32, C.c_uint32, C.c_uint8,
+                                         C.c_uint32, C.c_uint32]
         self.L = L
 
     # -- index ------------------------------------------------------------------------------------
@@ -204,6 +218,28 @@ class Oracle:
                                out.ctypes.data, hits.ctypes.data, threads, C.byref(ctr))
         return dict(out=out, hits=hits,
                     counters=dict(n_lookup=ctr.n_lookup, n_probe=ctr.n_probe, n_cand=ctr.n_cand))
+
+
+def _kalign_pe(L, fn, h, reads1, reads2, pe_mode, pair_min_len, pair_max_len, pair_strand, threads, **kw):
+    c1, o1, l1 = reads1 if isinstance(reads1, tuple) else flatten_reads(reads1)
+    c2, o2, l2 = reads2 if isinstance(reads2, tuple) else flatten_reads(reads2)
+    assert len(l1) == len(l2)
+    kp = KalignParams(kw.get("max_subs", 5), kw.get("min_edit_dist", 1), kw.get("max_ns", 1), kw.get("pmode", 0),
+                      kw.get("strand", STRAND_BOTH), 10, 1, kw.get("min_core_len", 0), kw.get("max_num_slides", 0))
+    pe = PeParams(pe_mode, pair_min_len, pair_max_len, 1 if pair_strand else 0)
+    out = np.zeros(2 * len(l1), dtype=PE_READ_DTYPE)
+    rc = fn(h, C.byref(kp), C.byref(pe), len(l1), c1.ctypes.data, o1.ctypes.data, l1.ctypes.data, c2.ctypes.data,
+            o2.ctypes.data, l2.ctypes.data, out.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError("kalign_pe_batch failed: %d" % rc)
+    return out
+
+
+def oracle_kalign_pe(O, h, reads1, reads2, pe_mode=2, pair_min_len=100, pair_max_len=1000, pair_strand=False, threads=4,
+                     **kw):
+    """CKAligner PE flow (ProcCoredApprox + ProcessPairedEnds) on the CPU oracle; out[2i] = PE1, out[2i+1] = PE2."""
+    return _kalign_pe(O.L, O.L.k4o_kalign_pe_batch, h, reads1, reads2, pe_mode, pair_min_len, pair_max_len, pair_strand,
+                      threads, **kw)
 
 
 class _RefHit(C.Structure):

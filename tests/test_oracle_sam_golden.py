@@ -1,0 +1,67 @@
+"""Pins the oracle's CKAligner-level restatement (AlignRead classification, ProcCoredApprox multi-hit pairing,
+ProcessPairedEnds incl. mate rescue) to what the real `ngskit4b kalign` wrote (tests/golden/sam_*.xz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import samutil
+from oracle_bindings import oracle_kalign_pe
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = json.load(open(os.path.join(GOLDEN, "sam_cases.json")))
+NAR_CODE = {"AA": 1, "EN": 2, "NL": 3, "MH": 4, "ML": 5, "UI": 13, "OI": 14, "UP": 15, "IS": 16, "IT": 17, "NP": 18}
+CHROMS = ["chr1", "chr2", "chr3", "chr4", "chr5"]
+
+
+def kalign_args(args):
+    kw = dict(max_subs=5, min_edit_dist=1, pmode=0)
+    pe = dict(pe_mode=0, pair_min_len=100, pair_max_len=1000)
+    for a in args:
+        if a.startswith("-s"): kw["max_subs"] = int(a[2:])
+        elif a.startswith("-e"): kw["min_edit_dist"] = int(a[2:])
+        elif a.startswith("-m"): kw["pmode"] = int(a[2:])
+        elif a.startswith("-U"): pe["pe_mode"] = int(a[2:])
+        elif a.startswith("-d"): pe["pair_min_len"] = int(a[2:])
+        elif a.startswith("-D"): pe["pair_max_len"] = int(a[2:])
+    return kw, pe
+
+
+def check_hist(nars, expect):
+    got = np.bincount(np.asarray(nars), minlength=32)
+    for name, code in NAR_CODE.items():
+        assert got[code] == expect.get(name, 0), (name, got[code], expect.get(name, 0))
+
+
+@pytest.mark.parametrize("case", sorted(c for c in CASES if c.startswith("se_")))
+def test_se_matches_reference_sam(oracle, golden_dir, case):
+    kw, _ = kalign_args(CASES[case]["args"])
+    names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % case))
+    h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    oracle.set_max_iter(h, 5000 if kw["pmode"] == 0 else 10000)
+    r = oracle.kalign_batch(h, reads, **kw)
+    check_hist(r["out"]["nar"], CASES[case]["nar"])
+    res = [dict(nar=int(o["nar"]), hit=hh[0], pe_aligned=0) for o, hh in zip(r["out"], r["hits"])]
+    _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    assert sorted(samutil.sam_records(names, reads, res, CHROMS)) == sorted(recs)
+    oracle.close(h)
+
+
+@pytest.mark.parametrize("case", sorted(c for c in CASES if c.startswith("pe_")))
+def test_pe_matches_reference_sam(oracle, golden_dir, case):
+    kw, pe = kalign_args(CASES[case]["args"])
+    n1, r1 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_1.fa.xz" % case))
+    n2, r2 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_2.fa.xz" % case))
+    h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    oracle.set_max_iter(h, 5000)
+    out = oracle_kalign_pe(oracle, h, r1, r2, threads=4, **pe, **kw)
+    check_hist(out["nar"], CASES[case]["nar"])
+    names = [x for p in zip(n1, n2) for x in p]
+    reads = [x for p in zip(r1, r2) for x in p]
+    res = [dict(nar=int(o["nar"]), hit=o["hit"], pe_aligned=int(o["pe_aligned"])) for o in out]
+    _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    assert sorted(samutil.sam_records(names, reads, res, CHROMS, paired=True)) == sorted(recs)
+    if case == "pe_u1":
+        assert out["rescued"].sum() > 0  # the mate-rescue path (AlignPairedRead) is exercised
+    oracle.close(h)
