@@ -182,6 +182,48 @@ int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n_reads
                         void* stream);
 int k4_min_core_len(const k4_index* ix, int pmode, int* max_num_slides); /* <- LocateCoredApprox, KAligner.cpp:9367-9393 */
 
+/* ---- paired ends -----------------------------------------------------------------------------------------
+ * k4_mate_rescue_batch <- CSfxArray::AlignPairedRead (SfxArray.h:880, SfxArray.cpp:8571-8767; MinChimericLen 0, insert
+ *                         window < 1000 => the linear-scan branch :8731-8766 with AdaptiveTrim's full-length rule :5612-5638)
+ * k4_kalign_pe_batch   <- the PE flow of CKAligner: ProcCoredApprox (KAligner.cpp:10160-10239: both ends aligned as SE
+ *                         with MaxHits 10, multi x multi resolution) + ProcessPairedEnds (:3159-3596: AcceptProvPE,
+ *                         PEInsertSize, orphan rescue, NAR reassignment).  out[2i] = PE1 of pair i, out[2i+1] = PE2. */
+enum { K4_NAR_CHROMFILT = 11, K4_NAR_PEINSERTMIN = 13, K4_NAR_PEINSERTMAX = 14, K4_NAR_PENOHIT = 15, K4_NAR_PESTRAND = 16,
+       K4_NAR_PECHROM = 17, K4_NAR_PEUNALIGN = 18 };  /* eNAR, KAligner.h:136-158 */
+typedef struct {
+  int32_t pe_mode;      /* etPEproc (KAligner.h:278-282): 1 orphan recovery, 2 unique only, 3 orphanSE, 4 uniqueSE */
+  int32_t pair_min_len; /* -d */
+  int32_t pair_max_len; /* -D */
+  int32_t pair_strand;  /* -E */
+} k4_pe_params;
+typedef struct {        /* the tsReadHit fields that matter after ProcessPairedEnds */
+  int32_t nar;
+  int32_t num_hits;
+  int32_t inst;
+  int32_t low_mm;
+  int32_t pe_aligned;   /* FlgPEAligned */
+  int32_t rescued;      /* 1 when the hit came from the mate rescue */
+  k4_hit hit;
+} k4_pe_read;
+typedef struct {        /* one AlignPairedRead call */
+  uint32_t chrom_id;    /* ChromID of the anchored mate */
+  uint32_t start_loci;  /* StartLoci / EndLoci of the anchored mate */
+  uint32_t end_loci;
+  uint32_t read_len;    /* ReadLen of the mate to place */
+  uint64_t read_off;    /* its bases: reads[read_off .. read_off+read_len) (etSeqBase bytes, sense as sequenced) */
+  int32_t b3prime_extend;
+  int32_t antisense;
+  int32_t min_insert;
+  int32_t max_insert;
+  int32_t max_allowed_mm;
+  int32_t reserved;
+} k4_rescue_task;
+int k4_mate_rescue_batch(k4_index* ix, int64_t n_tasks, const k4_rescue_task* tasks, const uint8_t* reads,
+                         uint64_t reads_bytes, int32_t* rslt, k4_hit* hits);
+int k4_kalign_pe_batch(k4_index* ix, const k4_kalign_params* p, const k4_pe_params* pe, int64_t n_pairs,
+                       const uint8_t* reads1, const uint64_t* offs1, const uint32_t* lens1, const uint8_t* reads2,
+                       const uint64_t* offs2, const uint32_t* lens2, k4_pe_read* out);
+
 /* kernel timing for roofline measurement: when enabled, every batch brackets the dominant kernel (k4k_align_fast) with
  * HIP events on the stream it is launched on; k4_get_kernel_times synchronises, returns the summed duration and the
  * number of launches since the last call, and resets. */

@@ -58,6 +58,17 @@ class KalignParams(C.Structure):
                 ("max_num_slides", C.c_int32)]
 
 
+class PeParams(C.Structure):
+    _fields_ = [("pe_mode", C.c_int32), ("pair_min_len", C.c_int32), ("pair_max_len", C.c_int32),
+                ("pair_strand", C.c_int32)]
+
+
+PE_READ_DTYPE = np.dtype(
+    [("nar", "<i4"), ("num_hits", "<i4"), ("inst", "<i4"), ("low_mm", "<i4"), ("pe_aligned", "<i4"), ("rescued", "<i4"),
+     ("hit", HIT_DTYPE)]
+)
+
+
 class Counters(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_lookup", C.c_uint64), ("n_probe", C.c_uint64), ("n_cand", C.c_uint64),
                 ("n_slow", C.c_uint64), ("n_bases", C.c_uint64)]
@@ -71,7 +82,7 @@ ABI_SYMBOLS = [
     "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
-    "k4_get_kernel_times",
+    "k4_get_kernel_times", "k4_mate_rescue_batch", "k4_kalign_pe_batch",
 ]
 
 
@@ -122,6 +133,8 @@ def lib():
     L.k4_reset_counters.argtypes = [vp]
     L.k4_enable_kernel_timing.argtypes = [vp, i32]
     L.k4_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.k4_mate_rescue_batch.argtypes = [vp, i64, vp, vp, u64, vp, vp]
+    L.k4_kalign_pe_batch.argtypes = [vp, C.POINTER(KalignParams), C.POINTER(PeParams), i64] + [vp] * 7
     _lib = L
     return L
 
@@ -282,6 +295,21 @@ class SfxIndex:
         self._ck(lib().k4_kalign_batch(self.h, C.byref(p), n, cat.ctypes.data, offs.ctypes.data, lens.ctypes.data,
                                        out.ctypes.data, hits.ctypes.data))
         return dict(out=out, hits=hits)
+
+    def kalign_pe_batch(self, reads1, reads2, pe_mode=2, pair_min_len=100, pair_max_len=1000, pair_strand=False,
+                        max_subs=5, min_edit_dist=1, max_ns=1, pmode=0, strand=STRAND_BOTH, min_core_len=0,
+                        max_num_slides=0):
+        """CKAligner's PE flow (ProcCoredApprox + ProcessPairedEnds); out[2i] = PE1, out[2i+1] = PE2."""
+        c1, o1, l1 = _flatten(reads1)
+        c2, o2, l2 = _flatten(reads2)
+        assert len(l1) == len(l2)
+        kp = KalignParams(max_subs, min_edit_dist, max_ns, pmode, strand, 10, 1, min_core_len, max_num_slides)
+        pe = PeParams(pe_mode, pair_min_len, pair_max_len, 1 if pair_strand else 0)
+        out = np.zeros(2 * len(l1), dtype=PE_READ_DTYPE)
+        self._ck(lib().k4_kalign_pe_batch(self.h, C.byref(kp), C.byref(pe), len(l1), c1.ctypes.data, o1.ctypes.data,
+                                          l1.ctypes.data, c2.ctypes.data, o2.ctypes.data, l2.ctypes.data,
+                                          out.ctypes.data))
+        return out
 
     # -- the hot path (device buffers; pointers are ints, e.g. torch.Tensor.data_ptr()) -------------------------
     def kalign_batch_dev(self, params, n, max_read_len, d_reads, d_offs, d_lens, d_out, d_hits, stream=0):

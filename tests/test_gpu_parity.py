@@ -194,3 +194,78 @@ def test_empty_and_degenerate_batches(k4, golden_dir):
     with pytest.raises(k4.K4Error):
         ix.align_reads_batch(reads, 2, 0, 33, 8)
     ix.close()
+
+
+# ---- paired ends -------------------------------------------------------------------------------------------------------
+import json  # noqa: E402
+
+import samutil  # noqa: E402
+from oracle_bindings import oracle_kalign_pe  # noqa: E402
+
+SAM_CASES = json.load(open(os.path.join(GOLDEN, "sam_cases.json")))
+CHROMS = ["chr1", "chr2", "chr3", "chr4", "chr5"]
+
+
+def _kalign_args(args):
+    kw = dict(max_subs=5, min_edit_dist=1, pmode=0)
+    pe = dict(pe_mode=0, pair_min_len=100, pair_max_len=1000)
+    for a in args:
+        if a.startswith("-s"): kw["max_subs"] = int(a[2:])
+        elif a.startswith("-e"): kw["min_edit_dist"] = int(a[2:])
+        elif a.startswith("-m"): kw["pmode"] = int(a[2:])
+        elif a.startswith("-U"): pe["pe_mode"] = int(a[2:])
+        elif a.startswith("-d"): pe["pair_min_len"] = int(a[2:])
+        elif a.startswith("-D"): pe["pair_max_len"] = int(a[2:])
+    return kw, pe
+
+
+@pytest.mark.parametrize("case", sorted(SAM_CASES))
+def test_reference_sam_end_to_end(k4, golden_dir, case):
+    """The records `ngskit4b kalign` wrote (SE and PE incl. mate rescue) are reproduced from the GPU results."""
+    kw, pe = _kalign_args(SAM_CASES[case]["args"])
+    ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    ix.set_max_iter(5000 if kw["pmode"] == 0 else 10000)
+    _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    if case.startswith("se_"):
+        names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % case))
+        r = ix.kalign_batch(reads, **kw)
+        res = [dict(nar=int(o["nar"]), hit=hh[0], pe_aligned=0) for o, hh in zip(r["out"], r["hits"])]
+        got = samutil.sam_records(names, reads, res, CHROMS)
+        nars = r["out"]["nar"]
+    else:
+        n1, r1 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_1.fa.xz" % case))
+        n2, r2 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_2.fa.xz" % case))
+        out = ix.kalign_pe_batch(r1, r2, **pe, **kw)
+        names = [x for p in zip(n1, n2) for x in p]
+        reads = [x for p in zip(r1, r2) for x in p]
+        res = [dict(nar=int(o["nar"]), hit=o["hit"], pe_aligned=int(o["pe_aligned"])) for o in out]
+        got = samutil.sam_records(names, reads, res, CHROMS, paired=True)
+        nars = out["nar"]
+    assert sorted(got) == sorted(recs)
+    hist = np.bincount(nars, minlength=32)
+    for name, code in {"AA": 1, "EN": 2, "NL": 3, "MH": 4, "ML": 5, "UI": 13, "OI": 14, "UP": 15, "IS": 16, "IT": 17}.items():
+        assert hist[code] == SAM_CASES[case]["nar"].get(name, 0), (name, hist[code])
+    ix.close()
+
+
+@pytest.mark.parametrize("pe_mode,pair_strand", [(1, False), (2, False), (3, False), (4, False), (1, True)])
+def test_pe_flow_vs_oracle(k4, oracle, golden_dir, pe_mode, pair_strand):
+    names, chroms = synth.golden_genome()
+    pe1, pe2, _ = synth.make_pe_reads(chroms, 3000, 125, seed=500 + pe_mode, sub_lambda=1.8, n_prob=0.03,
+                                      random_mate_frac=0.05, frag_min=260, frag_max=700)
+    ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    ho = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    ix.set_max_iter(5000)
+    oracle.set_max_iter(ho, 5000)
+    kw = dict(pe_mode=pe_mode, pair_min_len=220, pair_max_len=640, pair_strand=pair_strand, max_subs=2)
+    g = ix.kalign_pe_batch(pe1, pe2, **kw)
+    o = oracle_kalign_pe(oracle, ho, pe1, pe2, threads=8, **kw)
+    for f in ("nar", "num_hits", "inst", "low_mm", "pe_aligned", "rescued"):
+        bad = np.nonzero(g[f] != o[f])[0]
+        assert len(bad) == 0, (f, bad[:6], g[f][bad[:6]], o[f][bad[:6]])
+    acc = g["nar"] == 1
+    assert np.array_equal(g["hit"][acc], o["hit"][acc])
+    if pe_mode in (1, 3) and not pair_strand:
+        assert g["rescued"].sum() > 0
+    ix.close()
+    oracle.close(ho)
