@@ -269,3 +269,68 @@ def test_pe_flow_vs_oracle(k4, oracle, golden_dir, pe_mode, pair_strand):
         assert g["rescued"].sum() > 0
     ix.close()
     oracle.close(ho)
+
+
+# ---- host programs: k4align (SAM out) and the CSfxArray facade ------------------------------------------------------
+import lzma  # noqa: E402
+import subprocess  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _unxz(src, dst):
+    with lzma.open(src, "rb") as f, open(dst, "wb") as g:
+        g.write(f.read())
+    return dst
+
+
+@pytest.mark.parametrize("case", sorted(SAM_CASES))
+def test_k4align_writes_the_reference_sam(k4, golden_dir, tmp_path, case):
+    """`k4align` (C++ over the C ABI) against the SAM `ngskit4b kalign` wrote for the same reads, index and options:
+    identical header (but @PG) and identical records (the reference's order among equal keys is unspecified)."""
+    exe = os.path.join(ROOT, "kit4b_amd", "k4align")
+    assert os.path.exists(exe)
+    out = str(tmp_path / "out.sam")
+    cmd = [exe, "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out] + SAM_CASES[case]["args"]
+    if case.startswith("se_"):
+        cmd += ["-i", _unxz(os.path.join(golden_dir, "sam_%s.fa.xz" % case), str(tmp_path / "r.fa"))]
+    else:
+        cmd += ["-i", _unxz(os.path.join(golden_dir, "sam_%s_1.fa.xz" % case), str(tmp_path / "r1.fa")),
+                "-u", _unxz(os.path.join(golden_dir, "sam_%s_2.fa.xz" % case), str(tmp_path / "r2.fa"))]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    hdr, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    got = open(out).read().splitlines()
+    got_hdr = [l for l in got if l.startswith("@")]
+    got_recs = [l for l in got if not l.startswith("@")]
+    assert [l for l in got_hdr if not l.startswith("@PG")] == [l for l in hdr if not l.startswith("@PG")]
+    assert sorted(got_recs) == sorted(recs)
+    # coordinate order: (RNAME in header order, POS) non-decreasing
+    order = {l.split("\t")[2][3:]: i for i, l in enumerate(h for h in hdr if h.startswith("@SQ"))}
+    keys = [(order[l.split("\t")[2]], int(l.split("\t")[3])) for l in got_recs]
+    assert keys == sorted(keys)
+    for name, n in SAM_CASES[case]["nar"].items():
+        assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+
+
+def test_csfxarray_facade_program(k4, golden_dir):
+    """include/k4_sfxarray.hpp used the way CKAligner uses CSfxArray; known answers of SURVEY App. C."""
+    exe = os.path.join(ROOT, "kit4b_amd", "k4_facade_test")
+    p = subprocess.run([exe, os.path.join(golden_dir, "g1.sfx")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "entries 5 totlen 125420 dataset g1"
+    assert "entry 2 chr2 40000 ident 2" in lines
+    expect = {0: "rslt 1 inst 1 low 0 nxt 2", 1: "rslt 1 inst 1 low 1 nxt 3", 2: "rslt 1 inst 1 low 2 nxt 4",
+              3: "rslt 0 inst 0 low 4 nxt 4"}
+    n = 0
+    for l in lines:
+        if l.startswith("probe"):
+            f = l.split()
+            loci, subs = int(f[1]), int(f[3])
+            assert expect[subs] in l, l
+            if subs <= 2:
+                assert ("chrom 2 loci %d strand + mm %d len 100" % (loci, subs)) in l, l
+            n += 1
+    assert n == 16
+    assert lines[-1] == "chimeric rslt -3 msgs 1"
