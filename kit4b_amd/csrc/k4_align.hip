@@ -283,10 +283,11 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       // the next K4_PF cores are fetched together before any of them is searched: one memory round trip, not K4_PF.
       int oo[K4_PF];
       KT lb0[K4_PF], ps0[K4_PF], lb1[K4_PF];
+      uint32_t sig[K4_PF];
       int cnt = 0;
 #pragma unroll
       for (int j = 0; j < K4_PF; j++) {
-        oo[j] = 0; lb0[j] = 0; ps0[j] = 0; lb1[j] = 0;
+        oo[j] = 0; lb0[j] = 0; ps0[j] = 0; lb1[j] = 0; sig[j] = 0;
         if (cnt == j && slides < rp.max_slides && o_next <= len - cl && cur_delta > cl / 3) {
           if (o_next + cl + cur_delta > len) cur_delta = len - (o_next + cl);
           oo[j] = o_next;
@@ -300,7 +301,13 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       for (int j = 0; j < K4_PF; j++) {
         if (j < cnt) {
           const uint64_t code = ln.chunk_at(s, oo[j]) >> (64 - 2 * kk);
-          k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], lb1[j]);
+          k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j]);
+          // a bucket of one suffix whose next bases already disagree with the core cannot hold a match: drop it here
+          if (sizeof(KT) == 4 && tshift == 0 && lb1[j] == lb0[j] + 1 && cl > kk) {
+            const int nb = min(16, cl - kk);
+            const uint32_t cb = (uint32_t)(ln.chunk_at(s, oo[j] + kk) >> 32);
+            if ((cb ^ sig[j]) & (0xFFFFFFFFu << (32 - 2 * nb))) lb1[j] = lb0[j];
+          }
         }
       }
       // touch the first word of every non-empty bucket's first window now: the lines are on their way (and land in

@@ -45,26 +45,33 @@ K4_DEV uint64_t k4d_sa_at(const K4DevIndex& ix, uint64_t i) {
   }
 }
 
-// k-mer table entry c = {lb, pos0}: lb = number of suffixes sorting before k-mer c (its bucket is [lb(c), lb(c+1))),
-// pos0 = SA[lb] (offset of the bucket's first suffix, valid when the bucket is not empty).
+// k-mer table entry c = {lb, pos0[, sig]}: lb = number of suffixes sorting before k-mer c (its bucket is
+// [lb(c), lb(c+1))), pos0 = SA[lb] (offset of the bucket's first suffix, valid when the bucket is not empty) and, in
+// the 32-bit form, sig = the 16 bases that follow the k-mer in that first suffix (MSB-first), a filter that settles most
+// single-suffix buckets without touching the suffix array or the reference.
+#define K4_KTAB_STRIDE32 3
+#define K4_KTAB_STRIDE64 2
 K4_DEV uint64_t k4d_ktab_lb(const K4DevIndex& ix, uint64_t c) {
-  return ix.ktab64 ? reinterpret_cast<const uint64_t*>(ix.ktab)[2 * c] : reinterpret_cast<const uint32_t*>(ix.ktab)[2 * c];
+  return ix.ktab64 ? reinterpret_cast<const uint64_t*>(ix.ktab)[K4_KTAB_STRIDE64 * c]
+                   : reinterpret_cast<const uint32_t*>(ix.ktab)[K4_KTAB_STRIDE32 * c];
 }
-// bucket of the k-mer prefix range [c0, c1): lb0 = lb(c0), pos0 = pos0(c0), lb1 = lb(c1).  KT = table field type.
+// bucket of the k-mer prefix range [c0, c1): lb0 = lb(c0), pos0 = pos0(c0), sig = sig(c0), lb1 = lb(c1).  KT = field type.
 template <typename KT>
-K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& lb0, KT& pos0, KT& lb1) {
-  const KT* t = reinterpret_cast<const KT*>(ix.ktab);
-  if (c1 == c0 + 1) {  // the common case (core at least k long): three adjacent fields, one fetch
-    const KT* e = t + 2 * c0;
-    if (sizeof(KT) == 4) {
-      const k4_u32x3_a4 v = *reinterpret_cast<const k4_u32x3_a4*>(e);
-      lb0 = (KT)v.x; pos0 = (KT)v.y; lb1 = (KT)v.z;
+K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& lb0, KT& pos0, uint32_t& sig, KT& lb1) {
+  if (sizeof(KT) == 4) {
+    const uint32_t* t = reinterpret_cast<const uint32_t*>(ix.ktab);
+    const uint32_t* e = t + K4_KTAB_STRIDE32 * c0;
+    if (c1 == c0 + 1) {  // the common case (core at least k long): four adjacent fields, one 16-byte fetch
+      const k4_u32x4_a4 v = *reinterpret_cast<const k4_u32x4_a4*>(e);
+      lb0 = (KT)v.x; pos0 = (KT)v.y; sig = v.z; lb1 = (KT)v.w;
     } else {
-      const k4_u64x2_a8 v = *reinterpret_cast<const k4_u64x2_a8*>(e);
-      lb0 = (KT)v.x; pos0 = (KT)v.y; lb1 = e[2];
+      const k4_u32x3_a4 v = *reinterpret_cast<const k4_u32x3_a4*>(e);
+      lb0 = (KT)v.x; pos0 = (KT)v.y; sig = v.z; lb1 = (KT)t[K4_KTAB_STRIDE32 * c1];
     }
   } else {
-    lb0 = t[2 * c0]; pos0 = t[2 * c0 + 1]; lb1 = t[2 * c1];
+    const uint64_t* t = reinterpret_cast<const uint64_t*>(ix.ktab);
+    const k4_u64x2_a8 v = *reinterpret_cast<const k4_u64x2_a8*>(t + K4_KTAB_STRIDE64 * c0);
+    lb0 = (KT)v.x; pos0 = (KT)v.y; sig = 0; lb1 = (KT)t[K4_KTAB_STRIDE64 * c1];
   }
 }
 

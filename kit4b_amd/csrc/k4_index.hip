@@ -140,19 +140,22 @@ __global__ void __launch_bounds__(256) k4k_ktab_mark(K4DevIndex ix, T* __restric
   if (!v) return;
   bool vp = i > 0 && k4d_kmer_code(ix, k4d_sa_at<EL>(ix, i - 1), ix.k, &cp);
   if (!vp || cp != c) {  // first suffix of the run of k-mer c
-    tab[2 * c] = (T)i;
-    tab[2 * c + 1] = (T)k4d_sa_at<EL>(ix, i);
+    constexpr int ST = sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64;
+    const uint64_t pos = k4d_sa_at<EL>(ix, i);
+    tab[ST * c] = (T)i;
+    tab[ST * c + 1] = (T)pos;
+    if (sizeof(T) == 4) tab[ST * c + 2] = (T)(k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 32);  // the next 16 bases
   }
 }
 
-// reverse (suffix) min-scan over the lb fields (stride 2) in three passes: lb[c] = min(lb[c'], c' >= c); unset = max value.
+// reverse (suffix) min-scan over the lb fields (entry stride 3 or 2 words) in three passes: lb[c] = min(lb[c'], c' >= c); unset = max value.
 template <typename T>
 __global__ void __launch_bounds__(256) k4k_scan_block_min(const T* __restrict__ tab, uint64_t n, T* __restrict__ agg) {
   __shared__ T sh[256];
   uint64_t base = (uint64_t)blockIdx.x * 2048 + (uint64_t)threadIdx.x * 8;
   T m = (T)~(T)0;
   for (int j = 0; j < 8; j++)
-    if (base + j < n) m = min(m, tab[2 * (base + j)]);
+    if (base + j < n) m = min(m, tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)]);
   sh[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(256) k4k_scan_apply(T* __restrict__ tab, uint6
   T v[8];
   T m = (T)~(T)0;
   for (int j = 7; j >= 0; j--) {
-    T x = base + j < n ? tab[2 * (base + j)] : (T)~(T)0;
+    T x = base + j < n ? tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)] : (T)~(T)0;
     m = min(m, x);
     v[j] = m;  // min over this thread's elements j..7
   }
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(256) k4k_scan_apply(T* __restrict__ tab, uint6
   T right = threadIdx.x + 1 < 256 ? sh[threadIdx.x + 1] : (T)~(T)0;
   right = min(right, agg[blockIdx.x]);
   for (int j = 0; j < 8; j++)
-    if (base + j < n) tab[2 * (base + j)] = min(v[j], right);
+    if (base + j < n) tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)] = min(v[j], right);
 }
 
 __global__ void k4k_unpack_range(K4DevIndex ix, uint64_t start, uint64_t len, uint8_t* __restrict__ out) {
@@ -231,12 +234,13 @@ template <int EL, typename T>
 static int build_ktab(k4_index* ix) {
   uint64_t nent = (1ull << (2 * ix->d.k)) + 1;
   T* tab = nullptr;
-  K4_HIP(ix, hipMalloc(&tab, nent * 2 * sizeof(T) + 16));
+  const int ST = sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64;
+  K4_HIP(ix, hipMalloc(&tab, nent * ST * sizeof(T) + 32));
   ix->ktab = tab;
-  ix->device_bytes += nent * 2 * sizeof(T) + 16;
-  K4_HIP(ix, hipMemset(tab, 0xFF, nent * 2 * sizeof(T) + 16));
+  ix->device_bytes += nent * ST * sizeof(T) + 32;
+  K4_HIP(ix, hipMemset(tab, 0xFF, nent * ST * sizeof(T) + 32));
   T last = (T)ix->d.n;
-  K4_HIP(ix, hipMemcpy(tab + 2 * (nent - 1), &last, sizeof(T), hipMemcpyHostToDevice));
+  K4_HIP(ix, hipMemcpy(tab + (size_t)ST * (nent - 1), &last, sizeof(T), hipMemcpyHostToDevice));
   ix->d.ktab = tab;
   uint64_t nb = (ix->d.n + 255) / 256;
   hipLaunchKernelGGL((k4k_ktab_mark<EL, T>), dim3((unsigned)nb), dim3(256), 0, 0, ix->d, tab);

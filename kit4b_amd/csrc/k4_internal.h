@@ -16,10 +16,12 @@
 // excblk    sorted list of the flagged block numbers; excnib holds, for flagged block r, its 256 symbols as
 //           nibbles (32 words, symbol j in bits 4*(j&7) of word r*32 + (j>>3)) -- the exact 4-bit reference.
 // sa        the .sfx suffix array unchanged: 4- or 5-byte little-endian elements.
-// ktab      direct-address table over the first k bases, 4^k + 1 entries {lb, pos0} (32-bit fields when
-//           concat_len < 2^32): lb[c] = number of suffixes that sort before the k-mer with code c (first base most
-//           significant), so the bucket of c is SA[lb[c] .. lb[c+1]); pos0[c] = SA[lb[c]], the offset of the
-//           bucket's first suffix, which saves the dependent SA fetch for the first probe of a lookup.
+// ktab      direct-address table over the first k bases, 4^k + 1 entries {lb, pos0, sig} (12 bytes; {lb, pos0} of
+//           64-bit fields when concat_len >= 2^32): lb[c] = number of suffixes that sort before the k-mer with code c
+//           (first base most significant), so the bucket of c is SA[lb[c] .. lb[c+1]); pos0[c] = SA[lb[c]], the
+//           offset of the bucket's first suffix, which saves the dependent SA fetch for the first probe of a lookup;
+//           sig[c] = the 16 bases after the k-mer in that suffix: a core that disagrees with it cannot match a
+//           single-suffix bucket, so no probe is issued.
 // entries   start/end offsets and ids of the chromosomes (tsSfxEntry), sorted by start.
 #define K4_EXC_SHIFT 8            // log2 of the exception-bitmap block size in bases
 #define K4_EXC_BLOCK (1 << K4_EXC_SHIFT)
