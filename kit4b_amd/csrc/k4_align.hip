@@ -112,12 +112,12 @@ K4_DEV void k4d_fold(K4State& st, int mm, k4_hit* hits, int max_hits, uint32_t c
     st.inst = 1;
     st.nxt = st.low;
     st.low = mm;
-    k4d_store_hit(&hits[0], chrom_id, loci, len, strand, mm);
+    if (hits) k4d_store_hit(&hits[0], chrom_id, loci, len, strand, mm);
   } else if (mm == st.low) {
     st.inst += 1;
     if (st.cur_hit != -1 && st.inst <= max_hits) {
       st.cur_hit += 1;
-      if (st.cur_hit < max_hits) k4d_store_hit(&hits[st.cur_hit], chrom_id, loci, len, strand, mm);
+      if (hits && st.cur_hit < max_hits) k4d_store_hit(&hits[st.cur_hit], chrom_id, loci, len, strand, mm);
     }
   } else if (mm < st.nxt)
     st.nxt = mm;
@@ -334,7 +334,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           const uint64_t p = mid == (int64_t)lb0[j] ? (uint64_t)ps0[j] : k4d_sa_at<EL>(ix, (uint64_t)mid);
           const K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p);
           n_probe++;
-          if (pr.exc) return K4_NEED_SLOW;
+          if (pr.exc) return K4_NEED_SLOW;  // (handling it here instead costs the hot path 8 % in registers: measured)
           if (pr.cmp > 0) lo = mid + 1;
           else {
             if (pr.cmp == 0) { found = mid; fpos = p; fmm = pr.mm; }
@@ -633,56 +633,83 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
 }
 
 // ==== general kernel =================================================================================================
+// One WAVE per read: the literal LocateCoreMultiples / AlignReads control flow (wave-uniform), with the two inner loops
+// of the reference -- the core comparison and the Hamming extension -- spread over the 64 lanes on exact 4-bit symbols.
+// It takes whatever the 2-bit fast path cannot decide: N in the read, windows touching N runs / separators, deep repeats
+// (more candidates than the fast path's dedupe list), reads longer than 512 bp.
 struct K4Slow {
-  uint8_t* probe;   // this lane's probe bytes (mutable: reverse-complemented in place like the reference)
-  uint64_t* hash;   // (generation << 32 | TargSeqID) open addressing
+  uint8_t* probe;   // LDS: the probe, reverse-complemented in place like the reference does
+  uint64_t* hash;   // HBM scratch of this wave: (generation << 32 | TargSeqID), open addressing
   uint32_t cap;     // power of two
   uint32_t gen;
+  int lane;
 };
 
-// CmpProbeTarg, SfxArray.cpp:2508-2525, on exact symbols
-K4_DEV int k4d_cmp_slow(const K4DevIndex& ix, const uint8_t* probe, uint64_t pos, int len) {
-  for (int j = 0; j < len; j++) {
-    uint32_t t = pos + j < ix.n ? k4d_ref_base(ix, pos + j) : 7u;
-    if (t == 7) return -1;
-    uint32_t p = probe[j] & 0x0f;
-    if (p > t) return 1;
-    if (p < t) return -1;
+// CmpProbeTarg (SfxArray.cpp:2508-2525): lanes compare 64 symbols at a time, the first differing / EOS position decides
+K4_DEV int k4d_cmp_wave(const K4DevIndex& ix, const K4Slow& sc, int o, uint64_t pos, int len) {
+  for (int j0 = 0; j0 < len; j0 += 64) {
+    const int j = j0 + sc.lane;
+    uint32_t t = 7, p = 0;
+    bool diff = false;
+    if (j < len) {
+      t = pos + j < ix.n ? k4d_ref_base(ix, pos + j) : 7u;
+      p = sc.probe[o + j] & 0x0f;
+      diff = t == 7 || p != t;
+    }
+    const unsigned long long m = __ballot(diff);
+    if (m) {
+      const int f = __ffsll((long long)m) - 1;
+      const uint32_t tf = __shfl(t, f, 64), pf = __shfl(p, f, 64);
+      if (tf == 7) return -1;
+      return pf > tf ? 1 : -1;
+    }
   }
   return 0;
 }
 
-K4_DEV void k4d_revcomp_slow(uint8_t* s, int len) {  // CSeqTrans::ReverseComplement, SeqTrans.cpp:497-545
-  for (int j = 0; j < len; j++) {
-    uint8_t b = s[j];
-    if (b <= 3) s[j] = 3 - b;
-    else if (b == 4 || b == 5 || b == 6) continue;
-    else break;
+K4_DEV void k4d_revcomp_wave(const K4Slow& sc, int len) {  // CSeqTrans::ReverseComplement, SeqTrans.cpp:497-545
+  // complement stops at the first symbol that is not a base / N / InDel / Undef (values > 6): reads hold 0..7 here
+  int stop = len;
+  for (int j0 = 0; j0 < len; j0 += 64) {
+    const int j = j0 + sc.lane;
+    const bool bad = j < len && (sc.probe[j] & 0x0f) > 6;
+    const unsigned long long m = __ballot(bad);
+    if (m) { stop = j0 + __ffsll((long long)m) - 1; break; }
   }
-  for (int x = 0, y = len - 1; x < y; x++, y--) { uint8_t t = s[x]; s[x] = s[y]; s[y] = t; }
+  for (int j = sc.lane; j < stop; j += 64) {
+    const uint8_t b = sc.probe[j];
+    if (b <= 3) sc.probe[j] = 3 - b;
+  }
+  __syncthreads();
+  for (int x = sc.lane; x < len / 2; x += 64) {
+    const uint8_t t = sc.probe[x];
+    sc.probe[x] = sc.probe[len - 1 - x];
+    sc.probe[len - 1 - x] = t;
+  }
+  __syncthreads();
 }
 
 // LocateFirstExact (SfxArray.cpp:7938-8058): index+1 of the lowest matching suffix or 0
 template <int EL>
-K4_DEV int64_t k4d_first_exact_slow(const K4DevIndex& ix, const uint8_t* core, int cl, uint32_t& n_probe) {
+K4_DEV int64_t k4d_first_exact_wave(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, uint32_t& n_probe) {
   int64_t lo = 0, hi = (int64_t)ix.n - 1;
-  int kk = min((int)ix.k, cl);
+  const int kk = min((int)ix.k, cl);
   bool acgt = true;
   uint64_t code = 0;
-  for (int j = 0; j < kk; j++) {
-    uint32_t b = core[j] & 0x0f;
+  for (int j = 0; j < kk; j++) {  // uniform: every lane reads the same LDS bytes
+    const uint32_t b = sc.probe[o + j] & 0x0f;
     if (b > 3) { acgt = false; break; }
     code = (code << 2) | b;
   }
   if (acgt) {
-    int sh = 2 * ((int)ix.k - kk);
+    const int sh = 2 * ((int)ix.k - kk);
     lo = (int64_t)k4d_ktab_lb(ix, code << sh);
     hi = (int64_t)k4d_ktab_lb(ix, (code + 1) << sh) - 1;
   }
   int64_t found = -1;
   while (lo <= hi) {
-    int64_t mid = (lo + hi) >> 1;
-    int c = k4d_cmp_slow(ix, core, k4d_sa_at<EL>(ix, (uint64_t)mid), cl);
+    const int64_t mid = (lo + hi) >> 1;
+    const int c = k4d_cmp_wave(ix, sc, o, k4d_sa_at<EL>(ix, (uint64_t)mid), cl);
     n_probe++;
     if (c > 0) lo = mid + 1;
     else {
@@ -693,15 +720,19 @@ K4_DEV int64_t k4d_first_exact_slow(const K4DevIndex& ix, const uint8_t* core, i
   return found == lo ? found + 1 : 0;
 }
 
-K4_DEV bool k4d_hash_insert(K4Slow& sc, uint32_t id) {  // true when id is new in this strand pass
-  uint64_t key = ((uint64_t)sc.gen << 32) | id;
-  uint32_t h = (id * 2654435761u) & (sc.cap - 1);
-  for (;;) {
-    uint64_t v = sc.hash[h];
-    if ((uint32_t)(v >> 32) != sc.gen) { sc.hash[h] = key; return true; }
-    if (v == key) return false;
-    h = (h + 1) & (sc.cap - 1);
+K4_DEV bool k4d_hash_insert_wave(K4Slow& sc, uint32_t id) {  // true when id is new in this strand pass (lane 0 works)
+  int isnew = 0;
+  if (sc.lane == 0) {
+    const uint64_t key = ((uint64_t)sc.gen << 32) | id;
+    uint32_t h = (id * 2654435761u) & (sc.cap - 1);
+    for (;;) {
+      const uint64_t v = sc.hash[h];
+      if ((uint32_t)(v >> 32) != sc.gen) { sc.hash[h] = key; isnew = 1; break; }
+      if (v == key) break;
+      h = (h + 1) & (sc.cap - 1);
+    }
   }
+  return __shfl(isnew, 0, 64) != 0;
 }
 
 template <int EL>
@@ -724,8 +755,9 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
   const int64_t n = (int64_t)ix.n;
   int strand = rp.strand;
   char cur_strand = '+';
-  uint8_t* probe = sc.probe;
-  if (strand == K4_STRAND_CRICK) { k4d_revcomp_slow(probe, len); cur_strand = '-'; }
+  // hits are stored by lane 0 only (every lane folds the same wave-uniform state)
+  k4_hit* hits_w = sc.lane == 0 ? hits : nullptr;
+  if (strand == K4_STRAND_CRICK) { k4d_revcomp_wave(sc, len); cur_strand = '-'; }
   do {
     int cur_delta = core_delta;
     int slides = 0;
@@ -737,7 +769,7 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
          slides++, o += cur_delta) {
       if (o + cl + cur_delta > len) cur_delta = len - (o + cl);
       n_lookup++;
-      int64_t t = k4d_first_exact_slow<EL>(ix, probe + o, cl, n_probe);
+      int64_t t = k4d_first_exact_wave<EL>(ix, sc, o, cl, n_probe);
       if (t == 0) continue;
       t -= 1;
       int iter = 0;
@@ -746,62 +778,74 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
         if (n_nodes >= node_cap) break;
         if (!first) {
           if (t + 1 >= n) break;
-          uint64_t p2 = k4d_sa_at<EL>(ix, (uint64_t)t + 1);
+          const uint64_t p2 = k4d_sa_at<EL>(ix, (uint64_t)t + 1);
           if ((int64_t)p2 + cl > n) break;
           n_probe++;
-          if (k4d_cmp_slow(ix, probe + o, p2, cl) != 0) break;
+          if (k4d_cmp_wave(ix, sc, o, p2, cl) != 0) break;
           t += 1;
         }
         first = false;
-        uint64_t pos = k4d_sa_at<EL>(ix, (uint64_t)t);
+        const uint64_t pos = k4d_sa_at<EL>(ix, (uint64_t)t);
         if (pos < (uint64_t)o) continue;
-        uint64_t left = pos - (uint64_t)o;
-        int e = k4d_map_entry(ix, left);
+        const uint64_t left = pos - (uint64_t)o;
+        const int e = k4d_map_entry(ix, left);
         if (e < 0 || left + (uint64_t)len - 1 > ix.ent_end[e]) continue;
-        uint32_t targ_id = (uint32_t)(1 + pos - (uint32_t)o);
-        if (!k4d_hash_insert(sc, targ_id)) continue;
+        const uint32_t targ_id = (uint32_t)(1 + pos - (uint32_t)o);
+        if (!k4d_hash_insert_wave(sc, targ_id)) continue;
         n_nodes++;
         iter++;
         n_cand++;
-        int mm = 0, j;
-        for (j = 0; j < len; j++) {  // :6200-6261
-          uint32_t tv = k4d_ref_base(ix, left + j), pv = probe[j] & 0x0f;
-          if (tv == 7) break;
-          if (pv == tv) continue;
-          if (++mm > allow_mm) break;
-          if (mm >= st.nxt) break;
+        // extension (:6200-6261): the scalar loop stops at a target EOS or once the count passes MaxTotMM / reaches
+        // NxtLowMMCnt; it is accepted iff it runs to the end, i.e. no EOS, count <= MaxTotMM and count < NxtLowMMCnt
+        int mm = 0;
+        bool eos = false;
+        for (int j0 = 0; j0 < len && !eos && mm <= allow_mm && mm < st.nxt; j0 += 64) {
+          const int j = j0 + sc.lane;
+          bool d = false, z = false;
+          if (j < len) {
+            const uint32_t tv = k4d_ref_base(ix, left + j);
+            z = tv == 7;
+            d = tv != (uint32_t)(sc.probe[j] & 0x0f);
+          }
+          eos = __ballot(z) != 0;
+          mm += (int)__popcll(__ballot(d));
         }
-        if (j != len) continue;
-        k4d_fold(st, mm, hits, rp.max_hits, ix.ent_id[e], (uint32_t)(left - ix.ent_start[e]), len, cur_strand);
+        if (eos || mm > allow_mm || mm >= st.nxt) continue;
+        k4d_fold(st, mm, hits_w, rp.max_hits, ix.ent_id[e], (uint32_t)(left - ix.ent_start[e]), len, cur_strand);
         if (st.inst > rp.max_hits && st.low == 0) break;
       }
       if (st.inst > rp.max_hits && st.low == 0) { strand = 3; break; }
     }
     if (cur_strand == '+' && strand == K4_STRAND_BOTH) {
-      k4d_revcomp_slow(probe, len);
+      k4d_revcomp_wave(sc, len);
       cur_strand = '-';
       strand = K4_STRAND_CRICK;
     } else
       strand = 3;
   } while (!(st.inst > rp.max_hits && st.low == 0) && strand != 3);
-  if (cur_strand == '-') k4d_revcomp_slow(probe, len);
+  if (cur_strand == '-') k4d_revcomp_wave(sc, len);
   return k4d_lcm_result(*p_inst, *p_low, p_nxt, st, rp.mm_delta, rp.max_hits, p_inst, p_low);
 }
 
-// persistent lanes pull read ids from the slow list until it is drained (every lane reaches the exit test)
+// persistent waves pull read ids from the slow list until it is drained (every wave reaches the exit test)
 template <int EL>
-__global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_lanes) {
-  const uint32_t lane = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_waves) {
+  __shared__ uint8_t probe_s[K4_MAX_READ_LEN + 64];
+  const uint32_t wave = blockIdx.x;
+  const int lane = threadIdx.x;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0;
-  if (lane < n_lanes) {
+  if (wave < n_waves) {
     K4Slow sc;
-    sc.probe = a.slow_probe + (size_t)lane * K4_MAX_READ_LEN;
-    sc.hash = a.slow_hash + (size_t)lane * a.slow_hash_cap;
+    sc.probe = probe_s;
+    sc.hash = a.slow_hash + (size_t)wave * a.slow_hash_cap;
     sc.cap = a.slow_hash_cap;
-    sc.gen = a.slow_gen[lane];
+    sc.gen = a.slow_gen[wave];
+    sc.lane = lane;
     const uint32_t total = a.ctl[0];
     for (;;) {
-      uint32_t q = atomicAdd(&a.ctl[1], 1u);
+      uint32_t q = 0;
+      if (lane == 0) q = atomicAdd(&a.ctl[1], 1u);
+      q = __shfl(q, 0, 64);
       if (q >= total) break;
       const int64_t i = a.slow_list[q];
       const int from_phase = a.slow_step[q];
@@ -812,11 +856,13 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_l
       k4_hit* hits = a.hits + i * a.max_hits;
       int inst = 0, low = 0, nxt = 0, rslt = 0, allow = 0;
       if (len < 1 || len > K4_MAX_READ_LEN || rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits) {
-        k4d_finalize(a, i, len, rp, a.mode == 0 ? K4_ERR_PARAMS : K4_HR_FATAL, 0, 0, 0);
+        if (lane == 0) k4d_finalize(a, i, len, rp, a.mode == 0 ? K4_ERR_PARAMS : K4_HR_FATAL, 0, 0, 0);
         continue;
       }
       const uint8_t* src = a.reads + a.offs[i];
-      for (int j = 0; j < len; j++) sc.probe[j] = src[j] & 7;
+      __syncthreads();
+      for (int j = lane; j < len; j += 64) probe_s[j] = src[j] & 7;
+      __syncthreads();
       if (rp.tot_mm > 0) {
         for (allow = 0; allow <= rp.tot_mm; allow++) {
           int cl = len / (allow + rp.mm_delta);
@@ -833,15 +879,14 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_l
                                 n_lookup, n_probe, n_cand);
         if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }
       }
-      k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
+      if (lane == 0) k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
     }
-    a.slow_gen[lane] = sc.gen;
+    if (lane == 0) a.slow_gen[wave] = sc.gen;
   }
-  unsigned long long v[3] = {n_lookup, n_probe, n_cand};
-  for (int q = 0; q < 3; q++) {
-    unsigned long long x = v[q];
-    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-    if (threadIdx.x == 0 && x) atomicAdd(&a.counters[1 + q], x);
+  if (lane == 0) {  // the tallies are wave-uniform
+    if (n_lookup) atomicAdd(&a.counters[1], (unsigned long long)n_lookup);
+    if (n_probe) atomicAdd(&a.counters[2], (unsigned long long)n_probe);
+    if (n_cand) atomicAdd(&a.counters[3], (unsigned long long)n_cand);
   }
 }
 
@@ -969,7 +1014,7 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
     default: rc = launch_steps<EL, 16, KT>(ix, a, n_steps, st); break;
   }
   if (rc != K4_OK) return rc;
-  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3((w.slow_lanes + 63) / 64), dim3(64), 0, st, a, w.slow_lanes);
+  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(w.slow_lanes), dim3(64), 0, st, a, w.slow_lanes);
   K4_HIP(ix, hipGetLastError());
   return K4_OK;
 }
