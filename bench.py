@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--max-subs", type=int, default=2)
     ap.add_argument("--kmer-k", type=int, default=0)
+    ap.add_argument("--n-frac", type=float, default=0.0, help="fraction of reads given one N (general-kernel stress; not the BASELINE workload)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="upper bound on reads timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -143,6 +144,12 @@ def main():
     t0 = time.time()
     n_reads = args.reads
     reads, truth = make_reads(seq, n_chrom, chrom_len, n_reads, L, READS_SEED + rank, dev)
+    if args.n_frac > 0:
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(7)
+        sel = torch.nonzero(torch.rand(n_reads, device=dev, generator=g2) < args.n_frac).flatten()
+        reads[sel, torch.randint(0, L, (sel.numel(),), device=dev, generator=g2)] = 4
+        truth[sel, 3] = 99  # excluded from the truth property below
     offs = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
     lens = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
     out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
@@ -198,12 +205,12 @@ def main():
     h_loci = hits[:, 1].to(torch.int64) & 0xFFFFFFFF
     h_strand = hv[:, 10].to(torch.int64)
     h_mm = hv[:, 11].to(torch.int64)
-    good = torch.where(
+    good = torch.where(truth[:, 3] == 99, torch.ones_like(ok), torch.where(
         ok,
         (out[:, 4] == k4.NAR_ACCEPTED) & (h_chrom == truth[:, 0]) & (h_loci == truth[:, 1]) & (h_mm == truth[:, 3])
         & ((h_strand == ord("-")) == (truth[:, 2] == 1)),
         out[:, 4] == k4.NAR_NOHIT,
-    )
+    ))
     truth_viol = int((~good).sum().item())
 
     # (2) CPU baseline = the oracle on all host cores over a bounded sample, same index, same reads (rank 0, N=1 only)
@@ -274,7 +281,8 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        full = (n_chrom == 24 and chrom_len == 125_000_000 and n_reads == 50_000_000 and L == 100 and args.max_subs == 2)
+        full = (n_chrom == 24 and chrom_len == 125_000_000 and n_reads == 50_000_000 and L == 100 and args.max_subs == 2
+                and args.n_frac == 0)
         line = {
             "metric": "Mreads/sec aligned (100 bp SE vs 3 Gbp .sfx)",
             "value": value,

@@ -35,6 +35,10 @@
 #ifndef K4_PF
 #define K4_PF 4  // k-mer table entries fetched ahead per strand pass
 #endif
+#define K4_SLOW_WAVES 8192  // pass 0 of the general kernel: 32 waves per CU
+#define K4_SMALL_HASH 4096  // entries of a pass-0 dedupe table (2047 candidates per strand pass)
+#define K4_HUGE_WAVES 256
+#define K4_CTL_HUGE 68  // ctl[68] huge count, ctl[69] huge head
 #define K4_CTL_WORDS 72  // [0] slow count, [1] slow head, [2+t] survivors of step t
 
 struct K4AlignArgs {
@@ -55,6 +59,8 @@ struct K4AlignArgs {
   int32_t max_hits;
   uint32_t* slow_list;
   uint8_t* slow_step;  // phase ordinal at which the read left the fast path (its earlier phases are already tallied)
+  uint32_t* huge_list; // reads whose strand pass outgrew the small dedupe tables: second general pass with big tables
+  uint8_t* huge_step;
   uint32_t* ctl;
   unsigned long long* counters;
   uint8_t* slow_probe;
@@ -643,6 +649,7 @@ struct K4Slow {
   uint32_t cap;     // power of two
   uint32_t gen;
   int lane;
+  bool small;       // first general pass: small tables, overflow defers the read to the pass with big tables
 };
 
 // CmpProbeTarg (SfxArray.cpp:2508-2525): lanes compare 64 symbols at a time, the first differing / EOS position decides
@@ -763,7 +770,8 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
     int slides = 0;
     uint32_t n_nodes = 0;
     sc.gen++;
-    // cMaxNumIdentNodes (SfxArray.h:15); additionally bounded by the scratch table so an insert always terminates
+    // cMaxNumIdentNodes (SfxArray.h:15); additionally bounded by the scratch table so an insert always terminates.
+    // A pass that fills a small table before the reference's own limit is redone with a big one (K4_NEED_SLOW).
     const uint32_t node_cap = min((uint32_t)K4_MAX_IDENT_NODES, sc.cap / 2 - 1);
     for (int o = 0; slides < rp.max_slides && o <= len - cl && cur_delta > cl / 3 && n_nodes < node_cap;
          slides++, o += cur_delta) {
@@ -793,6 +801,10 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
         const uint32_t targ_id = (uint32_t)(1 + pos - (uint32_t)o);
         if (!k4d_hash_insert_wave(sc, targ_id)) continue;
         n_nodes++;
+        if (n_nodes >= node_cap && node_cap < (uint32_t)K4_MAX_IDENT_NODES && sc.small) {
+          if (cur_strand == '-') k4d_revcomp_wave(sc, len);
+          return K4_NEED_SLOW;
+        }
         iter++;
         n_cand++;
         // extension (:6200-6261): the scalar loop stops at a target EOS or once the count passes MaxTotMM / reaches
@@ -827,9 +839,12 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
   return k4d_lcm_result(*p_inst, *p_low, p_nxt, st, rp.mm_delta, rp.max_hits, p_inst, p_low);
 }
 
-// persistent waves pull read ids from the slow list until it is drained (every wave reaches the exit test)
+// persistent waves pull read ids from their list until it is drained (every wave reaches the exit test).
+// pass 0: many waves with small dedupe tables (list = slow_list, ctl[0]/[1]); pass 1: few waves with tables sized for
+// the reference's own limits (list = huge_list, ctl[K4_CTL_HUGE]/[+1]).
 template <int EL>
-__global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_waves) {
+__global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_waves, int pass, uint64_t* hash_base,
+                                                     uint32_t hash_cap, uint32_t* gen_base) {
   __shared__ uint8_t probe_s[K4_MAX_READ_LEN + 64];
   const uint32_t wave = blockIdx.x;
   const int lane = threadIdx.x;
@@ -837,20 +852,25 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
   if (wave < n_waves) {
     K4Slow sc;
     sc.probe = probe_s;
-    sc.hash = a.slow_hash + (size_t)wave * a.slow_hash_cap;
-    sc.cap = a.slow_hash_cap;
-    sc.gen = a.slow_gen[wave];
+    sc.hash = hash_base + (size_t)wave * hash_cap;
+    sc.cap = hash_cap;
+    sc.gen = gen_base[wave];
     sc.lane = lane;
-    const uint32_t total = a.ctl[0];
+    sc.small = pass == 0;
+    const uint32_t* list = pass == 0 ? a.slow_list : a.huge_list;
+    const uint8_t* steps = pass == 0 ? a.slow_step : a.huge_step;
+    uint32_t* cnt = a.ctl + (pass == 0 ? 0 : K4_CTL_HUGE);
+    const uint32_t total = cnt[0];
     for (;;) {
       uint32_t q = 0;
-      if (lane == 0) q = atomicAdd(&a.ctl[1], 1u);
+      if (lane == 0) q = atomicAdd(&cnt[1], 1u);
       q = __shfl(q, 0, 64);
       if (q >= total) break;
-      const int64_t i = a.slow_list[q];
-      const int from_phase = a.slow_step[q];
+      const int64_t i = list[q];
+      const int from_phase = steps[q];
       int phase = 0;
-      uint32_t t0, t1, t2;
+      uint32_t t0 = n_lookup, t1 = n_probe, t2 = n_cand;
+      const uint32_t r0 = n_lookup, r1 = n_probe, r2 = n_cand;
       const int len = (int)a.lens[i];
       const K4ReadParams rp = k4d_read_params(a, len);
       k4_hit* hits = a.hits + i * a.max_hits;
@@ -879,9 +899,18 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
                                 n_lookup, n_probe, n_cand);
         if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }
       }
+      if (rslt == K4_NEED_SLOW) {  // outgrew the small table: the big-table pass redoes the read (and tallies it)
+        n_lookup = r0; n_probe = r1; n_cand = r2;
+        if (lane == 0) {
+          const uint32_t slot = atomicAdd(&a.ctl[K4_CTL_HUGE], 1u);
+          a.huge_list[slot] = (uint32_t)i;
+          a.huge_step[slot] = (uint8_t)from_phase;
+        }
+        continue;
+      }
       if (lane == 0) k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
     }
-    if (lane == 0) a.slow_gen[wave] = sc.gen;
+    if (lane == 0) gen_base[wave] = sc.gen;
   }
   if (lane == 0) {  // the tallies are wave-uniform
     if (n_lookup) atomicAdd(&a.counters[1], (unsigned long long)n_lookup);
@@ -916,9 +945,11 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
     cap = (cap + 255) / 256 * 256;
     int len = std::max(fast_len, w.cap_len);
     int nch = nch_for(len);
-    for (void* q : {(void*)w.ids[0], (void*)w.ids[1], (void*)w.rows[0], (void*)w.rows[1], (void*)w.slow_list, (void*)w.slow_step})
+    for (void* q : {(void*)w.ids[0], (void*)w.ids[1], (void*)w.rows[0], (void*)w.rows[1], (void*)w.slow_list, (void*)w.slow_step,
+                    (void*)w.huge_list, (void*)w.huge_step})
       if (q) hipFree(q);
     w.ids[0] = w.ids[1] = nullptr; w.rows[0] = w.rows[1] = nullptr; w.slow_list = nullptr; w.slow_step = nullptr;
+    w.huge_list = nullptr; w.huge_step = nullptr;
     // survivors of step t (ids + packed rows, 2*nch words each) ping-pong between two buffers
     // every wave of the (at most 2048-block) grid may leave one partly used chunk behind
     const size_t slots = (size_t)cap + (size_t)2048 * 4 * K4_CHUNK;
@@ -928,6 +959,8 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
     }
     K4_HIP(ix, hipMalloc(&w.slow_list, (size_t)cap * 4));
     K4_HIP(ix, hipMalloc(&w.slow_step, (size_t)cap));
+    K4_HIP(ix, hipMalloc(&w.huge_list, (size_t)cap * 4));
+    K4_HIP(ix, hipMalloc(&w.huge_step, (size_t)cap));
     w.cap_reads = cap;
     w.cap_len = len;
   }
@@ -935,18 +968,19 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
     K4_HIP(ix, hipMalloc(&w.ctl, K4_CTL_WORDS * 4));
     K4_HIP(ix, hipMemset(w.ctl, 0, K4_CTL_WORDS * 4));
   }
-  // general-kernel scratch: sized from MaxIter (hash holds one strand pass: <= MaxIter per core, <= 1,024,000 nodes)
+  // general-kernel scratch.  Pass 0: K4_SLOW_WAVES waves with small dedupe tables; pass 1: K4_HUGE_WAVES waves whose
+  // tables hold one strand pass at the reference's own limits (<= MaxIter per core, <= 1,024,000 nodes, SfxArray.h:15)
   uint64_t nodes = ix->d.max_iter ? std::min<uint64_t>((uint64_t)ix->d.max_iter * 48, K4_MAX_IDENT_NODES) : K4_MAX_IDENT_NODES;
   uint32_t hcap = next_pow2(std::max<uint64_t>(2 * nodes + 2, 1024));
   if (!w.slow_hash || hcap > w.slow_hash_cap) {
     if (w.slow_hash) hipFree(w.slow_hash);
-    if (w.slow_probe) hipFree(w.slow_probe);
-    w.slow_hash = nullptr; w.slow_probe = nullptr;
-    w.slow_lanes = hcap > (1u << 19) ? 256 : 1024;
-    K4_HIP(ix, hipMalloc(&w.slow_hash, (size_t)w.slow_lanes * hcap * 8 + (size_t)w.slow_lanes * 4));
-    K4_HIP(ix, hipMemset(w.slow_hash, 0, (size_t)w.slow_lanes * hcap * 8 + (size_t)w.slow_lanes * 4));
-    K4_HIP(ix, hipMalloc(&w.slow_probe, (size_t)w.slow_lanes * K4_MAX_READ_LEN));
+    w.slow_hash = nullptr;
+    const size_t words = (size_t)K4_SLOW_WAVES * K4_SMALL_HASH + (size_t)K4_HUGE_WAVES * hcap;
+    const size_t bytes = words * 8 + (size_t)(K4_SLOW_WAVES + K4_HUGE_WAVES) * 4;
+    K4_HIP(ix, hipMalloc(&w.slow_hash, bytes));
+    K4_HIP(ix, hipMemset(w.slow_hash, 0, bytes));
     w.slow_hash_cap = hcap;
+    w.slow_lanes = K4_SLOW_WAVES;
   }
   w.cap_hits = std::max(w.cap_hits, max_hits);
   return K4_OK;
@@ -999,10 +1033,16 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
   a.slow_step = w.slow_step;
   a.ctl = w.ctl;
   a.counters = (unsigned long long*)ix->counters;
-  a.slow_probe = w.slow_probe;
+  a.huge_list = w.huge_list;
+  a.huge_step = w.huge_step;
+  a.slow_probe = nullptr;
   a.slow_hash = w.slow_hash;
-  a.slow_gen = reinterpret_cast<uint32_t*>(w.slow_hash + (size_t)w.slow_lanes * w.slow_hash_cap);
   a.slow_hash_cap = w.slow_hash_cap;
+  uint64_t* small_base = w.slow_hash;
+  uint64_t* big_base = w.slow_hash + (size_t)K4_SLOW_WAVES * K4_SMALL_HASH;
+  uint32_t* gen_small = reinterpret_cast<uint32_t*>(big_base + (size_t)K4_HUGE_WAVES * w.slow_hash_cap);
+  uint32_t* gen_big = gen_small + K4_SLOW_WAVES;
+  a.slow_gen = gen_small;
   a.nw = nch + 1;
   if (a.n_reads == 0) return K4_OK;
   K4_HIP(ix, hipMemsetAsync(w.ctl, 0, K4_CTL_WORDS * 4, st));
@@ -1014,7 +1054,10 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
     default: rc = launch_steps<EL, 16, KT>(ix, a, n_steps, st); break;
   }
   if (rc != K4_OK) return rc;
-  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(w.slow_lanes), dim3(64), 0, st, a, w.slow_lanes);
+  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(K4_SLOW_WAVES), dim3(64), 0, st, a, (uint32_t)K4_SLOW_WAVES, 0, small_base,
+                     (uint32_t)K4_SMALL_HASH, gen_small);
+  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(K4_HUGE_WAVES), dim3(64), 0, st, a, (uint32_t)K4_HUGE_WAVES, 1, big_base,
+                     w.slow_hash_cap, gen_big);
   K4_HIP(ix, hipGetLastError());
   return K4_OK;
 }

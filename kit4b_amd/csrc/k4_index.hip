@@ -546,7 +546,7 @@ extern "C" void k4_close(k4_index* ix) {
   hipSetDevice(ix->device);
   K4Workspace& w = ix->ws;
   void* ptrs[] = {ix->ref2_alloc, ix->excbm, ix->excsup, ix->excblk, ix->excnib, ix->owns_sa ? ix->sa : nullptr, ix->ktab,
-                  ix->ent_start, ix->ent_end, ix->ent_id, ix->counters, w.ids[0], w.ids[1], w.rows[0], w.rows[1], w.slow_list, w.slow_step, w.ctl,
+                  ix->ent_start, ix->ent_end, ix->ent_id, ix->counters, w.ids[0], w.ids[1], w.rows[0], w.rows[1], w.slow_list, w.slow_step, w.huge_list, w.huge_step, w.ctl,
                   w.slow_probe, w.slow_hash, w.d_reads, w.d_offs, w.d_lens, w.d_out4, w.d_hits};
   for (void* p : ptrs)
     if (p) hipFree(p);

@@ -63,6 +63,8 @@ struct K4Workspace {
   uint64_t* rows[2] = {nullptr, nullptr};  // ... and their packed rows (forward + reverse-complement words)
   uint32_t* slow_list = nullptr; // read ids for the general kernel
   uint8_t* slow_step = nullptr;  // and the phase ordinal at which each left the fast path
+  uint32_t* huge_list = nullptr; // reads that outgrew the small dedupe tables of the first general pass
+  uint8_t* huge_step = nullptr;
   uint32_t* ctl = nullptr;       // [0] slow count, [1] slow head, [2+t] survivor count of step t
   uint8_t* slow_probe = nullptr; // per slow lane: probe bytes scratch
   uint64_t* slow_hash = nullptr; // per slow lane: open-addressing table of (generation<<32 | TargSeqID)

@@ -334,3 +334,42 @@ def test_csfxarray_facade_program(k4, golden_dir):
             n += 1
     assert n == 16
     assert lines[-1] == "chimeric rslt -3 msgs 1"
+
+
+def test_deep_repeats_vs_oracle(k4, oracle):
+    """Thousands of candidates per core (long tandem arrays): exercises MaxIter, the dedupe set beyond the fast path's
+    list, the small-table overflow of the general kernel and its big-table second pass."""
+    rng = np.random.default_rng(77)
+    c1 = rng.integers(0, 4, size=120000, dtype=np.uint8)
+    c1[20000:27000] = np.resize(np.array([0, 2], np.uint8), 7000)           # (AG)n, 7 kb
+    c1[60000:66000] = np.resize(np.array([1, 1, 3, 0, 2], np.uint8), 6000)  # 5-mer array, 6 kb
+    c1[90000:94000] = 0                                                      # poly-A, 4 kb
+    c2 = rng.integers(0, 4, size=50000, dtype=np.uint8)
+    c2[10000:13000] = np.resize(np.array([0, 2], np.uint8), 3000)
+    names, chroms = ["chr1", "chr2"], [c1, c2]
+    ho = oracle.build(names, chroms, threads=8)
+    n = oracle.concat_len(ho)
+    import ctypes as C
+
+    sa_raw = np.ctypeslib.as_array(C.cast(oracle.L.k4o_sa_bytes(ho), C.POINTER(C.c_uint8)), shape=(n * 4,))
+    ix = k4.SfxIndex.from_host(np.array(oracle.seq(ho)), sa_raw, 4, k4.make_entries(names, [len(c) for c in chroms]))
+    try:
+        reads = []
+        for start in list(range(19950, 27050, 37)) + list(range(59960, 66040, 41)) + list(range(89950, 94050, 53)):
+            r = c1[start:start + 100].copy()
+            if start % 3 == 0:
+                r[50] = (r[50] + 1) % 4
+            reads.append(r if start % 2 else synth.revcomp(r))
+        r2, _ = synth.make_reads(chroms, 300, 100, seed=5)
+        reads += r2
+        for max_iter in (5000, 50, 20000):
+            oracle.set_max_iter(ho, max_iter)
+            ix.set_max_iter(max_iter)
+            for (tm, cl, cd, sl, mh) in [(2, 33, 33, 8, 1), (3, 25, 25, 8, 10)]:
+                ro = oracle.align_reads_batch(ho, reads, tm, cl, cd, sl, 0, 1, 0, mh, threads=8)
+                rg = ix.align_reads_batch(reads, tm, cl, cd, sl, 0, 1, 0, mh)
+                check_against(rg, ro, mh, "deep repeats maxiter %d" % max_iter)
+            assert ro["inst"].max() > 1000 or max_iter == 50
+    finally:
+        ix.close()
+        oracle.close(ho)
