@@ -321,7 +321,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       uint32_t touch = 0;
 #pragma unroll
       for (int j = 0; j < K4_PF; j++)
-        if (j < cnt && lb1[j] > lb0[j]) touch |= ix.ref2[((int64_t)ps0[j] - oo[j]) >> 4];
+        if (j < cnt && tshift == 0 && lb1[j] > lb0[j]) touch |= ix.ref2[((int64_t)ps0[j] - oo[j]) >> 4];
 
 #pragma unroll
       for (int j = 0; j < K4_PF; j++) {
@@ -337,7 +337,9 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
         int fmm = 0;
         while (lo <= hi) {
           const int64_t mid = (lo + hi) >> 1;
-          const uint64_t p = mid == (int64_t)lb0[j] ? (uint64_t)ps0[j] : k4d_sa_at<EL>(ix, (uint64_t)mid);
+          // pos0 belongs to the bucket of the exact k-mer: with a core shorter than k the interval spans several
+          // buckets and the first of them may be empty (pos0 unset), so the suffix array is read instead
+          const uint64_t p = (tshift == 0 && mid == (int64_t)lb0[j]) ? (uint64_t)ps0[j] : k4d_sa_at<EL>(ix, (uint64_t)mid);
           const K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p);
           n_probe++;
           if (pr.exc) return K4_NEED_SLOW;  // (handling it here instead costs the hot path 8 % in registers: measured)

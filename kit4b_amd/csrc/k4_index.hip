@@ -114,34 +114,33 @@ __global__ void __launch_bounds__(256) k4k_exc_nibbles(const uint8_t* __restrict
 }
 
 // ---- kernels: k-mer table -----------------------------------------------------------------------------------
-// code of the first k bases of the suffix at pos (first base most significant); false when they hold N/EOS.
-K4_DEV bool k4d_kmer_code(const K4DevIndex& ix, uint64_t pos, uint32_t k, uint64_t* code) {
-  if (pos + k > ix.n) return false;  // would run into (at least) the final EOS
-  if (k4d_any_exc(ix, (int64_t)pos, (int64_t)pos + k)) {
-    uint64_t c = 0;
-    for (uint32_t j = 0; j < k; j++) {
-      uint32_t s = k4d_ref_base(ix, pos + j);
-      if (s > 3) return false;
-      c = (c << 2) | s;
-    }
-    *code = c;
-    return true;
+// "Ceiling" of the suffix at pos among the k-mers: the smallest k-mer code whose k-mer sorts strictly after the suffix
+// (A<C<G<T<N<EOS).  A suffix whose first k symbols are ACGT with code c has ceiling c + 1; one that meets N / EOS (or
+// the end of the block) after j clean symbols with prefix code P is greater than every k-mer starting with P, so its
+// ceiling is (P + 1) << 2(k - j).  lb[c] = number of suffixes with ceiling <= c, exact for every code, which is what makes
+// prefix ranges of the table (cores shorter than k) an exact statement of "all suffixes that start with the core".
+K4_DEV uint64_t k4d_kmer_ceiling(const K4DevIndex& ix, uint64_t pos, uint32_t k) {
+  if (pos + k <= ix.n && !k4d_any_exc(ix, (int64_t)pos, (int64_t)pos + k))
+    return (k4d_ref_chunk(ix, (int64_t)pos) >> (64 - 2 * k)) + 1;
+  uint64_t c = 0;
+  for (uint32_t j = 0; j < k; j++) {
+    const uint32_t s = pos + j < ix.n ? k4d_ref_base(ix, pos + j) : 7u;
+    if (s > 3) return (c + 1) << (2 * (k - j));
+    c = (c << 2) | s;
   }
-  *code = k4d_ref_chunk(ix, (int64_t)pos) >> (64 - 2 * k);
-  return true;
+  return c + 1;
 }
 
 template <int EL, typename T>
 __global__ void __launch_bounds__(256) k4k_ktab_mark(K4DevIndex ix, T* __restrict__ tab) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= ix.n) return;
-  uint64_t c, cp = 0;
-  bool v = k4d_kmer_code(ix, k4d_sa_at<EL>(ix, i), ix.k, &c);  // (the entry's pos0 field is re-read below: rare path)
-  if (!v) return;
-  bool vp = i > 0 && k4d_kmer_code(ix, k4d_sa_at<EL>(ix, i - 1), ix.k, &cp);
-  if (!vp || cp != c) {  // first suffix of the run of k-mer c
+  const uint64_t pos = k4d_sa_at<EL>(ix, i);
+  const uint64_t cc = k4d_kmer_ceiling(ix, pos, ix.k);
+  const uint64_t cp = i > 0 ? k4d_kmer_ceiling(ix, k4d_sa_at<EL>(ix, i - 1), ix.k) : 0;
+  if (cc != cp) {  // first suffix with this ceiling: every code in [cp, cc) has lb = i; the min-scan fills downwards
     constexpr int ST = sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64;
-    const uint64_t pos = k4d_sa_at<EL>(ix, i);
+    const uint64_t c = cc - 1;
     tab[ST * c] = (T)i;
     tab[ST * c + 1] = (T)pos;
     if (sizeof(T) == 4) tab[ST * c + 2] = (T)(k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 32);  // the next 16 bases

@@ -336,6 +336,27 @@ def test_csfxarray_facade_program(k4, golden_dir):
     assert lines[-1] == "chimeric rslt -3 msgs 1"
 
 
+def test_cores_shorter_than_the_kmer_table(k4, oracle, golden_dir):
+    """Cores shorter than k use a prefix range of the table (several buckets, the first possibly empty)."""
+    names, chroms = synth.golden_genome()
+    ho = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    oracle.set_max_iter(ho, 5000)
+    reads, _ = synth.make_reads(chroms[:3], 1500, 40, seed=3, sub_lambda=1.0, edge_frac=0.1)
+    r15, _ = synth.make_reads(chroms[:3], 300, 15, seed=4, sub_lambda=0.3)
+    for kmer_k in (12, 14):
+        ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"), kmer_k=kmer_k)
+        ix.set_max_iter(5000)
+        for rd, (tm, cl, cd, sl, mh) in ((reads, (3, 8, 8, 4, 2)), (reads, (2, 10, 5, 6, 1)), (r15, (1, 6, 6, 2, 3))):
+            ro = oracle.align_reads_batch(ho, rd, tm, cl, cd, sl, 0, 1, 0, mh, threads=8)
+            rg = ix.align_reads_batch(rd, tm, cl, cd, sl, 0, 1, 0, mh)
+            check_against(rg, ro, mh, "k=%d cl=%d" % (kmer_k, cl))
+        eo = oracle.kalign_batch(ho, r15, max_subs=2, threads=8)
+        eg = ix.kalign_batch(r15, max_subs=2)
+        assert np.array_equal(eo["out"], eg["out"])
+        ix.close()
+    oracle.close(ho)
+
+
 def test_deep_repeats_vs_oracle(k4, oracle):
     """Thousands of candidates per core (long tandem arrays): exercises MaxIter, the dedupe set beyond the fast path's
     list, the small-table overflow of the general kernel and its big-table second pass."""
@@ -373,3 +394,33 @@ def test_deep_repeats_vs_oracle(k4, oracle):
     finally:
         ix.close()
         oracle.close(ho)
+
+
+def test_long_and_ragged_reads_vs_oracle(k4, oracle, golden_dir):
+    """Read lengths from 15 to 2000 bp in one batch: the 4/5/8/16-chunk fast kernels, the > 512 bp general path and
+    reads too short for any core, at both the AlignReads and the AlignRead level."""
+    names, chroms = synth.golden_genome()
+    ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    ho = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    ix.set_max_iter(5000)
+    oracle.set_max_iter(ho, 5000)
+    reads = []
+    for rl, nr in ((15, 20), (24, 30), (49, 50), (129, 200), (161, 200), (257, 150), (400, 100), (513, 60), (900, 40),
+                   (2000, 20)):
+        r, _ = synth.make_reads(chroms[:3], nr, rl, seed=rl, sub_lambda=max(1.0, rl / 80.0), n_prob=0.05, edge_frac=0.1)
+        reads += r
+    for kw in (dict(max_subs=2), dict(max_subs=5, max_ml=10, pe_mode=1)):
+        eo = oracle.kalign_batch(ho, reads, threads=8, **kw)
+        eg = ix.kalign_batch(reads, **kw)
+        assert np.array_equal(eo["out"], eg["out"]), np.nonzero(eo["out"] != eg["out"])[0][:5]
+        mh = kw.get("max_ml", 1)
+        for i in range(len(reads)):
+            r = eo["out"][i]
+            nh = min(int(r["inst"]), mh) if r["hit_rslt"] in (1, 2, 3) else 0
+            assert np.array_equal(eo["hits"][i, :nh], eg["hits"][i, :nh]), i
+    ro = oracle.align_reads_batch(ho, reads, 4, 20, 20, 30, 0, 1, 0, 3, threads=8)
+    rg = ix.align_reads_batch(reads, 4, 20, 20, 30, 0, 1, 0, 3)
+    check_against(rg, ro, 3, "ragged raw")
+    assert ix.counters()["n_slow"] > 0
+    ix.close()
+    oracle.close(ho)
