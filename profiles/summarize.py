@@ -1,0 +1,56 @@
+"""Summarise a gpurun_out/prof_<tag> directory written by profiles/run_profile_pmc.sh into profiles/<tag>/ and refresh
+profiles/r01_pmc_hbm.json (the `traffic` figure bench.py reports).
+
+HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are KB from separate --pmc passes;
+on gfx950 FETCH_SIZE tallies 64 B per 128-B request (calibrated in this run on tools/randgather: one TCC_EA0_RDREQ and
+64 B of FETCH_SIZE per random 4-byte touch, 1.27 requests per unaligned 36-byte window), so the read side is doubled.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", "prof_" + tag)
+dst = os.path.join("profiles", tag)
+os.makedirs(dst, exist_ok=True)
+shutil.copy(glob.glob(os.path.join(src, "trace", "runc", "*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
+for f in ("bench_trace.json", "randgather_pmc.txt"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+out = {}
+for kind in ("pmc_sq", "pmc_tcc", "pmc_fetch", "pmc_write", "cal_fetch", "cal_tcc"):
+    fs = glob.glob(os.path.join(src, kind, "runc", "*_counter_collection.csv"))
+    if not fs:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"]
+        if "k4k_align" in k or "k_indep" in k or "k_chain" in k:
+            agg[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out[kind] = {n: {c: {"dispatches": len(v), "avg": sum(v) / len(v)} for c, v in cs.items()} for n, cs in agg.items()}
+json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+
+
+def per_batch(kind, counter):
+    tot = 0.0
+    for name, cs in out.get(kind, {}).items():
+        if "k4k_align_step" not in name:
+            continue
+        v = cs[counter]
+        # the PMC benches run 2 steps: FIRST variant is dispatched once per batch, the other variant (phases-1) times
+        tot += v["avg"] * (v["dispatches"] / 2.0)
+    return tot
+
+
+fetch_kb, write_kb = per_batch("pmc_fetch", "FETCH_SIZE"), per_batch("pmc_write", "WRITE_SIZE")
+rdreq = per_batch("pmc_tcc", "TCC_EA0_RDREQ_sum")
+hbm = {"tag": tag, "kernel": "k4k_align_step (all phases of one 50 M-read batch)",
+       "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_EA0_RDREQ": rdreq,
+       "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+       "note": "read side doubled per MI355X_MICROARCH.md (FETCH_SIZE tallies 64 B per 128-B request on gfx950)"}
+json.dump(hbm, open(os.path.join("profiles", "r01_pmc_hbm.json"), "w"), indent=1)
+print(json.dumps(hbm, indent=1))
