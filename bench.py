@@ -128,14 +128,15 @@ def main():
     torch.cuda.synchronize()
     log(rank, "genome %d x %d bp = %.3f Gbp in %.1fs" % (n_chrom, chrom_len, n_chrom * chrom_len / 1e9, time.time() - t0))
     t0 = time.time()
-    sa = torch.empty(n, dtype=torch.int32, device=dev)
-    k4.build_sa_device(n, 4, seq.data_ptr(), sa.data_ptr(), device=local_rank)
+    el = 4 if n < 4_000_000_000 else 5  # cThres8ByteSfxEls, libkit4b/SfxArray.h:184
+    sa = torch.empty(n * el + 16, dtype=torch.uint8, device=dev)
+    k4.build_sa_device(n, el, seq.data_ptr(), sa.data_ptr(), device=local_rank)
     t_sa = time.time() - t0
     log(rank, "suffix array (%d elements) built on the GPU in %.1fs" % (n, t_sa))
     t0 = time.time()
     names = ["chr%d" % (i + 1) for i in range(n_chrom)]
     ents = k4.make_entries(names, [chrom_len] * n_chrom)
-    ix = k4.SfxIndex.from_device(n, 4, seq.data_ptr(), sa.data_ptr(), ents, dataset="syn3g", device=local_rank,
+    ix = k4.SfxIndex.from_device(n, el, seq.data_ptr(), sa.data_ptr(), ents, dataset="syn3g", device=local_rank,
                                  kmer_k=args.kmer_k, keep=(sa,))
     info = ix.info()
     ix.set_max_iter(5000)  # cDfltKASensCoreIters, KAligner.cpp:373-388
@@ -223,7 +224,7 @@ def main():
         O = Oracle()
         t0 = time.time()
         seq_h = seq.cpu().numpy()
-        sa_h = sa.cpu().numpy().view(np.uint8)
+        sa_h = sa[: n * el].cpu().numpy()
         oents = (OEntry * n_chrom)()
         for i in range(n_chrom):
             oents[i].entry_id = i + 1
@@ -232,7 +233,7 @@ def main():
             oents[i].seq_len = chrom_len
             oents[i].start_ofs = i * (chrom_len + 1)
             oents[i].end_ofs = i * (chrom_len + 1) + chrom_len - 1
-        ho = O.L.k4o_from_parts(n, 4, seq_h.ctypes.data, sa_h.ctypes.data, n_chrom, oents, b"syn3g")
+        ho = O.L.k4o_from_parts(n, el, seq_h.ctypes.data, sa_h.ctypes.data, n_chrom, oents, b"syn3g")
         O.set_max_iter(ho, 5000)
         log(rank, "index copied to the host for the CPU baseline in %.1fs" % (time.time() - t0))
         # the GPU box gives one GPU a 16-core CPU share (os.cpu_count() reports the whole host)
@@ -267,7 +268,7 @@ def main():
         value = total_reads / elapsed / 1e6
         # roofline of the dominant kernel (k4k_align_fast), SURVEY.md 8(d) algorithmic bytes, counted at run time
         Lbits = math.ceil(math.log2(n))
-        E = 4
+        E = el
         per_launch = {k: ctr[k] / max(launches, 1) for k in ("n_reads", "n_lookup", "n_probe", "n_cand", "n_slow")}
         b_lookup = Lbits * (E + 8)
         b_cand = E + 8 * math.ceil(L / 32)
@@ -300,7 +301,7 @@ def main():
                 "workload": ("C2: %d x %d bp SE reads per GPU vs %.2f Gbp synthetic genome (%d x %d bp), kalign -s%d"
                              % (n_reads, L, n_chrom * chrom_len / 1e9, n_chrom, chrom_len, args.max_subs))
                 + ("" if full else " [REDUCED: not the BASELINE configuration]"),
-                "reads_per_gpu": n_reads, "read_len": L, "genome_bp": n_chrom * chrom_len, "sfx_el_size": 4,
+                "reads_per_gpu": n_reads, "read_len": L, "genome_bp": n_chrom * chrom_len, "sfx_el_size": el,
                 "kmer_table_k": info["kmer_k"], "index_hbm_gb": round(info["device_bytes"] / 1e9, 2),
                 "parallelism": "reads sharded per GPU, index replicated, RCCL all-reduce of NAR counts only",
                 "sa_build_s": round(t_sa, 1),

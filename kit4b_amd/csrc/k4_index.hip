@@ -4,6 +4,7 @@
 #include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <strings.h>
 #include <sys/mman.h>
@@ -133,32 +134,36 @@ K4_DEV uint64_t k4d_kmer_ceiling(const K4DevIndex& ix, uint64_t pos, uint32_t k)
 
 template <int EL, typename T>
 __global__ void __launch_bounds__(256) k4k_ktab_mark(K4DevIndex ix, T* __restrict__ tab) {
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= ix.n) return;
-  const uint64_t pos = k4d_sa_at<EL>(ix, i);
-  const uint64_t cc = k4d_kmer_ceiling(ix, pos, ix.k);
-  const uint64_t cp = i > 0 ? k4d_kmer_ceiling(ix, k4d_sa_at<EL>(ix, i - 1), ix.k) : 0;
-  if (cc != cp) {  // first suffix with this ceiling: every code in [cp, cc) has lb = i; the min-scan fills downwards
-    constexpr int ST = sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64;
-    const uint64_t c = cc - 1;
-    tab[ST * c] = (T)i;
-    tab[ST * c + 1] = (T)pos;
-    if (sizeof(T) == 4) tab[ST * c + 2] = (T)(k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 32);  // the next 16 bases
+  // grid-stride: a launch may not exceed 2^32 threads in total, the block may hold more symbols than that
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < ix.n; i += stride) {
+    const uint64_t pos = k4d_sa_at<EL>(ix, i);
+    const uint64_t cc = k4d_kmer_ceiling(ix, pos, ix.k);
+    const uint64_t cp = i > 0 ? k4d_kmer_ceiling(ix, k4d_sa_at<EL>(ix, i - 1), ix.k) : 0;
+    if (cc != cp) {  // first suffix with this ceiling: every code in [cp, cc) has lb = i; the min-scan fills downwards
+      constexpr int ST = sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64;
+      const uint64_t c = cc - 1;
+      tab[ST * c] = (T)i;
+      tab[ST * c + 1] = (T)pos;
+      if (sizeof(T) == 4) tab[ST * c + 2] = (T)(k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 32);  // the next 16 bases
+    }
   }
 }
 
-// reverse (suffix) min-scan over the lb fields (entry stride 3 or 2 words) in three passes: lb[c] = min(lb[c'], c' >= c); unset = max value.
+template <typename T>
+K4_DEV T k4_tmin(T a, T b) { return b < a ? b : a; }  // (no reliance on which ::min overload a 64-bit T picks)
+// reverse (suffix) min-scan over the lb fields (entry stride 3 or 2 words) in three passes: lb[c] = min over c' >= c of lb[c']; unset = max value.
 template <typename T>
 __global__ void __launch_bounds__(256) k4k_scan_block_min(const T* __restrict__ tab, uint64_t n, T* __restrict__ agg) {
   __shared__ T sh[256];
   uint64_t base = (uint64_t)blockIdx.x * 2048 + (uint64_t)threadIdx.x * 8;
   T m = (T)~(T)0;
   for (int j = 0; j < 8; j++)
-    if (base + j < n) m = min(m, tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)]);
+    if (base + j < n) m = k4_tmin<T>(m, tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)]);
   sh[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) sh[threadIdx.x] = min(sh[threadIdx.x], sh[threadIdx.x + s]);
+    if (threadIdx.x < s) sh[threadIdx.x] = k4_tmin<T>(sh[threadIdx.x], sh[threadIdx.x + s]);
     __syncthreads();
   }
   if (threadIdx.x == 0) agg[blockIdx.x] = sh[0];
@@ -179,15 +184,15 @@ __global__ void __launch_bounds__(1024) k4k_scan_agg(T* __restrict__ agg, uint64
     for (int s = 1; s < 1024; s <<= 1) {  // inclusive reverse scan (Hillis-Steele)
       T o = threadIdx.x + s < 1024 ? sh[threadIdx.x + s] : (T)~(T)0;
       __syncthreads();
-      sh[threadIdx.x] = min(sh[threadIdx.x], o);
+      sh[threadIdx.x] = k4_tmin<T>(sh[threadIdx.x], o);
       __syncthreads();
     }
     T carry = carry_s;
     T excl = threadIdx.x + 1 < 1024 ? sh[threadIdx.x + 1] : (T)~(T)0;  // strictly-right within the tile
     T tile_min = sh[0];
     __syncthreads();
-    if (i < nb) agg[i] = min(excl, carry);
-    if (threadIdx.x == 0) carry_s = min(carry, tile_min);
+    if (i < nb) agg[i] = k4_tmin<T>(excl, carry);
+    if (threadIdx.x == 0) carry_s = k4_tmin<T>(carry, tile_min);
     __syncthreads();
   }
 }
@@ -199,7 +204,7 @@ __global__ void __launch_bounds__(256) k4k_scan_apply(T* __restrict__ tab, uint6
   T m = (T)~(T)0;
   for (int j = 7; j >= 0; j--) {
     T x = base + j < n ? tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)] : (T)~(T)0;
-    m = min(m, x);
+    m = k4_tmin<T>(m, x);
     v[j] = m;  // min over this thread's elements j..7
   }
   sh[threadIdx.x] = m;
@@ -207,13 +212,13 @@ __global__ void __launch_bounds__(256) k4k_scan_apply(T* __restrict__ tab, uint6
   for (int s = 1; s < 256; s <<= 1) {
     T o = threadIdx.x + s < 256 ? sh[threadIdx.x + s] : (T)~(T)0;
     __syncthreads();
-    sh[threadIdx.x] = min(sh[threadIdx.x], o);
+    sh[threadIdx.x] = k4_tmin<T>(sh[threadIdx.x], o);
     __syncthreads();
   }
   T right = threadIdx.x + 1 < 256 ? sh[threadIdx.x + 1] : (T)~(T)0;
-  right = min(right, agg[blockIdx.x]);
+  right = k4_tmin<T>(right, agg[blockIdx.x]);
   for (int j = 0; j < 8; j++)
-    if (base + j < n) tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)] = min(v[j], right);
+    if (base + j < n) tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)] = k4_tmin<T>(v[j], right);
 }
 
 __global__ void k4k_unpack_range(K4DevIndex ix, uint64_t start, uint64_t len, uint8_t* __restrict__ out) {
@@ -241,7 +246,7 @@ static int build_ktab(k4_index* ix) {
   T last = (T)ix->d.n;
   K4_HIP(ix, hipMemcpy(tab + (size_t)ST * (nent - 1), &last, sizeof(T), hipMemcpyHostToDevice));
   ix->d.ktab = tab;
-  uint64_t nb = (ix->d.n + 255) / 256;
+  uint64_t nb = std::min<uint64_t>((ix->d.n + 255) / 256, 1ull << 23);
   hipLaunchKernelGGL((k4k_ktab_mark<EL, T>), dim3((unsigned)nb), dim3(256), 0, 0, ix->d, tab);
   K4_HIP(ix, hipGetLastError());
   uint64_t sb = (nent + 2047) / 2048;
@@ -341,6 +346,7 @@ int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
   ix->d.n_entries = ne;
   ix->d.k = (uint32_t)choose_k(n, kmer_k);
   ix->d.ktab64 = n >= 0xFFFFFFFFull ? 1 : 0;
+  if (ix->d.el == 5 && getenv("K4_FORCE_KTAB64")) ix->d.ktab64 = 1;  // test hook: 64-bit table fields on a small index
   ix->d.max_iter = 50000;  // cDfltMaxIter, libkit4b/SfxArray.h:12
   int rc;
   if (ix->d.el == 4)
@@ -591,6 +597,21 @@ extern "C" int k4_set_max_iter(k4_index* ix, int max_iter) {  // CSfxArray::SetM
   int prev = ix->d.max_iter;
   ix->d.max_iter = max_iter > 0 ? max_iter : 0;
   return prev;
+}
+
+// test hook (not part of the ABI header): raw k-mer table entry {lb, pos0[, sig]} of code c
+extern "C" int k4i_debug_ktab(const k4_index* ix, uint64_t c, uint64_t* out) {
+  if (!ix || !out) return K4_ERR_PARAMS;
+  hipSetDevice(ix->device);
+  if (ix->d.ktab64) {
+    if (hipMemcpy(out, (const uint64_t*)ix->ktab + K4_KTAB_STRIDE64 * c, 16, hipMemcpyDeviceToHost) != hipSuccess) return K4_ERR_NO_DEVICE;
+    out[2] = 0;
+  } else {
+    uint32_t v[3];
+    if (hipMemcpy(v, (const uint32_t*)ix->ktab + K4_KTAB_STRIDE32 * c, 12, hipMemcpyDeviceToHost) != hipSuccess) return K4_ERR_NO_DEVICE;
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
+  }
+  return K4_OK;
 }
 
 static int unpack_to_host(const k4_index* cix, uint64_t start, uint64_t len, uint8_t* out) {

@@ -424,3 +424,71 @@ def test_long_and_ragged_reads_vs_oracle(k4, oracle, golden_dir):
     assert ix.counters()["n_slow"] > 0
     ix.close()
     oracle.close(ho)
+
+
+def test_index_above_4gbp_5byte_elements(k4, oracle):
+    """>= 2^32 symbols: 5-byte suffix elements (SfxArray.h:184), 64-bit table fields, 64-bit suffix sort.  4.5 Gbp built
+    on the GPU; truth property on 1 M reads and read-for-read equality with the oracle on a sample."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 215 * (1 << 30):
+        pytest.skip("needs ~210 GB of free HBM")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(synth.GENOME_SEED + 5)
+    n_chrom, chrom_len = 36, 125_000_000
+    n = n_chrom * (chrom_len + 1)
+    assert n > (1 << 32)
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    for c in range(n_chrom):
+        o = c * (chrom_len + 1)
+        seq[o:o + chrom_len] = torch.randint(0, 4, (chrom_len,), dtype=torch.uint8, device=dev, generator=g)
+        seq[o + chrom_len] = 7
+    sa = torch.empty(n * 5 + 16, dtype=torch.uint8, device=dev)
+    k4.build_sa_device(n, 5, seq.data_ptr(), sa.data_ptr())
+    names = ["chr%d" % (i + 1) for i in range(n_chrom)]
+    ix = k4.SfxIndex.from_device(n, 5, seq.data_ptr(), sa.data_ptr(), k4.make_entries(names, [chrom_len] * n_chrom),
+                                 keep=(sa,))
+    try:
+        info = ix.info()
+        assert info["sfx_el_size"] == 5 and info["kmer_k"] == 16
+        ix.set_max_iter(5000)
+        # reads from the far end of the concatenation (offsets above 2^32) and from the start
+        rng = np.random.default_rng(9)
+        nr, L = 200000, 100
+        chrom = np.concatenate([rng.integers(33, 36, nr // 2), rng.integers(0, 3, nr // 2)])
+        start = rng.integers(0, chrom_len - L, nr)
+        gofs = torch.from_numpy(chrom * (chrom_len + 1) + start).to(dev)
+        rd = seq[gofs[:, None] + torch.arange(L, device=dev)[None, :]].cpu().numpy()
+        nsubs = np.minimum(rng.poisson(1.0, nr), 8)
+        strand = rng.integers(0, 2, nr)
+        reads = []
+        for i in range(nr):
+            r = rd[i].copy()
+            for p_ in rng.choice(L, size=nsubs[i], replace=False):
+                r[p_] = (r[p_] + rng.integers(1, 4)) % 4
+            reads.append(synth.revcomp(r) if strand[i] else r)
+        res = ix.kalign_batch(reads, max_subs=2)
+        out, hits = res["out"], res["hits"][:, 0]
+        ok = nsubs <= 2
+        assert (out["nar"][ok] == 1).all() and (out["nar"][~ok] == 3).all()
+        assert np.array_equal(hits["chrom_id"][ok], chrom[ok] + 1) and np.array_equal(hits["match_loci"][ok], start[ok])
+        assert np.array_equal(hits["mismatches"][ok], nsubs[ok])
+        # oracle on the same 27 GB index (host copy), a 20 k sample
+        seq_h = seq.cpu().numpy()
+        sa_h = sa[: n * 5].cpu().numpy()
+        from oracle_bindings import Entry as OEntry
+
+        oe = (OEntry * n_chrom)()
+        for i in range(n_chrom):
+            oe[i].entry_id = i + 1; oe[i].fblock_id = 1; oe[i].name = names[i].encode(); oe[i].seq_len = chrom_len
+            oe[i].start_ofs = i * (chrom_len + 1); oe[i].end_ofs = i * (chrom_len + 1) + chrom_len - 1
+        ho = oracle.L.k4o_from_parts(n, 5, seq_h.ctypes.data, sa_h.ctypes.data, n_chrom, oe, b"big")
+        oracle.set_max_iter(ho, 5000)
+        sample = list(range(0, 10000)) + list(range(nr // 2, nr // 2 + 10000))
+        eo = oracle.kalign_batch(ho, [reads[i] for i in sample], max_subs=2, threads=16)
+        assert np.array_equal(eo["out"], out[sample]) and np.array_equal(eo["hits"][:, 0], hits[sample])
+        oracle.close(ho)
+    finally:
+        ix.close()
