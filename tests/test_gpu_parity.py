@@ -492,3 +492,88 @@ def test_index_above_4gbp_5byte_elements(k4, oracle):
         oracle.close(ho)
     finally:
         ix.close()
+
+
+@pytest.mark.gpu
+def test_c5_scale_15gbp_se_and_pe_truth(k4):
+    """BASELINE config C5 at full index size on one GPU: 120 x 125 Mbp = 15 Gbp built on the device (5-byte elements,
+    bucketed suffix sort, 64-bit table), 150 bp reads, `-s3` (MaxTotMM 5), PE `-U2 -d200 -D600`.  The oracle cannot run
+    at this size; the check is the analytic truth property of SURVEY.md 8(d): a read is accepted, at its true locus and
+    with Mismatches == induced substitutions, iff it carries <= MaxTotMM substitutions, else it is NL."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 240 * (1 << 30):
+        pytest.skip("needs ~230 GB of free HBM")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(synth.GENOME_SEED + 15)
+    n_chrom, chrom_len = 120, 125_000_000
+    n = n_chrom * (chrom_len + 1)
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    for c in range(n_chrom):
+        o = c * (chrom_len + 1)
+        seq[o:o + chrom_len] = torch.randint(0, 4, (chrom_len,), dtype=torch.uint8, device=dev, generator=g)
+        seq[o + chrom_len] = 7
+    sa = torch.empty(n * 5 + 16, dtype=torch.uint8, device=dev)
+    k4.build_sa_device(n, 5, seq.data_ptr(), sa.data_ptr())
+    names = ["chr%d" % (i + 1) for i in range(n_chrom)]
+    ix = k4.SfxIndex.from_device(n, 5, seq.data_ptr(), sa.data_ptr(), k4.make_entries(names, [chrom_len] * n_chrom),
+                                 keep=(sa,))
+    try:
+        ix.set_max_iter(5000)
+        rng = np.random.default_rng(15)
+        L, nfrag = 150, 60000
+        chrom = rng.integers(0, n_chrom, nfrag)
+        flen = rng.integers(300, 501, nfrag)
+        fstart = rng.integers(0, chrom_len - 500, nfrag)
+        fstrand = rng.integers(0, 2, nfrag)
+        base = torch.from_numpy(chrom * (chrom_len + 1) + fstart).to(dev)
+        left = seq[base[:, None] + torch.arange(L, device=dev)[None, :]].cpu().numpy()
+        rofs = torch.from_numpy(chrom * (chrom_len + 1) + fstart + flen - L).to(dev)
+        right = seq[rofs[:, None] + torch.arange(L, device=dev)[None, :]].cpu().numpy()
+
+        def mutate(r):
+            ns = int(min(rng.poisson(2.0), 9))
+            for p_ in rng.choice(L, size=ns, replace=False):
+                r[p_] = (r[p_] + rng.integers(1, 4)) % 4
+            return r, ns
+
+        pe1, pe2, ns1, ns2 = [], [], np.zeros(nfrag, int), np.zeros(nfrag, int)
+        loci1, loci2 = np.zeros(nfrag, np.int64), np.zeros(nfrag, np.int64)
+        for i in range(nfrag):
+            if fstrand[i] == 0:  # PE1 = fragment 5' end, PE2 = revcomp of its 3' end
+                a, b = left[i].copy(), synth.revcomp(right[i])
+                loci1[i], loci2[i] = fstart[i], fstart[i] + flen[i] - L
+            else:
+                a, b = synth.revcomp(right[i]), left[i].copy()
+                loci1[i], loci2[i] = fstart[i] + flen[i] - L, fstart[i]
+            a, ns1[i] = mutate(a)
+            b, ns2[i] = mutate(b)
+            pe1.append(a)
+            pe2.append(b)
+        # ---- SE: every end on its own ----------------------------------------------------------------------------------
+        res = ix.kalign_batch(pe1 + pe2, max_subs=3)
+        out, hits = res["out"], res["hits"][:, 0]
+        ns = np.concatenate([ns1, ns2])
+        ok = ns <= 5
+        assert (~ok).sum() > 100
+        assert (out["nar"][ok] == 1).all() and (out["nar"][~ok] == 3).all()
+        assert np.array_equal(hits["chrom_id"][ok], np.concatenate([chrom, chrom])[ok] + 1)
+        assert np.array_equal(hits["match_loci"][ok], np.concatenate([loci1, loci2])[ok])
+        assert np.array_equal(hits["mismatches"][ok], ns[ok])
+        st = np.concatenate([np.where(fstrand == 0, ord("+"), ord("-")), np.where(fstrand == 0, ord("-"), ord("+"))])
+        assert np.array_equal(hits["strand"][ok], st[ok])
+        # ---- PE: pairs whose two ends are both within MaxTotMM are accepted as proper pairs at the true loci -----------
+        pe = ix.kalign_pe_batch(pe1, pe2, pe_mode=2, pair_min_len=200, pair_max_len=600, max_subs=3)
+        both = (ns1 <= 5) & (ns2 <= 5)
+        o1, o2 = pe[0::2], pe[1::2]
+        assert (o1["nar"][both] == 1).all() and (o2["nar"][both] == 1).all()
+        assert (o1["pe_aligned"][both] == 1).all() and (o2["pe_aligned"][both] == 1).all()
+        assert np.array_equal(o1["hit"]["match_loci"][both], loci1[both])
+        assert np.array_equal(o2["hit"]["match_loci"][both], loci2[both])
+        assert np.array_equal(o1["hit"]["chrom_id"][both], chrom[both] + 1)
+        neither = (ns1 > 5) & (ns2 > 5)
+        assert (o1["nar"][neither] != 1).all() and (o2["nar"][neither] != 1).all()
+    finally:
+        ix.close()
