@@ -223,6 +223,12 @@ int k4_mate_rescue_batch(k4_index* ix, int64_t n_tasks, const k4_rescue_task* ta
 int k4_kalign_pe_batch(k4_index* ix, const k4_kalign_params* p, const k4_pe_params* pe, int64_t n_pairs,
                        const uint8_t* reads1, const uint64_t* offs1, const uint32_t* lens1, const uint8_t* reads2,
                        const uint64_t* offs2, const uint32_t* lens2, k4_pe_read* out);
+/* Device-resident form: reads interleaved (read 2i = PE1 of pair i, read 2i+1 = its PE2), every array in HBM; the SE
+ * pass, the pairing kernel (AcceptProvPE / PEInsertSize / NAR reassignment, one thread per pair) and the orphan kernel
+ * (AlignPairedRead, one wave per orphan pair) are enqueued on `stream`, which is then waited for. */
+int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, const k4_pe_params* pe, int64_t n_pairs,
+                           int32_t max_read_len, const void* d_reads, const void* d_offs, const void* d_lens,
+                           void* d_out, void* stream);
 
 /* kernel timing for roofline measurement: when enabled, every batch brackets the dominant kernel (k4k_align_fast) with
  * HIP events on the stream it is launched on; k4_get_kernel_times synchronises, returns the summed duration and the

@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
-    "k4_get_kernel_times", "k4_mate_rescue_batch", "k4_kalign_pe_batch",
+    "k4_get_kernel_times", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
 ]
 
 
@@ -135,6 +135,7 @@ def lib():
     L.k4_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.k4_mate_rescue_batch.argtypes = [vp, i64, vp, vp, u64, vp, vp]
     L.k4_kalign_pe_batch.argtypes = [vp, C.POINTER(KalignParams), C.POINTER(PeParams), i64] + [vp] * 7
+    L.k4_kalign_pe_batch_dev.argtypes = [vp, C.POINTER(KalignParams), C.POINTER(PeParams), i64, C.c_int32] + [vp] * 5
     _lib = L
     return L
 
@@ -312,6 +313,10 @@ class SfxIndex:
         return out
 
     # -- the hot path (device buffers; pointers are ints, e.g. torch.Tensor.data_ptr()) -------------------------
+    def kalign_pe_batch_dev(self, params, pe_params, n_pairs, max_read_len, d_reads, d_offs, d_lens, d_out, stream=0):
+        self._ck(lib().k4_kalign_pe_batch_dev(self.h, C.byref(params), C.byref(pe_params), n_pairs, max_read_len,
+                                              d_reads, d_offs, d_lens, d_out, stream))
+
     def kalign_batch_dev(self, params, n, max_read_len, d_reads, d_offs, d_lens, d_out, d_hits, stream=0):
         self._ck(lib().k4_kalign_batch_dev(self.h, C.byref(params), n, max_read_len, d_reads, d_offs, d_lens, d_out,
                                            d_hits, stream))

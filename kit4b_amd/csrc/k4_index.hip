@@ -555,6 +555,8 @@ extern "C" void k4_close(k4_index* ix) {
                   w.slow_probe, w.slow_hash, w.d_reads, w.d_offs, w.d_lens, w.d_out4, w.d_hits};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  for (void* p : {(void*)ix->pe_rr, (void*)ix->pe_hits, (void*)ix->pe_list, (void*)ix->pe_ctl})
+    if (p) hipFree(p);
   if (ix->stream) hipStreamDestroy(ix->stream);
   for (hipEvent_t e : ix->ev0) hipEventDestroy(e);
   for (hipEvent_t e : ix->ev1) hipEventDestroy(e);

@@ -100,6 +100,13 @@ struct k4_index {
   uint64_t device_bytes = 0;
   std::string err;
   K4Workspace ws;
+  // paired-end pass (k4_pe.hip): both ends' SE results, their hit slots, the orphan list, {orphan count, error flag}
+  k4_read_result* pe_rr = nullptr;
+  k4_hit* pe_hits = nullptr;
+  uint32_t* pe_list = nullptr;
+  uint32_t* pe_ctl = nullptr;
+  int64_t pe_cap_pairs = 0;
+  int32_t pe_cap_hits = 0;
   hipStream_t stream = nullptr; // internal stream for the host-pointer entry points
   bool timing = false;          // bracket k4k_align_fast with events
   std::vector<hipEvent_t> ev0, ev1;

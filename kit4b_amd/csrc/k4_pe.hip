@@ -1,4 +1,4 @@
-// kit4b_amd/csrc/k4_pe.hip -- paired-end pass: mate rescue kernel + the CKAligner pairing logic on the host.
+// kit4b_amd/csrc/k4_pe.hip -- paired-end pass: mate rescue and the CKAligner pairing logic as kernels.
 //
 //   CSfxArray::AlignPairedRead    libkit4b/SfxArray.cpp:8571-8767 (linear-scan branch) + AdaptiveTrim :5561-5639
 //   CKAligner::ProcCoredApprox    ngskit4b/KAligner.cpp:10160-10239 (multi x multi pair resolution)
@@ -8,11 +8,84 @@
 #include <vector>
 #include "k4_device.h"
 
-// ---- mate rescue: one wave per task scans every locus of the insert window -------------------------------------
+// ---- mate rescue: one wave scans every locus of the insert window ------------------------------------------------
 // A locus is acceptable when the full-length mismatch count is <= ((len*rate)+99)/100, no mismatch sits in the first
 // three or the last two bases (AdaptiveTrim :5622-5631 with MinFlankMatches 3) and the count is < rate + 1
 // (PrevBestMaxChimericMMs :8684).  The reference keeps the first strictly better locus and stops at a 0-mismatch one,
 // i.e. the lexicographic minimum of (mismatches, locus).
+// Wave-cooperative; rs = K4_MAX_READ_LEN bytes of LDS owned by this wave.  Returns the AlignPairedRead result
+// (1 placed, 0 not, < 0 error), identical in every lane; h is filled when 1.
+K4_DEV int k4d_mate_rescue(const K4DevIndex& ix, const k4_rescue_task& tk, const uint8_t* __restrict__ reads, int lane,
+                           uint8_t* rs, k4_hit& h) {
+  int res = 0;
+  uint32_t best = 0xFFFFFFFFu;  // (mm << 20) | (locus - sp)
+  uint32_t sp = 0, ep = 0;
+  const int len = (int)tk.read_len;
+  bool run = false;
+  if (tk.chrom_id >= 1 && tk.chrom_id <= ix.n_entries && len >= 1 && len <= K4_MAX_READ_LEN) {
+    const uint64_t cs = ix.ent_start[tk.chrom_id - 1];
+    const uint32_t chrom_len = (uint32_t)(ix.ent_end[tk.chrom_id - 1] - cs + 1);
+    int min_ins = tk.min_insert, max_ins = tk.max_insert;
+    if (tk.start_loci >= tk.end_loci || tk.end_loci >= chrom_len) res = -1;
+    else if (min_ins > max_ins) res = 0;
+    else {
+      if (min_ins < len) { max_ins += len - min_ins; min_ins = len; }
+      run = true;
+      if (tk.b3prime_extend) {
+        if ((uint32_t)(tk.start_loci + min_ins) >= chrom_len) run = false;
+        else {
+          sp = tk.start_loci + min_ins - len;
+          ep = min(chrom_len - (uint32_t)len, (uint32_t)(tk.start_loci + max_ins - len));
+        }
+      } else {
+        if (tk.end_loci < (uint32_t)min_ins) run = false;
+        else {
+          sp = tk.end_loci <= (uint32_t)max_ins ? 0 : tk.end_loci - max_ins;
+          ep = tk.end_loci - min_ins;
+        }
+      }
+      if (run && (ep - sp) >= 1000) { run = false; res = K4_ERR_UNSUPPORTED; }  // the reference's CoreLen==0 path
+      // AdaptiveTrim parameter validation (:5598-5603): failing it means no locus is ever accepted
+      if (run && (len < 25 || len > 2048 || (uint32_t)tk.max_allowed_mm > (uint32_t)((15 * len + 99) / 100))) run = false;
+    }
+    if (run) {
+      __syncthreads();  // (blocks are one wave)
+      const uint8_t* src = reads + tk.read_off;
+      for (int q = lane; q < len; q += 64) {
+        uint8_t b = tk.antisense ? src[len - 1 - q] & 7 : src[q] & 7;
+        if (tk.antisense && b <= 3) b = 3 - b;
+        rs[q] = b;
+      }
+      __syncthreads();
+      const uint32_t max_allowed = ((uint32_t)len * (uint32_t)tk.max_allowed_mm + 99) / 100;
+      for (uint32_t loci = sp + lane; loci <= ep; loci += 64) {
+        const uint64_t g = cs + loci;
+        uint32_t mm = 0;
+        bool ok = true;
+        for (int o = 0; o < len; o++) {
+          if (rs[o] != k4d_ref_base(ix, g + o)) {
+            if (++mm > max_allowed) { ok = false; break; }
+            if (o < 3 || (len - o) < 3) { ok = false; break; }
+          }
+        }
+        if (ok && mm <= (uint32_t)tk.max_allowed_mm) best = min(best, (mm << 20) | (loci - sp));
+      }
+    }
+  } else
+    res = -1;
+  for (int d = 32; d > 0; d >>= 1) best = min(best, (uint32_t)__shfl_xor(best, d, 64));
+  memset(&h, 0, sizeof(h));
+  if (run && best != 0xFFFFFFFFu) {
+    res = 1;
+    h.chrom_id = tk.chrom_id;
+    h.match_loci = sp + (best & 0xFFFFF);
+    h.match_len = (uint16_t)len;
+    h.strand = tk.antisense ? '-' : '+';
+    h.mismatches = (uint8_t)(best >> 20);
+  }
+  return res;
+}
+
 __global__ void __launch_bounds__(64) k4k_mate_rescue(K4DevIndex ix, const k4_rescue_task* __restrict__ tasks,
                                                       const uint8_t* __restrict__ reads, int64_t n_tasks,
                                                       int32_t* __restrict__ rslt, k4_hit* __restrict__ hits) {
@@ -20,74 +93,9 @@ __global__ void __launch_bounds__(64) k4k_mate_rescue(K4DevIndex ix, const k4_re
   const int lane = threadIdx.x;
   for (int64_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
     const k4_rescue_task tk = tasks[t];
-    int res = 0;
-    uint32_t best = 0xFFFFFFFFu;  // (mm << 20) | (locus - sp)
-    uint32_t sp = 0, ep = 0;
-    const int len = (int)tk.read_len;
-    bool run = false;
-    if (tk.chrom_id >= 1 && tk.chrom_id <= ix.n_entries && len >= 1 && len <= K4_MAX_READ_LEN) {
-      const uint64_t cs = ix.ent_start[tk.chrom_id - 1];
-      const uint32_t chrom_len = (uint32_t)(ix.ent_end[tk.chrom_id - 1] - cs + 1);
-      int min_ins = tk.min_insert, max_ins = tk.max_insert;
-      if (tk.start_loci >= tk.end_loci || tk.end_loci >= chrom_len) res = -1;
-      else if (min_ins > max_ins) res = 0;
-      else {
-        if (min_ins < len) { max_ins += len - min_ins; min_ins = len; }
-        run = true;
-        if (tk.b3prime_extend) {
-          if ((uint32_t)(tk.start_loci + min_ins) >= chrom_len) run = false;
-          else {
-            sp = tk.start_loci + min_ins - len;
-            ep = min(chrom_len - (uint32_t)len, (uint32_t)(tk.start_loci + max_ins - len));
-          }
-        } else {
-          if (tk.end_loci < (uint32_t)min_ins) run = false;
-          else {
-            sp = tk.end_loci <= (uint32_t)max_ins ? 0 : tk.end_loci - max_ins;
-            ep = tk.end_loci - min_ins;
-          }
-        }
-        if (run && (ep - sp) >= 1000) { run = false; res = K4_ERR_UNSUPPORTED; }  // the reference's CoreLen==0 path
-        // AdaptiveTrim parameter validation (:5598-5603): failing it means no locus is ever accepted
-        if (run && (len < 25 || len > 2048 || (uint32_t)tk.max_allowed_mm > (uint32_t)((15 * len + 99) / 100))) run = false;
-      }
-      if (run) {
-        __syncthreads();
-        const uint8_t* src = reads + tk.read_off;
-        for (int q = lane; q < len; q += 64) {
-          uint8_t b = tk.antisense ? src[len - 1 - q] & 7 : src[q] & 7;
-          if (tk.antisense && b <= 3) b = 3 - b;
-          rs[q] = b;
-        }
-        __syncthreads();
-        const uint32_t max_allowed = ((uint32_t)len * (uint32_t)tk.max_allowed_mm + 99) / 100;
-        for (uint32_t loci = sp + lane; loci <= ep; loci += 64) {
-          const uint64_t g = cs + loci;
-          uint32_t mm = 0;
-          bool ok = true;
-          for (int o = 0; o < len; o++) {
-            if (rs[o] != k4d_ref_base(ix, g + o)) {
-              if (++mm > max_allowed) { ok = false; break; }
-              if (o < 3 || (len - o) < 3) { ok = false; break; }
-            }
-          }
-          if (ok && mm <= (uint32_t)tk.max_allowed_mm) best = min(best, (mm << 20) | (loci - sp));
-        }
-      }
-    } else
-      res = -1;
-    for (int d = 32; d > 0; d >>= 1) best = min(best, (uint32_t)__shfl_down(best, d, 64));
+    k4_hit h;
+    const int res = k4d_mate_rescue(ix, tk, reads, lane, rs, h);
     if (lane == 0) {
-      k4_hit h;
-      memset(&h, 0, sizeof(h));
-      if (run && best != 0xFFFFFFFFu) {
-        res = 1;
-        h.chrom_id = tk.chrom_id;
-        h.match_loci = sp + (best & 0xFFFFF);
-        h.match_len = (uint16_t)len;
-        h.strand = tk.antisense ? '-' : '+';
-        h.mismatches = (uint8_t)(best >> 20);
-      }
       rslt[t] = res;
       hits[t] = h;
     }
@@ -133,187 +141,288 @@ extern "C" int k4_mate_rescue_batch(k4_index* ix, int64_t n, const k4_rescue_tas
   return K4_OK;
 }
 
-// ---- host: the pairing logic ----------------------------------------------------------------------------------------
-static int pe_insert_size(const k4_pe_params& pe, uint8_t s1, uint32_t st1, uint32_t en1, uint8_t s2, uint32_t st2,
-                          uint32_t en2) {  // PEInsertSize, KAligner.cpp:2875-2918
+// ---- the pairing logic (device) -------------------------------------------------------------------------------------
+K4_DEV int k4d_pe_insert_size(const k4_pe_params& pe, uint8_t s1, uint32_t st1, uint32_t en1, uint8_t s2, uint32_t st2,
+                              uint32_t en2) {  // PEInsertSize, KAligner.cpp:2875-2918
   if ((pe.pair_strand && s1 != s2) || (!pe.pair_strand && s1 == s2)) return -1;
-  int frag = (int)(1 + std::max(en1, en2) - std::min(st1, st2));
+  int frag = (int)(1 + max(en1, en2) - min(st1, st2));
   if (frag < 0) return -1;
   if (frag < pe.pair_min_len) return -6;
   if (frag > pe.pair_max_len) return -7;
   return frag;
 }
-static int accept_prov_pe(const k4_pe_params& pe, int nh1, const k4_hit& h1, int nh2, const k4_hit& h2) {  // :2799-2861
+K4_DEV int k4d_accept_prov_pe(const k4_pe_params& pe, int nh1, const k4_hit& h1, int nh2, const k4_hit& h2) {  // :2799-2861
   if (!(nh1 == 1 && nh2 == 1)) return 0;
   if (h1.chrom_id != h2.chrom_id) return -2;
-  return pe_insert_size(pe, h1.strand, h1.match_loci, h1.match_loci + h1.match_len - 1, h2.strand, h2.match_loci,
-                        h2.match_loci + h2.match_len - 1);
+  return k4d_pe_insert_size(pe, h1.strand, h1.match_loci, h1.match_loci + h1.match_len - 1, h2.strand, h2.match_loci,
+                            h2.match_loci + h2.match_len - 1);
+}
+K4_DEV bool k4d_pe_unaligned(int nar) { return nar == K4_NAR_NS || nar == K4_NAR_NOHIT || nar == K4_NAR_UNALIGNED; }
+
+// what is left of an orphan pair that could not be accepted as a pair (KAligner.cpp:3538-3585)
+K4_DEV void k4d_pe_leftover(const k4_pe_params& pe, k4_pe_read& f, k4_pe_read& r) {
+  if (!(pe.pe_mode == 3 || pe.pe_mode == 4)) {
+    f.num_hits = r.num_hits = 0; f.inst = r.inst = 0;
+    if (f.nar == K4_NAR_ACCEPTED) f.nar = K4_NAR_PENOHIT;
+    if (r.nar == K4_NAR_ACCEPTED) r.nar = K4_NAR_PENOHIT;
+    return;
+  }
+  if (f.num_hits != 1) { f.num_hits = 0; f.inst = 0; if (f.nar == K4_NAR_ACCEPTED) f.nar = K4_NAR_PEUNALIGN; }
+  else f.nar = K4_NAR_ACCEPTED;
+  if (r.num_hits != 1) { r.num_hits = 0; r.inst = 0; if (r.nar == K4_NAR_ACCEPTED) r.nar = K4_NAR_PEUNALIGN; }
+  else r.nar = K4_NAR_ACCEPTED;
 }
 
+// One thread per pair: AlignRead's PE view of each end, ProcCoredApprox's multi x multi resolution (KAligner.cpp:10185-10239)
+// and ProcessPairedEnds (:3207-3318) up to the point where a mate rescue is needed; pairs that need one are listed.
+__global__ void __launch_bounds__(256) k4k_pe_pair(k4_pe_params pe, int64_t n_pairs, int mh, const k4_read_result* __restrict__ rr,
+                                                   const k4_hit* __restrict__ hits, k4_pe_read* __restrict__ out,
+                                                   uint32_t* __restrict__ orphans, uint32_t* __restrict__ ctl) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pairs) return;
+  const k4_hit* h1 = hits + (size_t)(2 * i) * mh;
+  const k4_hit* h2 = hits + (size_t)(2 * i + 1) * mh;
+  const k4_read_result q1 = rr[2 * i], q2 = rr[2 * i + 1];
+  k4_pe_read f, r;
+  memset(&f, 0, sizeof(f));
+  memset(&r, 0, sizeof(r));
+  f.nar = q1.nar; f.num_hits = q1.num_hits; f.inst = q1.inst; f.low_mm = q1.low_mm;
+  r.nar = q2.nar; r.num_hits = q2.num_hits; r.inst = q2.inst; r.low_mm = q2.low_mm;
+  if (q1.nar == K4_NAR_ACCEPTED) f.hit = h1[0];
+  if (q2.nar == K4_NAR_ACCEPTED) r.hit = h2[0];
+  if (q1.hit_rslt == K4_HR_HITS && q2.hit_rslt == K4_HR_HITS && !(f.inst == 1 && r.inst == 1) && f.inst < 10 && r.inst < 10) {
+    bool multi = false, accepted = false;
+    k4_hit p1, p2;
+    memset(&p1, 0, sizeof(p1));
+    memset(&p2, 0, sizeof(p2));
+    for (int a = 0; !(multi && !accepted) && a < f.inst; a++)
+      for (int b = 0; b < r.inst; b++) {
+        const k4_hit ha = h1[a], hb = h2[b];
+        if (k4d_accept_prov_pe(pe, 1, ha, 1, hb) > 0) {
+          if (!multi) { p1 = ha; p2 = hb; multi = true; accepted = true; }
+          else { accepted = false; break; }
+        }
+      }
+    if (accepted) {
+      f.hit = p1; f.nar = K4_NAR_ACCEPTED; f.num_hits = 1;
+      r.hit = p2; r.nar = K4_NAR_ACCEPTED; r.num_hits = 1;
+    }
+  }
+  bool orphan = false;
+  if (f.nar == K4_NAR_ACCEPTED || r.nar == K4_NAR_ACCEPTED) {
+    bool strict_fail = pe.pe_mode == 2 && (k4d_pe_unaligned(f.nar) || k4d_pe_unaligned(r.nar));
+    bool paired = false;
+    if (!strict_fail && f.nar == K4_NAR_ACCEPTED && r.nar == K4_NAR_ACCEPTED) {
+      const int frag = k4d_accept_prov_pe(pe, f.num_hits, f.hit, r.num_hits, r.hit);
+      if (frag > 0) { f.pe_aligned = r.pe_aligned = 1; paired = true; }
+      else {
+        switch (frag) {
+          case -1: f.nar = r.nar = K4_NAR_PESTRAND; break;
+          case -2: f.nar = r.nar = K4_NAR_PECHROM; break;
+          case -6: f.nar = r.nar = K4_NAR_PEINSERTMIN; break;
+          case -7: f.nar = r.nar = K4_NAR_PEINSERTMAX; break;
+          default: break;
+        }
+        if (pe.pe_mode == 2) strict_fail = true;
+      }
+    }
+    if (!paired) {
+      if (strict_fail) {
+        f.num_hits = r.num_hits = 0; f.inst = r.inst = 0;
+        if (f.nar == K4_NAR_ACCEPTED) f.nar = K4_NAR_PENOHIT;
+        if (r.nar == K4_NAR_ACCEPTED) r.nar = K4_NAR_PENOHIT;
+      } else if (pe.pe_mode == 1 || pe.pe_mode == 3) orphan = true;  // orphan recovery follows
+      else k4d_pe_leftover(pe, f, r);
+    }
+  }
+  out[2 * i] = f;
+  out[2 * i + 1] = r;
+  if (orphan) orphans[atomicAdd(&ctl[0], 1u)] = (uint32_t)i;
+}
+
+// One wave per orphan pair (modes 1 and 3): first the PE1 alignment as anchor (:3320-3418), then PE2 (:3424-3535),
+// then the leftover rule.  Every lane carries the same copy of the two records; lane 0 writes them back.
+__global__ void __launch_bounds__(64) k4k_pe_orphans(K4DevIndex ix, k4_pe_params pe, int max_subs, const uint8_t* __restrict__ reads,
+                                                     const uint64_t* __restrict__ offs, const uint32_t* __restrict__ lens,
+                                                     const uint32_t* __restrict__ orphans, k4_pe_read* __restrict__ out,
+                                                     uint32_t* __restrict__ ctl) {
+  __shared__ uint8_t rs[K4_MAX_READ_LEN];
+  const int lane = threadIdx.x;
+  const uint32_t n_orph = ctl[0];
+  for (uint32_t t = blockIdx.x; t < n_orph; t += gridDim.x) {
+    const int64_t i = orphans[t];
+    k4_pe_read f = out[2 * i], r = out[2 * i + 1];
+    bool done = false;
+    for (int round = 0; round < 2 && !done; round++) {
+      const k4_pe_read& anchor = round == 0 ? f : r;
+      const bool mate_unal = k4d_pe_unaligned(round == 0 ? r.nar : f.nar);
+      if (!(anchor.num_hits == 1 && !mate_unal)) continue;
+      const bool plus = anchor.hit.strand == '+';
+      k4_rescue_task tk;
+      memset(&tk, 0, sizeof(tk));
+      if (round == 0) { tk.b3prime_extend = plus; tk.antisense = pe.pair_strand ? !plus : plus; }
+      else {
+        tk.b3prime_extend = plus; tk.antisense = plus;
+        if (pe.pair_strand) { tk.b3prime_extend = !tk.b3prime_extend; tk.antisense = !tk.antisense; }
+      }
+      tk.chrom_id = anchor.hit.chrom_id;
+      tk.start_loci = anchor.hit.match_loci;
+      tk.end_loci = anchor.hit.match_loci + anchor.hit.match_len - 1;
+      const int64_t mate = round == 0 ? 2 * i + 1 : 2 * i;
+      tk.read_len = lens[mate];
+      tk.read_off = offs[mate];
+      tk.min_insert = pe.pair_min_len;
+      tk.max_insert = pe.pair_max_len;
+      tk.max_allowed_mm = max_subs;  // the per-100 bp rate, as the reference passes it (KAligner.cpp:3379, Q15)
+      k4_hit h;
+      const int res = k4d_mate_rescue(ix, tk, reads, lane, rs, h);
+      if (res == K4_ERR_UNSUPPORTED && lane == 0) atomicOr(&ctl[1], 1u);
+      if (res != 1) continue;
+      const uint32_t hs = h.match_loci, he = h.match_loci + h.match_len - 1;
+      const uint32_t as = anchor.hit.match_loci, ae = anchor.hit.match_loci + anchor.hit.match_len - 1;
+      const int frag = round == 0 ? k4d_pe_insert_size(pe, anchor.hit.strand, as, ae, h.strand, hs, he)
+                                  : k4d_pe_insert_size(pe, h.strand, hs, he, anchor.hit.strand, as, ae);
+      if (frag <= 0) continue;
+      k4_pe_read& m = round == 0 ? r : f;
+      m.hit = h; m.num_hits = 1; m.low_mm = h.mismatches; m.inst = 1; m.rescued = 1;
+      f.pe_aligned = r.pe_aligned = 1;
+      f.nar = r.nar = K4_NAR_ACCEPTED;
+      done = true;
+    }
+    if (!done) k4d_pe_leftover(pe, f, r);
+    if (lane == 0) {
+      out[2 * i] = f;
+      out[2 * i + 1] = r;
+    }
+  }
+}
+
+static int pe_reserve(k4_index* ix, int64_t n_pairs, int mh) {
+  if (n_pairs <= ix->pe_cap_pairs && mh <= ix->pe_cap_hits) return K4_OK;
+  const int64_t cap = std::max(n_pairs, ix->pe_cap_pairs);
+  const int h = std::max(mh, ix->pe_cap_hits);
+  for (void* p : {(void*)ix->pe_rr, (void*)ix->pe_hits, (void*)ix->pe_list, (void*)ix->pe_ctl})
+    if (p) hipFree(p);
+  ix->pe_rr = nullptr; ix->pe_hits = nullptr; ix->pe_list = nullptr; ix->pe_ctl = nullptr;
+  ix->pe_cap_pairs = 0;
+  K4_HIP(ix, hipMalloc(&ix->pe_rr, (size_t)(2 * cap + 1) * sizeof(k4_read_result)));
+  K4_HIP(ix, hipMalloc(&ix->pe_hits, (size_t)(2 * cap + 1) * h * sizeof(k4_hit)));
+  K4_HIP(ix, hipMalloc(&ix->pe_list, (size_t)(cap + 1) * 4));
+  K4_HIP(ix, hipMalloc(&ix->pe_ctl, 16));
+  ix->pe_cap_pairs = cap;
+  ix->pe_cap_hits = h;
+  return K4_OK;
+}
+
+// Device buffers in, device records out; reads are interleaved (read 2i = PE1 of pair i, read 2i+1 = its PE2).
+// Enqueues the SE pass over the 2n ends, the pairing kernel and the orphan kernel on `stream`, then waits for the
+// stream (the insert-window error of the rescue can only be reported after the fact).
+extern "C" int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, const k4_pe_params* pe_in, int64_t n_pairs,
+                                      int32_t max_read_len, const void* d_reads, const void* d_offs, const void* d_lens,
+                                      void* d_out, void* stream) {
+  if (!ix || !p || !pe_in) return K4_ERR_PARAMS;
+  if (n_pairs < 0 || (n_pairs > 0 && (!d_reads || !d_offs || !d_lens || !d_out))) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  const k4_pe_params pe = *pe_in;
+  if (pe.pe_mode < 1 || pe.pe_mode > 4 || pe.pair_min_len < 1 || pe.pair_max_len < pe.pair_min_len)
+    return k4_fail(ix, K4_ERR_PARAMS, "PE parameters out of range");
+  if (n_pairs == 0) return K4_OK;
+  if (n_pairs >= 0x7FFFFFF0ll) return k4_fail(ix, K4_ERR_PARAMS, "at most 2^31-16 pairs per batch");
+  K4_HIP(ix, hipSetDevice(ix->device));
+  // both ends as SE reads with MaxHits = max(m_MaxMLmatches, cMaxMLPEmatches) and the PE classification
+  k4_kalign_params kp = *p;
+  kp.pe_mode = 1;
+  kp.max_ml = std::max(p->max_ml, 10);
+  const int mh = kp.max_ml;
+  int rc = pe_reserve(ix, n_pairs, mh);
+  if (rc != K4_OK) return rc;
+  rc = k4_reserve(ix, 2 * n_pairs, max_read_len, mh);
+  if (rc != K4_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  K4_HIP(ix, hipMemsetAsync(ix->pe_ctl, 0, 16, st));
+  rc = k4_kalign_batch_dev(ix, &kp, 2 * n_pairs, max_read_len, d_reads, d_offs, d_lens, ix->pe_rr, ix->pe_hits, stream);
+  if (rc != K4_OK) return rc;
+  hipLaunchKernelGGL(k4k_pe_pair, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, pe, n_pairs, mh, ix->pe_rr,
+                     ix->pe_hits, (k4_pe_read*)d_out, ix->pe_list, ix->pe_ctl);
+  if (pe.pe_mode == 1 || pe.pe_mode == 3)
+    hipLaunchKernelGGL(k4k_pe_orphans, dim3((unsigned)std::min<int64_t>(n_pairs, 256 * 32)), dim3(64), 0, st, ix->d, pe, p->max_subs,
+                       (const uint8_t*)d_reads, (const uint64_t*)d_offs, (const uint32_t*)d_lens, ix->pe_list,
+                       (k4_pe_read*)d_out, ix->pe_ctl);
+  K4_HIP(ix, hipGetLastError());
+  uint32_t ctl[2] = {0, 0};
+  K4_HIP(ix, hipMemcpyAsync(ctl, ix->pe_ctl, 8, hipMemcpyDeviceToHost, st));
+  K4_HIP(ix, hipStreamSynchronize(st));
+  if (ctl[1])
+    return k4_fail(ix, K4_ERR_UNSUPPORTED, "insert window of 1000 or more loci (reference takes its CoreLen==0 seed path): keep -D minus -d below 1000");
+  return K4_OK;
+}
+
+// Host buffers: interleave the two files' reads, run the device flow in slices, copy the records back.
 extern "C" int k4_kalign_pe_batch(k4_index* ix, const k4_kalign_params* p, const k4_pe_params* pe_in, int64_t n_pairs,
                                   const uint8_t* reads1, const uint64_t* offs1, const uint32_t* lens1,
                                   const uint8_t* reads2, const uint64_t* offs2, const uint32_t* lens2, k4_pe_read* out) {
   if (!ix || !p || !pe_in) return K4_ERR_PARAMS;
   if (n_pairs < 0 || (n_pairs > 0 && (!reads1 || !offs1 || !lens1 || !reads2 || !offs2 || !lens2 || !out)))
     return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
-  const k4_pe_params pe = *pe_in;
-  if (pe.pe_mode < 1 || pe.pe_mode > 4 || pe.pair_min_len < 1 || pe.pair_max_len < pe.pair_min_len)
+  if (pe_in->pe_mode < 1 || pe_in->pe_mode > 4 || pe_in->pair_min_len < 1 || pe_in->pair_max_len < pe_in->pair_min_len)
     return k4_fail(ix, K4_ERR_PARAMS, "PE parameters out of range");
   if (n_pairs == 0) return K4_OK;
-  const int64_t n = n_pairs;
-  // 1. both ends as SE reads with MaxHits = max(m_MaxMLmatches, cMaxMLPEmatches) and the PE classification
-  k4_kalign_params kp = *p;
-  kp.pe_mode = 1;
-  kp.max_ml = std::max(p->max_ml, 10);
-  const int mh = kp.max_ml;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  const int64_t slice = 4 << 20;  // pairs per pass: bounds the staging buffers
   std::vector<uint8_t> cat;
-  std::vector<uint64_t> offs((size_t)2 * n);
-  std::vector<uint32_t> lens((size_t)2 * n);
-  uint64_t tot = 0;
-  for (int64_t i = 0; i < n; i++) tot += (uint64_t)lens1[i] + lens2[i];
-  cat.resize(tot + 16);
-  uint64_t o = 0;
-  for (int64_t i = 0; i < n; i++) {
-    offs[2 * i] = o; lens[2 * i] = lens1[i];
-    memcpy(cat.data() + o, reads1 + offs1[i], lens1[i]);
-    o += lens1[i];
-    offs[2 * i + 1] = o; lens[2 * i + 1] = lens2[i];
-    memcpy(cat.data() + o, reads2 + offs2[i], lens2[i]);
-    o += lens2[i];
+  std::vector<uint64_t> offs;
+  std::vector<uint32_t> lens;
+  uint8_t* d_reads = nullptr;
+  uint64_t* d_offs = nullptr;
+  uint32_t* d_lens = nullptr;
+  k4_pe_read* d_out = nullptr;
+  size_t reads_cap = 0;
+  auto cleanup = [&]() {
+    for (void* q : {(void*)d_reads, (void*)d_offs, (void*)d_lens, (void*)d_out})
+      if (q) hipFree(q);
+  };
+  int rc = K4_OK;
+  const int64_t cap = std::min(n_pairs, slice);
+  if ((rc = k4_check_hip(ix, hipMalloc(&d_offs, (size_t)(2 * cap + 1) * 8), "PE staging")) != K4_OK ||
+      (rc = k4_check_hip(ix, hipMalloc(&d_lens, (size_t)(2 * cap + 1) * 4), "PE staging")) != K4_OK ||
+      (rc = k4_check_hip(ix, hipMalloc(&d_out, (size_t)(2 * cap + 1) * sizeof(k4_pe_read)), "PE staging")) != K4_OK) {
+    cleanup();
+    return rc;
   }
-  std::vector<k4_read_result> rr((size_t)2 * n);
-  std::vector<k4_hit> hits((size_t)2 * n * mh);
-  int rc = k4_kalign_batch(ix, &kp, 2 * n, cat.data(), offs.data(), lens.data(), rr.data(), hits.data());
-  if (rc != K4_OK) return rc;
-
-  // 2. per pair: AlignRead's PE view of each end, ProcCoredApprox's multi x multi resolution, then ProcessPairedEnds up
-  //    to the point where a mate rescue is needed
-  enum { DONE = 0, ORPHAN = 1 };
-  std::vector<uint8_t> state((size_t)n, DONE), f_unal((size_t)n), r_unal((size_t)n);
-  for (int64_t i = 0; i < n; i++) {
-    k4_pe_read& f = out[2 * i];
-    k4_pe_read& r = out[2 * i + 1];
-    for (int e = 0; e < 2; e++) {
-      const k4_read_result& q = rr[2 * i + e];
-      k4_pe_read& d = out[2 * i + e];
-      memset(&d, 0, sizeof(d));
-      d.nar = q.nar; d.num_hits = q.num_hits; d.inst = q.inst; d.low_mm = q.low_mm;
-      if (q.nar == K4_NAR_ACCEPTED) d.hit = hits[(size_t)(2 * i + e) * mh];
+  for (int64_t s0 = 0; s0 < n_pairs && rc == K4_OK; s0 += slice) {
+    const int64_t n = std::min(slice, n_pairs - s0);
+    uint64_t tot = 0;
+    int max_len = 1;
+    for (int64_t i = s0; i < s0 + n; i++) {
+      tot += (uint64_t)lens1[i] + lens2[i];
+      max_len = std::max<int>(max_len, (int)std::max(lens1[i], lens2[i]));
     }
-    const k4_hit* h1 = &hits[(size_t)(2 * i) * mh];
-    const k4_hit* h2 = &hits[(size_t)(2 * i + 1) * mh];
-    if (rr[2 * i].hit_rslt == K4_HR_HITS && rr[2 * i + 1].hit_rslt == K4_HR_HITS && !(f.inst == 1 && r.inst == 1) &&
-        f.inst < 10 && r.inst < 10) {  // KAligner.cpp:10185-10239
-      bool multi = false, accepted = false;
-      k4_hit p1{}, p2{};
-      for (int a = 0; !(multi && !accepted) && a < f.inst; a++)
-        for (int b = 0; b < r.inst; b++)
-          if (accept_prov_pe(pe, 1, h1[a], 1, h2[b]) > 0) {
-            if (!multi) { p1 = h1[a]; p2 = h2[b]; multi = true; accepted = true; }
-            else { accepted = false; break; }
-          }
-      if (accepted) {
-        f.hit = p1; f.nar = K4_NAR_ACCEPTED; f.num_hits = 1;
-        r.hit = p2; r.nar = K4_NAR_ACCEPTED; r.num_hits = 1;
-      }
+    if (max_len > K4_MAX_READ_LEN) { rc = k4_fail(ix, K4_ERR_PARAMS, "read longer than %d bases", K4_MAX_READ_LEN); break; }
+    cat.resize(tot + 16);
+    offs.resize((size_t)2 * n);
+    lens.resize((size_t)2 * n);
+    uint64_t o = 0;
+    for (int64_t i = 0; i < n; i++) {
+      offs[2 * i] = o; lens[2 * i] = lens1[s0 + i];
+      memcpy(cat.data() + o, reads1 + offs1[s0 + i], lens1[s0 + i]);
+      o += lens1[s0 + i];
+      offs[2 * i + 1] = o; lens[2 * i + 1] = lens2[s0 + i];
+      memcpy(cat.data() + o, reads2 + offs2[s0 + i], lens2[s0 + i]);
+      o += lens2[s0 + i];
     }
-    // ProcessPairedEnds, KAligner.cpp:3207-3318
-    f_unal[i] = f.nar == K4_NAR_NS || f.nar == K4_NAR_NOHIT || f.nar == K4_NAR_UNALIGNED;
-    r_unal[i] = r.nar == K4_NAR_NS || r.nar == K4_NAR_NOHIT || r.nar == K4_NAR_UNALIGNED;
-    if (!(f.nar == K4_NAR_ACCEPTED || r.nar == K4_NAR_ACCEPTED)) continue;
-    bool strict_fail = pe.pe_mode == 2 && (f_unal[i] || r_unal[i]);
-    if (!strict_fail && f.nar == K4_NAR_ACCEPTED && r.nar == K4_NAR_ACCEPTED) {
-      int frag = accept_prov_pe(pe, f.num_hits, f.hit, r.num_hits, r.hit);
-      if (frag > 0) { f.pe_aligned = r.pe_aligned = 1; continue; }
-      switch (frag) {
-        case -1: f.nar = r.nar = K4_NAR_PESTRAND; break;
-        case -2: f.nar = r.nar = K4_NAR_PECHROM; break;
-        case -6: f.nar = r.nar = K4_NAR_PEINSERTMIN; break;
-        case -7: f.nar = r.nar = K4_NAR_PEINSERTMAX; break;
-        default: break;
-      }
-      if (pe.pe_mode == 2) strict_fail = true;
+    if (tot + 64 > reads_cap) {
+      if (d_reads) hipFree(d_reads);
+      d_reads = nullptr;
+      if ((rc = k4_check_hip(ix, hipMalloc(&d_reads, tot + 64), "PE staging")) != K4_OK) break;
+      reads_cap = tot + 64;
     }
-    if (strict_fail) {
-      f.num_hits = r.num_hits = 0; f.inst = r.inst = 0;
-      if (f.nar == K4_NAR_ACCEPTED) f.nar = K4_NAR_PENOHIT;
-      if (r.nar == K4_NAR_ACCEPTED) r.nar = K4_NAR_PENOHIT;
-      continue;
-    }
-    state[i] = ORPHAN;
+    hipStream_t st = ix->stream;
+    if ((rc = k4_check_hip(ix, hipMemcpyAsync(d_reads, cat.data(), tot, hipMemcpyHostToDevice, st), "PE upload")) != K4_OK) break;
+    if ((rc = k4_check_hip(ix, hipMemcpyAsync(d_offs, offs.data(), (size_t)2 * n * 8, hipMemcpyHostToDevice, st), "PE upload")) != K4_OK) break;
+    if ((rc = k4_check_hip(ix, hipMemcpyAsync(d_lens, lens.data(), (size_t)2 * n * 4, hipMemcpyHostToDevice, st), "PE upload")) != K4_OK) break;
+    rc = k4_kalign_pe_batch_dev(ix, p, pe_in, n, max_len, d_reads, d_offs, d_lens, d_out, st);
+    if (rc != K4_OK) break;
+    rc = k4_check_hip(ix, hipMemcpy(out + 2 * s0, d_out, (size_t)2 * n * sizeof(k4_pe_read), hipMemcpyDeviceToHost), "PE download");
   }
-
-  // 3. orphan recovery (modes 1 and 3): first the PE1 alignment as anchor (:3320-3418), then PE2 (:3424-3535)
-  if (pe.pe_mode == 1 || pe.pe_mode == 3) {
-    for (int round = 0; round < 2; round++) {
-      std::vector<k4_rescue_task> tasks;
-      std::vector<int64_t> owner;
-      for (int64_t i = 0; i < n; i++) {
-        if (state[i] != ORPHAN) continue;
-        const k4_pe_read& anchor = round == 0 ? out[2 * i] : out[2 * i + 1];
-        const bool mate_unal = round == 0 ? r_unal[i] : f_unal[i];
-        if (!(anchor.num_hits == 1 && !mate_unal)) continue;
-        const bool plus = anchor.hit.strand == '+';
-        k4_rescue_task t;
-        memset(&t, 0, sizeof(t));
-        if (round == 0) { t.b3prime_extend = plus; t.antisense = pe.pair_strand ? !plus : plus; }
-        else {
-          t.b3prime_extend = plus; t.antisense = plus;
-          if (pe.pair_strand) { t.b3prime_extend = !t.b3prime_extend; t.antisense = !t.antisense; }
-        }
-        t.chrom_id = anchor.hit.chrom_id;
-        t.start_loci = anchor.hit.match_loci;
-        t.end_loci = anchor.hit.match_loci + anchor.hit.match_len - 1;
-        const int64_t mate = round == 0 ? 2 * i + 1 : 2 * i;
-        t.read_len = lens[mate];
-        t.read_off = offs[mate];
-        t.min_insert = pe.pair_min_len;
-        t.max_insert = pe.pair_max_len;
-        t.max_allowed_mm = p->max_subs;  // the per-100 bp rate, as the reference passes it (KAligner.cpp:3379, Q15)
-        tasks.push_back(t);
-        owner.push_back(i);
-      }
-      if (tasks.empty()) continue;
-      std::vector<int32_t> res(tasks.size());
-      std::vector<k4_hit> rh(tasks.size());
-      rc = k4_mate_rescue_batch(ix, (int64_t)tasks.size(), tasks.data(), cat.data(), tot, res.data(), rh.data());
-      if (rc != K4_OK) return rc;
-      for (size_t q = 0; q < tasks.size(); q++) {
-        if (res[q] != 1) continue;
-        const int64_t i = owner[q];
-        k4_pe_read& f = out[2 * i];
-        k4_pe_read& r = out[2 * i + 1];
-        const k4_hit& h = rh[q];
-        const uint32_t hs = h.match_loci, he = h.match_loci + h.match_len - 1;
-        const k4_pe_read& anchor = round == 0 ? f : r;
-        const uint32_t as = anchor.hit.match_loci, ae = anchor.hit.match_loci + anchor.hit.match_len - 1;
-        int frag = round == 0 ? pe_insert_size(pe, anchor.hit.strand, as, ae, h.strand, hs, he)
-                              : pe_insert_size(pe, h.strand, hs, he, anchor.hit.strand, as, ae);
-        if (frag <= 0) continue;
-        k4_pe_read& m = round == 0 ? r : f;
-        m.hit = h; m.num_hits = 1; m.low_mm = h.mismatches; m.inst = 1; m.rescued = 1;
-        f.pe_aligned = r.pe_aligned = 1;
-        f.nar = r.nar = K4_NAR_ACCEPTED;
-        state[i] = DONE;
-      }
-    }
-  }
-
-  // 4. what is left could not be accepted as a pair (:3538-3585)
-  for (int64_t i = 0; i < n; i++) {
-    if (state[i] != ORPHAN) continue;
-    k4_pe_read& f = out[2 * i];
-    k4_pe_read& r = out[2 * i + 1];
-    if (!(pe.pe_mode == 3 || pe.pe_mode == 4)) {
-      f.num_hits = r.num_hits = 0; f.inst = r.inst = 0;
-      if (f.nar == K4_NAR_ACCEPTED) f.nar = K4_NAR_PENOHIT;
-      if (r.nar == K4_NAR_ACCEPTED) r.nar = K4_NAR_PENOHIT;
-      continue;
-    }
-    for (k4_pe_read* e : {&f, &r}) {
-      if (e->num_hits != 1) { e->num_hits = 0; e->inst = 0; if (e->nar == K4_NAR_ACCEPTED) e->nar = K4_NAR_PEUNALIGN; }
-      else e->nar = K4_NAR_ACCEPTED;
-    }
-  }
-  return K4_OK;
+  cleanup();
+  return rc;
 }

@@ -267,6 +267,23 @@ def test_pe_flow_vs_oracle(k4, oracle, golden_dir, pe_mode, pair_strand):
     assert np.array_equal(g["hit"][acc], o["hit"][acc])
     if pe_mode in (1, 3) and not pair_strand:
         assert g["rescued"].sum() > 0
+    # the device-resident entry point on the same pairs (reads interleaved in HBM) returns the same records
+    import torch
+
+    inter = [x for pair in zip(pe1, pe2) for x in pair]
+    lens = np.array([len(x) for x in inter], dtype=np.uint32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    cat = np.concatenate(inter + [np.zeros(16, np.uint8)])
+    dev = torch.device("cuda:0")
+    d_reads, d_offs = torch.from_numpy(cat).to(dev), torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_lens = torch.from_numpy(lens.view(np.int32)).to(dev)
+    d_out = torch.zeros(len(inter) * k4.PE_READ_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 10, 1, 0, 0)
+    pp = k4.PeParams(pe_mode, 220, 640, 1 if pair_strand else 0)
+    ix.kalign_pe_batch_dev(kp, pp, len(pe1), int(lens.max()), d_reads.data_ptr(), d_offs.data_ptr(), d_lens.data_ptr(),
+                           d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    gd = d_out.cpu().numpy().view(k4.PE_READ_DTYPE)
+    assert np.array_equal(gd, g)
     ix.close()
     oracle.close(ho)
 
