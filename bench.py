@@ -55,6 +55,20 @@ def make_genome(dev, n_chrom, chrom_len):
     return seq
 
 
+def mutate(r, g, dev):
+    """In place: Poisson(1) substitutions truncated at 8, distinct uniform positions, new base != old.  Returns the counts."""
+    m, read_len = r.shape
+    nsubs = torch.poisson(torch.ones(m, device=dev), generator=g).clamp_(max=8).to(torch.int64)
+    score = torch.rand((m, read_len), device=dev, generator=g)
+    pos = score.topk(8, dim=1).indices  # 8 distinct uniform positions
+    use = torch.arange(8, device=dev)[None, :] < nsubs[:, None]
+    delta = torch.randint(1, 4, (m, 8), device=dev, generator=g, dtype=torch.uint8)
+    old = r.gather(1, pos)
+    new = torch.where(use, (old + delta) % 4, old)
+    r.scatter_(1, pos, new)
+    return nsubs
+
+
 def make_reads(seq, n_chrom, chrom_len, n_reads, read_len, seed, dev, chunk=1 << 20):
     """simreads semantics: uniform start, strand 50/50, substitutions ~ Poisson(1) truncated at 8 at
     distinct uniform positions, substituted base != original.  Returns reads [n, L] u8 and truth [n, 4] i64."""
@@ -71,14 +85,7 @@ def make_reads(seq, n_chrom, chrom_len, n_reads, read_len, seed, dev, chunk=1 <<
         off = u - c * valid
         start = c * (chrom_len + 1) + off
         r = seq[start[:, None] + ar[None, :]]
-        nsubs = torch.poisson(torch.ones(m, device=dev), generator=g).clamp_(max=8).to(torch.int64)
-        score = torch.rand((m, read_len), device=dev, generator=g)
-        pos = score.topk(8, dim=1).indices  # 8 distinct uniform positions
-        use = torch.arange(8, device=dev)[None, :] < nsubs[:, None]
-        delta = torch.randint(1, 4, (m, 8), device=dev, generator=g, dtype=torch.uint8)
-        old = r.gather(1, pos)
-        new = torch.where(use, (old + delta) % 4, old)
-        r.scatter_(1, pos, new)
+        nsubs = mutate(r, g, dev)
         strand = torch.randint(0, 2, (m,), device=dev, generator=g)
         rc = (3 - r).flip(1)
         r = torch.where(strand[:, None] == 1, rc, r)
@@ -87,7 +94,46 @@ def make_reads(seq, n_chrom, chrom_len, n_reads, read_len, seed, dev, chunk=1 <<
         truth[b:b + m, 1] = off
         truth[b:b + m, 2] = strand
         truth[b:b + m, 3] = nsubs
-        del r, rc, score, pos, use, delta, old, new
+        del r, rc
+    return reads, truth
+
+
+def make_pe_reads(seq, n_chrom, chrom_len, n_pairs, read_len, seed, dev, frag_min=300, frag_max=500, chunk=1 << 20):
+    """`simreads -p` semantics: fragment length uniform in [frag_min, frag_max], fragment strand 50/50,
+    PE1 = the fragment's 5' end, PE2 = reverse complement of its 3' end, substitutions per end as for SE reads.
+    Returns interleaved reads [2n, L] u8 (2i = PE1, 2i+1 = PE2) and truth [2n, 4] i64 (chrom, start, strand, nsubs)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    reads = torch.empty((2 * n_pairs, read_len), dtype=torch.uint8, device=dev)
+    truth = torch.empty((2 * n_pairs, 4), dtype=torch.int64, device=dev)
+    valid = chrom_len - frag_max + 1
+    ar = torch.arange(read_len, device=dev)
+    for b in range(0, n_pairs, chunk):
+        m = min(chunk, n_pairs - b)
+        u = torch.randint(0, n_chrom * valid, (m,), device=dev, generator=g)
+        c = u // valid
+        off = u - c * valid
+        flen = torch.randint(frag_min, frag_max + 1, (m,), device=dev, generator=g)
+        fstrand = torch.randint(0, 2, (m,), device=dev, generator=g)
+        base = c * (chrom_len + 1) + off
+        left = seq[base[:, None] + ar[None, :]]                          # fragment's leftmost read_len bases
+        right = seq[(base + flen - read_len)[:, None] + ar[None, :]]     # and its rightmost
+        rrc = (3 - right).flip(1)
+        fwd = (fstrand == 0)[:, None]
+        pe1 = torch.where(fwd, left, rrc)   # '+' fragment: PE1 reads the left end forward; '-': revcomp of the right end
+        pe2 = torch.where(fwd, rrc, left)   # PE2 = revcomp of the fragment's 3' end
+        ns1 = mutate(pe1, g, dev)
+        ns2 = mutate(pe2, g, dev)
+        sl = slice(2 * b, 2 * (b + m))
+        reads[sl][0::2] = pe1
+        reads[sl][1::2] = pe2
+        t = truth[sl]
+        t[0::2, 0] = c + 1; t[1::2, 0] = c + 1
+        t[0::2, 1] = torch.where(fstrand == 0, off, off + flen - read_len)
+        t[1::2, 1] = torch.where(fstrand == 0, off + flen - read_len, off)
+        t[0::2, 2] = fstrand; t[1::2, 2] = 1 - fstrand
+        t[0::2, 3] = ns1; t[1::2, 3] = ns2
+        del left, right, rrc, pe1, pe2
     return reads, truth
 
 
@@ -96,15 +142,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chroms", type=int, default=24)
+    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
+                    help="c2 (default, the BASELINE metric's configuration): 50 M x 100 bp SE vs 3 Gbp, -s2; "
+                         "c3: 50 M pairs 2x150 bp vs 3 Gbp, -s2 -U2 -d200 -D600; c5: 2x150 bp pairs vs 15 Gbp, -s3 -U2 "
+                         "(40 M pairs per step: the 200 M of BASELINE config 5 do not fit one GPU next to the 162 GB index)")
+    ap.add_argument("--chroms", type=int, default=None)
     ap.add_argument("--chrom-mbp", type=float, default=125.0)
-    ap.add_argument("--reads", type=int, default=50_000_000)
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--max-subs", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=None, help="reads (SE) or pairs (PE) per GPU per step")
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--max-subs", type=int, default=None)
     ap.add_argument("--kmer-k", type=int, default=0)
     ap.add_argument("--n-frac", type=float, default=0.0, help="fraction of reads given one N (general-kernel stress; not the BASELINE workload)")
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="upper bound on reads timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
+    wl = {"c2": (24, 50_000_000, 100, 2, False), "c3": (24, 50_000_000, 150, 2, True), "c5": (120, 40_000_000, 150, 3, True)}[args.workload]
+    args.chroms = wl[0] if args.chroms is None else args.chroms
+    args.reads = wl[1] if args.reads is None else args.reads
+    args.read_len = wl[2] if args.read_len is None else args.read_len
+    args.max_subs = wl[3] if args.max_subs is None else args.max_subs
+    pe = wl[4]
+    std_cfg = (args.chroms, args.reads, args.read_len, args.max_subs) == wl[:4] and args.chrom_mbp == 125.0 and args.n_frac == 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,8 +200,12 @@ def main():
     log(rank, "index packed: k=%d, %.1f GB in HBM, %.1fs" % (info["kmer_k"], info["device_bytes"] / 1e9, time.time() - t0))
 
     t0 = time.time()
-    n_reads = args.reads
-    reads, truth = make_reads(seq, n_chrom, chrom_len, n_reads, L, READS_SEED + rank, dev)
+    n_units = args.reads                    # reads (SE) or pairs (PE)
+    n_reads = 2 * n_units if pe else n_units  # reads through the SE pass
+    if pe:
+        reads, truth = make_pe_reads(seq, n_chrom, chrom_len, n_units, L, READS_SEED + 2 + rank, dev)
+    else:
+        reads, truth = make_reads(seq, n_chrom, chrom_len, n_reads, L, READS_SEED + rank, dev)
     if args.n_frac > 0:
         g2 = torch.Generator(device=dev)
         g2.manual_seed(7)
@@ -153,18 +214,26 @@ def main():
         truth[sel, 3] = 99  # excluded from the truth property below
     offs = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
     lens = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
-    out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
-    hits = torch.zeros((n_reads, 4), dtype=torch.int32, device=dev)
+    if pe:
+        out_pe = torch.zeros((n_reads, 10), dtype=torch.int32, device=dev)  # k4_pe_read records (40 B)
+    else:
+        out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
+        hits = torch.zeros((n_reads, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     log(rank, "%d reads x %d bp synthesised in %.1fs" % (n_reads, L, time.time() - t0))
 
     kp = k4.KalignParams(args.max_subs, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
-    ix.reserve(n_reads, L, 1)
+    pp = k4.PeParams(2, 200, 600, 0)  # -U2 -d200 -D600
+    ix.reserve(n_reads, L, 10 if pe else 1)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        ix.kalign_batch_dev(kp, n_reads, L, reads.data_ptr(), offs.data_ptr(), lens.data_ptr(), out.data_ptr(),
-                            hits.data_ptr(), stream)
+        if pe:
+            ix.kalign_pe_batch_dev(kp, pp, n_units, L, reads.data_ptr(), offs.data_ptr(), lens.data_ptr(),
+                                   out_pe.data_ptr(), stream)
+        else:
+            ix.kalign_batch_dev(kp, n_reads, L, reads.data_ptr(), offs.data_ptr(), lens.data_ptr(), out.data_ptr(),
+                                hits.data_ptr(), stream)
 
     def barrier():
         if world > 1:
@@ -193,7 +262,11 @@ def main():
     ctr = ix.counters()
 
     # ---- after the timed region: the count/merge collective and the parity checks --------------------------------
-    nar_hist = torch.bincount(out[:, 4].to(torch.int64), minlength=8)[:8]
+    if pe:  # the SE-shaped views of the PE records: nar, and the 16-byte hit
+        out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
+        out[:, 4] = out_pe[:, 0]
+        hits = out_pe[:, 6:10].contiguous()
+    nar_hist = torch.bincount(out[:, 4].to(torch.int64), minlength=20)[:20]
     if world > 1:
         dist.all_reduce(nar_hist, op=dist.ReduceOp.SUM)  # RCCL: the only collective on this path
     nar = nar_hist.tolist()
@@ -201,6 +274,9 @@ def main():
     # (1) truth property on i.i.d. genomes: AA at the truth locus with Mismatches == nsubs iff nsubs <= MaxTotMM, else NL
     max_tot_mm = 0 if args.max_subs == 0 else max(1, int(0.5 + L * args.max_subs / 100.0))
     ok = truth[:, 3] <= max_tot_mm
+    if pe:  # -U2: a pair is reported only when both ends are placed; then both are proper-pair flagged
+        both = ok[0::2] & ok[1::2]
+        ok = torch.repeat_interleave(both, 2)
     hv = hits.view(torch.uint8).view(n_reads, 16)
     h_chrom = hits[:, 0].to(torch.int64)
     h_loci = hits[:, 1].to(torch.int64) & 0xFFFFFFFF
@@ -210,8 +286,10 @@ def main():
         ok,
         (out[:, 4] == k4.NAR_ACCEPTED) & (h_chrom == truth[:, 0]) & (h_loci == truth[:, 1]) & (h_mm == truth[:, 3])
         & ((h_strand == ord("-")) == (truth[:, 2] == 1)),
-        out[:, 4] == k4.NAR_NOHIT,
+        (out[:, 4] != k4.NAR_ACCEPTED) if pe else (out[:, 4] == k4.NAR_NOHIT),
     ))
+    if pe:
+        good &= torch.where(ok, out_pe[:, 4] == 1, out_pe[:, 4] == 0)  # FlgPEAligned
     truth_viol = int((~good).sum().item())
 
     # (2) CPU baseline = the oracle on all host cores over a bounded sample, same index, same reads (rank 0, N=1 only)
@@ -240,7 +318,18 @@ def main():
         cores = max(1, min(len(os.sched_getaffinity(0)), 16))
         l_all = np.full(min(args.cpu_sample, n_reads), L, dtype=np.uint32)
 
-        def run_cpu(a, b):
+        def run_cpu(a, b):  # reads [a, b) (PE: a and b even, i.e. whole pairs)
+            if pe:
+                from oracle_bindings import oracle_kalign_pe
+
+                m = (b - a) // 2
+                c1 = reads[a:b:2].cpu().numpy().reshape(-1)
+                c2 = reads[a + 1:b:2].cpu().numpy().reshape(-1)
+                o_h = (np.arange(m, dtype=np.uint64) * L)
+                t0 = time.perf_counter()
+                r = oracle_kalign_pe(O, ho, (c1, o_h, l_all[:m]), (c2, o_h, l_all[:m]), pe_mode=2, pair_min_len=200,
+                                     pair_max_len=600, threads=cores, max_subs=args.max_subs)
+                return r, time.perf_counter() - t0
             cat = reads[a:b].cpu().numpy().reshape(-1)
             o_h = (np.arange(b - a, dtype=np.uint64) * L)
             t0 = time.perf_counter()
@@ -250,17 +339,24 @@ def main():
         # pilot on 50k reads (also warms the page cache of the 15 GB index), then a sample sized for ~15 s of CPU work
         S0 = min(50_000, n_reads)
         _, t_pilot = run_cpu(0, S0)
-        S = int(max(S0, min(args.cpu_sample, n_reads, 15.0 * S0 / max(t_pilot, 1e-3))))
+        S = int(max(S0, min(args.cpu_sample, n_reads, 15.0 * S0 / max(t_pilot, 1e-3)))) & ~1
         ro, t_cpu = run_cpu(0, S)
         cpu = {"value": S / t_cpu / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port",
                "sample": "first %d of the %d reads, same index (%.2f Gbp), oracle/k4oracle.c on %d threads, %.1f s"
                          % (S, n_reads, n_chrom * chrom_len / 1e9, cores, t_cpu)}
-        g_out = out[:S].cpu().numpy()
-        g_hits = hits[:S].cpu().numpy().view(np.uint8).reshape(S, 16)
-        o_out = ro["out"].view(np.int32).reshape(S, 6)
-        o_hits = ro["hits"][:, 0].view(np.uint8).reshape(S, 16)
-        parity_sample = {"reads": S, "result_mismatches": int((g_out != o_out).any(axis=1).sum()),
-                         "hit_mismatches": int((g_hits != o_hits).any(axis=1).sum())}
+        if pe:
+            g_rec = out_pe[:S].cpu().numpy().view(np.uint8).reshape(S, 40)
+            o_rec = ro.view(np.uint8).reshape(S, 40)
+            acc = g_rec.view(np.int32)[:, 0] == k4.NAR_ACCEPTED
+            parity_sample = {"reads": S, "result_mismatches": int((g_rec[:, :24] != o_rec[:, :24]).any(axis=1).sum()),
+                             "hit_mismatches": int((g_rec[acc, 24:] != o_rec[acc, 24:]).any(axis=1).sum())}
+        else:
+            g_out = out[:S].cpu().numpy()
+            g_hits = hits[:S].cpu().numpy().view(np.uint8).reshape(S, 16)
+            o_out = ro["out"].view(np.int32).reshape(S, 6)
+            o_hits = ro["hits"][:, 0].view(np.uint8).reshape(S, 16)
+            parity_sample = {"reads": S, "result_mismatches": int((g_out != o_out).any(axis=1).sum()),
+                             "hit_mismatches": int((g_hits != o_hits).any(axis=1).sum())}
         O.close(ho)
 
     if rank == 0:
@@ -275,17 +371,14 @@ def main():
         alg_bytes = per_launch["n_lookup"] * b_lookup + per_launch["n_cand"] * b_cand + per_launch["n_reads"] * (L + 16)
         k_ms = fast_ms / max(launches, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        full = args.workload == "c2" and std_cfg
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch") if full else None
-            except Exception:
-                traffic = None
-        full = (n_chrom == 24 and chrom_len == 125_000_000 and n_reads == 50_000_000 and L == 100 and args.max_subs == 2
-                and args.n_frac == 0)
+        if full and os.path.exists(pmc):  # PMC-measured HBM bytes of the same launches (profiles/run_profile_pmc.sh)
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
-            "metric": "Mreads/sec aligned (100 bp SE vs 3 Gbp .sfx)",
+            "metric": "Mreads/sec aligned (100 bp SE vs 3 Gbp .sfx)" if not pe else
+                      "Mreads/sec aligned (2x%d bp PE vs %.0f Gbp .sfx; both ends counted)" % (L, n_chrom * chrom_len / 1e9),
             "value": value,
             "unit": "Mreads/s",
             "n_gpus": world,
@@ -298,9 +391,12 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": ("C2: %d x %d bp SE reads per GPU vs %.2f Gbp synthetic genome (%d x %d bp), kalign -s%d"
-                             % (n_reads, L, n_chrom * chrom_len / 1e9, n_chrom, chrom_len, args.max_subs))
-                + ("" if full else " [REDUCED: not the BASELINE configuration]"),
+                "workload": ("%s: %d x %s%d bp %s per GPU vs %.2f Gbp synthetic genome (%d x %d bp), kalign -s%d%s"
+                             % (args.workload.upper(), n_units, "2x" if pe else "", L, "pairs" if pe else "SE reads",
+                                n_chrom * chrom_len / 1e9, n_chrom, chrom_len, args.max_subs,
+                                " -U2 -d200 -D600" if pe else ""))
+                + ("" if std_cfg else " [REDUCED: not the named configuration]")
+                + ("" if args.workload == "c2" else " [not the BASELINE metric's configuration, which is C2]"),
                 "reads_per_gpu": n_reads, "read_len": L, "genome_bp": n_chrom * chrom_len, "sfx_el_size": el,
                 "kmer_table_k": info["kmer_k"], "index_hbm_gb": round(info["device_bytes"] / 1e9, 2),
                 "parallelism": "reads sharded per GPU, index replicated, RCCL all-reduce of NAR counts only",
@@ -319,7 +415,8 @@ def main():
                 "slow_path_reads_per_launch": per_launch["n_slow"],
             },
             "cpu_baseline": cpu,
-            "parity": {"nar_histogram": {"AA": nar[1], "EN": nar[2], "NL": nar[3], "MH": nar[4], "ML": nar[5]},
+            "parity": {"nar_histogram": {"AA": nar[1], "EN": nar[2], "NL": nar[3], "MH": nar[4], "ML": nar[5], "UP": nar[15],
+                                         "other": int(sum(nar)) - nar[1] - nar[2] - nar[3] - nar[4] - nar[5] - nar[15]},
                        "truth_property_violations_rank0": truth_viol, "oracle_sample": parity_sample},
         }
         print(json.dumps(line), flush=True)
