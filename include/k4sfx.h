@@ -30,6 +30,7 @@ enum {
   K4_ERR_PARAMS = -100,    /* eBSFerrParams */
   K4_ERR_MEM = -95,        /* eBSFerrMem */
   K4_ERR_NOT_SFX = -94,    /* eBSFerrNotBioseq */
+  K4_ERR_NOT_FASTA = -93,  /* eBSFerrNotFasta */
   K4_ERR_OPEN_FILE = -90,  /* eBSFerrOpnFile */
   K4_ERR_CREATE_FILE = -89,/* eBSFerrCreateFile */
   K4_ERR_FILE_VER = -86,   /* eBSFerrFileVer */
@@ -229,6 +230,57 @@ int k4_kalign_pe_batch(k4_index* ix, const k4_kalign_params* p, const k4_pe_para
 int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, const k4_pe_params* pe, int64_t n_pairs,
                            int32_t max_read_len, const void* d_reads, const void* d_offs, const void* d_lens,
                            void* d_out, void* stream);
+
+/* ---- read ingest and SAM emit on the device ----------------------------------------------
+ * k4_parse_fastx_dev   <- CKAligner::LoadRawReads (KAligner.cpp:11648-12421) over CFasta: FASTA ('>', sequence over any
+ *                         number of lines) or FASTQ ('@', four lines per record) text resident in HBM -> etSeqBase reads
+ *                         (a/c/g/t/u either case -> 0..3, any other non-blank -> 4), offsets, lengths, and the span of
+ *                         each descriptor's first token (<= 127 bytes).  A chunk that is not the last one may end inside a
+ *                         record: info->consumed tells how many bytes were used; resubmit the rest in front of the next
+ *                         chunk.  The bases go to d_reads[reads_base ...) (room for text_bytes + 16 bytes), offs are
+ *                         relative to d_reads; name offsets are text_base + offset in this chunk; the per-record arrays
+ *                         hold max_records elements.
+ * k4_prepare_reads_dev <- the length filter of LoadRawReads (:12024-12060; a pair is dropped when either mate fails) and
+ *                         the PE1/PE2 interleave: slots of dropped reads stay in place with length 0.
+ * k4_format_sam_dev    <- WriteBAMReadHits (:5718-5914) / ReportBAMread (:5957-6320) / SortHitMatch (:10969) /
+ *                         CSAMfile::AddAlignment (SAMfile.cpp:2194-2377): the accepted reads as SAM lines in coordinate
+ *                         order (chrom, start, len, strand, mismatches, then load order), in a buffer this call
+ *                         allocates (*d_sam, release with k4_free_device); header lines are the caller's.  Also the
+ *                         ReportAlignStats tallies and which chromosomes received a hit (for the @SQ rule of :5785-5821). */
+enum { K4_FASTA = 1, K4_FASTQ = 2 };
+typedef struct {
+  uint64_t n_records;
+  uint64_t consumed;     /* text bytes that belonged to the records returned */
+  uint64_t n_bases;
+  uint32_t max_len;
+  uint32_t format;       /* K4_FASTA | K4_FASTQ */
+} k4_parse_info;
+typedef struct {          /* where the QNAMEs live: [0] the reads / PE1 file, [1] the PE2 file (PE only) */
+  const void* d_text[2];
+  const void* d_name_off[2]; /* uint64 per record: byte offset into d_text */
+  const void* d_name_len[2]; /* uint32 per record */
+} k4_sam_names;
+typedef struct {
+  uint64_t nar[20];      /* reads per eNAR value (slots of dropped reads are not counted) */
+  uint64_t plus, minus;  /* accepted alignments per strand */
+  uint64_t n_lines;      /* SAM lines written */
+} k4_sam_stats;
+int k4_parse_fastx_dev(k4_index* ix, const void* d_text, uint64_t text_bytes, uint64_t text_base, int final_chunk,
+                       int format /* 0: from the first byte */, int64_t max_records, void* d_reads, uint64_t reads_base,
+                       void* d_offs, void* d_lens, void* d_name_off, void* d_name_len, k4_parse_info* info, void* stream);
+int k4_prepare_reads_dev(k4_index* ix, int pe, int64_t n_units, int32_t min_len, int32_t max_len, const void* d_offs1,
+                         const void* d_lens1, const void* d_offs2, const void* d_lens2, uint64_t reads2_base,
+                         void* d_offs_out, void* d_lens_out, uint64_t* n_under, uint64_t* n_over, uint32_t* max_read_len,
+                         void* stream);
+int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                      const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens,
+                      const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
+                      uint8_t* chrom_hit /* host, n_entries + 1 bytes, or NULL */, void* stream);
+void k4_free_device(void* p);
+/* device memory for host programs that use the *_dev entry points without a HIP runtime of their own */
+int k4_alloc_device(k4_index* ix, uint64_t bytes, void** d_ptr);
+int k4_copy_to_device(k4_index* ix, void* d_dst, const void* src, uint64_t bytes);
+int k4_copy_to_host(k4_index* ix, void* dst, const void* d_src, uint64_t bytes);
 
 /* kernel timing for roofline measurement: when enabled, every batch brackets the dominant kernel (k4k_align_fast) with
  * HIP events on the stream it is launched on; k4_get_kernel_times synchronises, returns the summed duration and the

@@ -69,6 +69,22 @@ PE_READ_DTYPE = np.dtype(
 )
 
 
+class ParseInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("consumed", C.c_uint64), ("n_bases", C.c_uint64), ("max_len", C.c_uint32),
+                ("format", C.c_uint32)]
+
+
+class SamNames(C.Structure):
+    _fields_ = [("d_text", C.c_void_p * 2), ("d_name_off", C.c_void_p * 2), ("d_name_len", C.c_void_p * 2)]
+
+
+class SamStats(C.Structure):
+    _fields_ = [("nar", C.c_uint64 * 20), ("plus", C.c_uint64), ("minus", C.c_uint64), ("n_lines", C.c_uint64)]
+
+
+FASTA, FASTQ = 1, 2
+
+
 class Counters(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_lookup", C.c_uint64), ("n_probe", C.c_uint64), ("n_cand", C.c_uint64),
                 ("n_slow", C.c_uint64), ("n_bases", C.c_uint64)]
@@ -83,6 +99,8 @@ ABI_SYMBOLS = [
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
     "k4_get_kernel_times", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
+    "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
+    "k4_copy_to_device", "k4_copy_to_host",
 ]
 
 
@@ -136,6 +154,16 @@ def lib():
     L.k4_mate_rescue_batch.argtypes = [vp, i64, vp, vp, u64, vp, vp]
     L.k4_kalign_pe_batch.argtypes = [vp, C.POINTER(KalignParams), C.POINTER(PeParams), i64] + [vp] * 7
     L.k4_kalign_pe_batch_dev.argtypes = [vp, C.POINTER(KalignParams), C.POINTER(PeParams), i64, C.c_int32] + [vp] * 5
+    L.k4_parse_fastx_dev.argtypes = [vp, vp, u64, u64, i32, i32, i64, vp, u64, vp, vp, vp, vp, C.POINTER(ParseInfo), vp]
+    L.k4_prepare_reads_dev.argtypes = [vp, i32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, u64, vp, vp,
+                                       C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), vp]
+    L.k4_format_sam_dev.argtypes = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, C.POINTER(SamNames), C.POINTER(vp),
+                                    C.POINTER(u64), C.POINTER(SamStats), vp, vp]
+    L.k4_free_device.argtypes = [vp]
+    L.k4_free_device.restype = None
+    L.k4_alloc_device.argtypes = [vp, u64, C.POINTER(vp)]
+    L.k4_copy_to_device.argtypes = [vp, vp, vp, u64]
+    L.k4_copy_to_host.argtypes = [vp, vp, vp, u64]
     _lib = L
     return L
 
@@ -311,6 +339,98 @@ class SfxIndex:
                                           l1.ctypes.data, c2.ctypes.data, o2.ctypes.data, l2.ctypes.data,
                                           out.ctypes.data))
         return out
+
+    # -- read ingest and SAM emit on the device ----------------------------------------------------------------------
+    def parse_fastx(self, text, fmt=0, chunk_bytes=None, device=None):
+        """FASTA / FASTQ bytes -> dict of device tensors (reads u8, offs i64, lens i32, name_off i64, name_len i32) plus
+        the text tensor they point into.  chunk_bytes < len(text) exercises the chunked protocol."""
+        import torch
+
+        dev = torch.device("cuda", self.info()["device"]) if device is None else device
+        raw = np.frombuffer(bytes(text), dtype=np.uint8)
+        T = len(raw)
+        d_text = torch.from_numpy(np.concatenate([raw, np.zeros(16, np.uint8)])).to(dev)
+        cap = int((raw == 10).sum()) // 2 + 4
+        d_reads = torch.zeros(T + 32, dtype=torch.uint8, device=dev)
+        d_offs = torch.zeros(cap, dtype=torch.int64, device=dev)
+        d_lens = torch.zeros(cap, dtype=torch.int32, device=dev)
+        d_noff = torch.zeros(cap, dtype=torch.int64, device=dev)
+        d_nlen = torch.zeros(cap, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        pos, n, bases, max_len = 0, 0, 0, 0
+        chunk = T if not chunk_bytes else chunk_bytes
+        while pos < T:
+            ln = min(chunk, T - pos)
+            final = 1 if pos + ln == T else 0
+            info = ParseInfo()
+            self._ck(lib().k4_parse_fastx_dev(self.h, d_text.data_ptr() + pos, ln, pos, final, fmt, cap - n, d_reads.data_ptr(),
+                                              bases, d_offs.data_ptr() + 8 * n, d_lens.data_ptr() + 4 * n,
+                                              d_noff.data_ptr() + 8 * n, d_nlen.data_ptr() + 4 * n, C.byref(info), st))
+            fmt = info.format or fmt
+            if info.consumed == 0:
+                if final:
+                    break
+                chunk *= 2  # a record longer than the chunk
+                continue
+            n += info.n_records
+            bases += info.n_bases
+            max_len = max(max_len, info.max_len)
+            pos += info.consumed
+        return {"n": n, "n_bases": bases, "max_len": max_len, "format": fmt, "text": d_text, "reads": d_reads,
+                "offs": d_offs[:n], "lens": d_lens[:n], "name_off": d_noff[:n], "name_len": d_nlen[:n]}
+
+    def prepare_reads(self, p1, p2=None, min_len=50, max_len=500):
+        """length filter (+ PE interleave) over parse_fastx results; PE needs both parsed into ONE reads buffer, so
+        p2's reads are appended behind p1's here."""
+        import torch
+
+        pe = p2 is not None
+        n = p1["n"]
+        dev = p1["reads"].device
+        if pe:
+            assert p2["n"] == n
+            reads = torch.cat([p1["reads"][: p1["n_bases"]], p2["reads"][: p2["n_bases"] + 16]])
+        else:
+            reads = p1["reads"]
+        tot = 2 * n if pe else n
+        d_offs = torch.zeros(max(tot, 1), dtype=torch.int64, device=dev)
+        d_lens = torch.zeros(max(tot, 1), dtype=torch.int32, device=dev)
+        under, over, ml = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        self._ck(lib().k4_prepare_reads_dev(self.h, 1 if pe else 0, n, min_len, max_len, p1["offs"].data_ptr(),
+                                            p1["lens"].data_ptr(), p2["offs"].data_ptr() if pe else None,
+                                            p2["lens"].data_ptr() if pe else None, p1["n_bases"] if pe else 0,
+                                            d_offs.data_ptr(), d_lens.data_ptr(), C.byref(under), C.byref(over), C.byref(ml),
+                                            torch.cuda.current_stream().cuda_stream))
+        return {"reads": reads, "offs": d_offs[:tot], "lens": d_lens[:tot], "n_under": under.value, "n_over": over.value,
+                "max_len": ml.value, "n_units": n, "pe": pe}
+
+    def format_sam(self, prep, p1, p2=None, rr=None, hits=None, max_ml=1, pe_recs=None):
+        """SAM body (bytes), stats dict and per-chromosome hit flags for device-resident results."""
+        import torch
+
+        names = SamNames()
+        for w, p in enumerate([p1, p2]):
+            if p is not None:
+                names.d_text[w] = p["text"].data_ptr()
+                names.d_name_off[w] = p["name_off"].data_ptr()
+                names.d_name_len[w] = p["name_len"].data_ptr()
+        d_sam, nbytes, stats = C.c_void_p(), C.c_uint64(), SamStats()
+        ne = self.info()["n_entries"]
+        chrom_hit = np.zeros(ne + 1, dtype=np.uint8)
+        self._ck(lib().k4_format_sam_dev(self.h, 1 if prep["pe"] else 0, prep["n_units"],
+                                         rr.data_ptr() if rr is not None else None,
+                                         hits.data_ptr() if hits is not None else None, max_ml,
+                                         pe_recs.data_ptr() if pe_recs is not None else None, prep["reads"].data_ptr(),
+                                         prep["offs"].data_ptr(), prep["lens"].data_ptr(), C.byref(names), C.byref(d_sam),
+                                         C.byref(nbytes), C.byref(stats), chrom_hit.ctypes.data,
+                                         torch.cuda.current_stream().cuda_stream))
+        body = b""
+        if nbytes.value:
+            buf = np.empty(nbytes.value, dtype=np.uint8)
+            self._ck(lib().k4_copy_to_host(self.h, buf.ctypes.data, d_sam, nbytes.value))
+            body = buf.tobytes()
+        lib().k4_free_device(d_sam)
+        return body, {"nar": list(stats.nar), "plus": stats.plus, "minus": stats.minus, "n_lines": stats.n_lines}, chrom_hit
 
     # -- the hot path (device buffers; pointers are ints, e.g. torch.Tensor.data_ptr()) -------------------------
     def kalign_pe_batch_dev(self, params, pe_params, n_pairs, max_read_len, d_reads, d_offs, d_lens, d_out, stream=0):

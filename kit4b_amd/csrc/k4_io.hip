@@ -1,0 +1,630 @@
+// kit4b_amd/csrc/k4_io.hip -- the two ends of the read pipeline on the device.
+//
+//   k4_parse_fastx_dev   FASTA / FASTQ text in HBM -> etSeqBase reads, offsets, lengths, descriptor spans
+//                        <- CKAligner::LoadRawReads  ngskit4b/KAligner.cpp:11648-12421 (descriptor = first token of the
+//                           header line, bases a/c/g/t/u in either case -> 0..3, anything else that is not white space -> N)
+//   k4_format_sam_dev    alignment records in HBM -> coordinate-sorted SAM text in HBM
+//                        <- CKAligner::WriteBAMReadHits :5718-5914, ReportBAMread :5957-6320, SortHitMatch :10969,
+//                           CSAMfile::AddAlignment libkit4b/SAMfile.cpp:2194-2377
+// Both are bandwidth-bound byte shuffles: newline positions by a flagged select, one thread per record for the
+// bookkeeping, one wave per record for the byte moves (coalesced along the line).
+#include <string.h>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+#include "k4_device.h"
+
+namespace {
+
+struct IsNewline {
+  __device__ __host__ uint8_t operator()(uint8_t c) const { return c == '\n'; }
+};
+
+K4_DEV bool k4d_is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+K4_DEV uint8_t k4d_base_code(uint8_t c) {
+  switch (c | 0x20) {  // lower-case the letters
+    case 'a': return 0;
+    case 'c': return 1;
+    case 'g': return 2;
+    case 't': case 'u': return 3;
+    default: return 4;
+  }
+}
+
+struct K4FastxArgs {
+  const uint8_t* text;
+  uint64_t text_bytes;   // bytes that belong to whole records (end of the last one)
+  const uint32_t* nl;    // line j ends at nl[j] (offset of its '\n', or text end for an unterminated last line)
+  const uint32_t* hdr;   // FASTA: line numbers of the header lines
+  uint64_t n_hdr;        // FASTA: headers found (one more than n_rec when the last record is left for the next chunk)
+  int64_t n_rec;
+  int fastq;
+  uint64_t text_base;
+  uint32_t* seq_off;     // out: offset of the first sequence byte, span in bytes
+  uint32_t* seq_span;
+  uint32_t* lens;        // out: bases
+  uint64_t* name_off;    // out
+  uint32_t* name_len;
+  unsigned long long* tot;  // [0] bases, [1] max len, [2] malformed records
+};
+
+K4_DEV uint32_t k4d_line_start(const uint32_t* nl, uint64_t j) { return j == 0 ? 0u : nl[j - 1] + 1; }
+
+// one thread per record: header token, sequence span, number of bases
+__global__ void __launch_bounds__(256) k4k_fastx_records(K4FastxArgs a) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n_rec) return;
+  const uint64_t hl = a.fastq ? (uint64_t)4 * r : a.hdr[r];
+  uint32_t s0 = k4d_line_start(a.nl, hl), e0 = a.nl[hl];
+  bool bad = a.text[s0] != (a.fastq ? '@' : '>');
+  uint32_t p = s0 + 1;
+  while (p < e0 && !k4d_is_space(a.text[p])) p++;
+  a.name_off[r] = a.text_base + s0 + 1;
+  a.name_len[r] = min(p - (s0 + 1), 127u);
+  const uint32_t s1 = e0 + 1;
+  uint32_t e1;
+  if (a.fastq) e1 = a.nl[hl + 1];
+  else e1 = (uint64_t)r + 1 < a.n_hdr ? k4d_line_start(a.nl, a.hdr[r + 1]) : (uint32_t)a.text_bytes;
+  if (e1 < s1) e1 = s1;
+  uint32_t n = 0;
+  for (uint32_t q = s1; q < e1; q++) n += !k4d_is_space(a.text[q]);
+  if (a.fastq && a.text[k4d_line_start(a.nl, hl + 2)] != '+') bad = true;
+  a.seq_off[r] = s1;
+  a.seq_span[r] = e1 - s1;
+  a.lens[r] = n;
+  atomicAdd(&a.tot[0], (unsigned long long)n);
+  atomicMax(&a.tot[1], (unsigned long long)n);
+  if (bad) atomicAdd(&a.tot[2], 1ull);
+}
+
+// one wave per record: the sequence bytes of its span, white space squeezed out, as etSeqBase codes
+__global__ void __launch_bounds__(64) k4k_fastx_encode(const uint8_t* __restrict__ text, const uint32_t* __restrict__ seq_off,
+                                                       const uint32_t* __restrict__ seq_span, const uint64_t* __restrict__ offs,
+                                                       int64_t n_rec, uint8_t* __restrict__ reads) {
+  const int lane = threadIdx.x;
+  for (int64_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
+    const uint8_t* src = text + seq_off[r];
+    const uint32_t span = seq_span[r];
+    uint8_t* dst = reads + offs[r];
+    uint32_t done = 0;
+    for (uint32_t q = 0; q < span; q += 64) {
+      const uint8_t c = q + lane < span ? src[q + lane] : (uint8_t)' ';
+      const bool keep = !k4d_is_space(c);
+      const unsigned long long m = __ballot(keep);
+      if (keep) dst[done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k4d_base_code(c);
+      done += (uint32_t)__popcll(m);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k4k_count_newlines(const uint8_t* __restrict__ text, uint64_t n, unsigned long long* __restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint32_t c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) c += text[i] == '\n';
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+struct IsHeaderLine {  // FASTA: the line starts with '>'
+  const uint8_t* text;
+  const uint32_t* nl;
+  __device__ bool operator()(uint32_t j) const { return text[j == 0 ? 0u : nl[j - 1] + 1] == '>'; }
+};
+
+struct Buf {
+  void* p = nullptr;
+  ~Buf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+}  // namespace
+
+extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t text_bytes, uint64_t text_base, int final_chunk,
+                                  int format, int64_t max_records, void* d_reads, uint64_t reads_base, void* d_offs,
+                                  void* d_lens, void* d_name_off, void* d_name_len, k4_parse_info* info, void* stream) {
+  if (!ix || !info) return K4_ERR_PARAMS;
+  memset(info, 0, sizeof(*info));
+  if (text_bytes == 0 || max_records <= 0) return K4_OK;
+  if (!d_text_v || !d_reads || !d_offs || !d_lens || !d_name_off || !d_name_len) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  if (text_bytes >= 0xFFFFFF00ull) return k4_fail(ix, K4_ERR_PARAMS, "text chunks are limited to 2^32-256 bytes");
+  K4_HIP(ix, hipSetDevice(ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  const uint8_t* text = (const uint8_t*)d_text_v;
+  if (format == 0) {  // first byte decides, as CFasta does
+    uint8_t c = 0;
+    K4_HIP(ix, hipMemcpyAsync(&c, text, 1, hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+    format = c == '@' ? K4_FASTQ : c == '>' ? K4_FASTA : 0;
+    if (!format) return k4_fail(ix, K4_ERR_NOT_FASTA, "input is neither FASTA ('>') nor FASTQ ('@')");
+  }
+  const bool fastq = format == K4_FASTQ;
+  Buf tot, nlb, hdrb, tmp, cnt, so, ss;
+  K4_HIP(ix, tot.alloc(32));
+  K4_HIP(ix, cnt.alloc(8));
+  K4_HIP(ix, hipMemsetAsync(tot.p, 0, 32, st));
+  hipLaunchKernelGGL(k4k_count_newlines, dim3(4096), dim3(256), 0, st, text, text_bytes, tot.as<unsigned long long>() + 3);
+  unsigned long long n_nl = 0;
+  uint8_t last = 0;
+  K4_HIP(ix, hipMemcpyAsync(&n_nl, tot.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, st));
+  K4_HIP(ix, hipMemcpyAsync(&last, text + text_bytes - 1, 1, hipMemcpyDeviceToHost, st));
+  K4_HIP(ix, hipStreamSynchronize(st));
+  // line ends: every '\n', plus the end of the text when the final chunk's last line is unterminated
+  uint64_t n_lines = n_nl;
+  K4_HIP(ix, nlb.alloc((n_nl + 2) * 4));
+  {
+    rocprim::counting_iterator<uint32_t> idx(0);
+    auto flags = rocprim::make_transform_iterator(text, IsNewline());
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::select(nullptr, tb, idx, flags, nlb.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)text_bytes, st));
+    K4_HIP(ix, tmp.alloc(tb));
+    K4_HIP(ix, rocprim::select(tmp.p, tb, idx, flags, nlb.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)text_bytes, st));
+  }
+  if (final_chunk && last != '\n') {
+    const uint32_t endp = (uint32_t)text_bytes;
+    K4_HIP(ix, hipMemcpyAsync(nlb.as<uint32_t>() + n_nl, &endp, 4, hipMemcpyHostToDevice, st));
+    K4_HIP(ix, hipStreamSynchronize(st));  // (endp is a stack variable)
+    n_lines++;
+  }
+  if (n_lines == 0) return K4_OK;  // no complete line in this chunk yet
+  int64_t n_rec = 0;
+  uint64_t n_hdr = 0;
+  uint64_t consumed = 0;
+  if (fastq) {
+    n_rec = (int64_t)std::min<uint64_t>(n_lines / 4, (uint64_t)max_records);
+    if (n_rec == 0) return K4_OK;
+    uint32_t e = 0;
+    K4_HIP(ix, hipMemcpyAsync(&e, nlb.as<uint32_t>() + (4 * n_rec - 1), 4, hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+    consumed = std::min<uint64_t>((uint64_t)e + 1, text_bytes);
+    if (final_chunk && (uint64_t)n_rec == n_lines / 4 && (uint64_t)n_rec < (uint64_t)max_records) consumed = text_bytes;
+  } else {
+    K4_HIP(ix, hdrb.alloc((n_lines + 1) * 4));
+    rocprim::counting_iterator<uint32_t> lines(0);
+    IsHeaderLine pred{text, nlb.as<uint32_t>()};
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::select(nullptr, tb, lines, hdrb.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)n_lines, pred, st));
+    Buf tmp2;
+    K4_HIP(ix, tmp2.alloc(tb));
+    K4_HIP(ix, rocprim::select(tmp2.p, tb, lines, hdrb.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)n_lines, pred, st));
+    K4_HIP(ix, hipMemcpyAsync(&n_hdr, cnt.p, 8, hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+    if (n_hdr == 0) return K4_OK;
+    // a non-final chunk keeps its last record for the next call (more of its sequence may follow)
+    uint64_t avail = final_chunk ? n_hdr : n_hdr - 1;
+    n_rec = (int64_t)std::min<uint64_t>(avail, (uint64_t)max_records);
+    if (n_rec == 0) return K4_OK;
+    if ((uint64_t)n_rec < n_hdr) {  // ends where the next header line starts
+      uint32_t hl = 0, e = 0;
+      K4_HIP(ix, hipMemcpyAsync(&hl, hdrb.as<uint32_t>() + n_rec, 4, hipMemcpyDeviceToHost, st));
+      K4_HIP(ix, hipStreamSynchronize(st));
+      if (hl > 0) {
+        K4_HIP(ix, hipMemcpyAsync(&e, nlb.as<uint32_t>() + (hl - 1), 4, hipMemcpyDeviceToHost, st));
+        K4_HIP(ix, hipStreamSynchronize(st));
+        consumed = (uint64_t)e + 1;
+      }
+    } else
+      consumed = text_bytes;
+  }
+  K4_HIP(ix, so.alloc((size_t)n_rec * 4));
+  K4_HIP(ix, ss.alloc((size_t)n_rec * 4));
+  K4FastxArgs a;
+  a.text = text; a.text_bytes = consumed; a.nl = nlb.as<uint32_t>(); a.hdr = hdrb.as<uint32_t>(); a.n_hdr = n_hdr;
+  a.n_rec = n_rec; a.fastq = fastq ? 1 : 0; a.text_base = text_base;
+  a.seq_off = so.as<uint32_t>(); a.seq_span = ss.as<uint32_t>(); a.lens = (uint32_t*)d_lens;
+  a.name_off = (uint64_t*)d_name_off; a.name_len = (uint32_t*)d_name_len; a.tot = tot.as<unsigned long long>();
+  hipLaunchKernelGGL(k4k_fastx_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, a);
+  {
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, (const uint32_t*)d_lens, (uint64_t*)d_offs, reads_base, (size_t)n_rec,
+                                       rocprim::plus<uint64_t>(), st));
+    Buf tmp3;
+    K4_HIP(ix, tmp3.alloc(tb));
+    K4_HIP(ix, rocprim::exclusive_scan(tmp3.p, tb, (const uint32_t*)d_lens, (uint64_t*)d_offs, reads_base, (size_t)n_rec,
+                                       rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL(k4k_fastx_encode, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 20)), dim3(64), 0, st, text, so.as<uint32_t>(),
+                       ss.as<uint32_t>(), (const uint64_t*)d_offs, n_rec, (uint8_t*)d_reads);
+    K4_HIP(ix, hipGetLastError());
+    K4_HIP(ix, hipStreamSynchronize(st));  // tmp3 is released here
+  }
+  unsigned long long t[3] = {0, 0, 0};
+  K4_HIP(ix, hipMemcpy(t, tot.p, 24, hipMemcpyDeviceToHost));
+  info->n_records = (uint64_t)n_rec;
+  info->consumed = consumed;
+  info->n_bases = t[0];
+  info->max_len = (uint32_t)t[1];
+  info->format = (uint32_t)format;
+  if (t[2]) return k4_fail(ix, K4_ERR_NOT_FASTA, "%llu malformed %s records (header / separator line not where expected)", t[2], fastq ? "FASTQ" : "FASTA");
+  return K4_OK;
+}
+
+// ---- length filter + PE interleave --------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k4k_prepare_reads(int pe, int64_t n, uint32_t min_len, uint32_t max_len,
+                                                         const uint64_t* __restrict__ o1, const uint32_t* __restrict__ l1,
+                                                         const uint64_t* __restrict__ o2, const uint32_t* __restrict__ l2,
+                                                         uint64_t base2, uint64_t* __restrict__ oo, uint32_t* __restrict__ lo,
+                                                         unsigned long long* __restrict__ tot) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t a = l1[i], b = pe ? l2[i] : a;
+  const bool under = a < min_len || b < min_len;      // sloughed, KAligner.cpp:12024-12060
+  const bool over = !under && (a > max_len || b > max_len);
+  const bool keep = !under && !over;
+  if (under) atomicAdd(&tot[0], 1ull);
+  if (over) atomicAdd(&tot[1], 1ull);
+  if (keep) atomicMax(&tot[2], (unsigned long long)max(a, b));
+  if (pe) {
+    oo[2 * i] = o1[i]; lo[2 * i] = keep ? a : 0;
+    oo[2 * i + 1] = o2[i] + base2; lo[2 * i + 1] = keep ? b : 0;
+  } else {
+    oo[i] = o1[i]; lo[i] = keep ? a : 0;
+  }
+}
+}  // namespace
+
+extern "C" int k4_prepare_reads_dev(k4_index* ix, int pe, int64_t n, int32_t min_len, int32_t max_len, const void* d_offs1,
+                                    const void* d_lens1, const void* d_offs2, const void* d_lens2, uint64_t reads2_base,
+                                    void* d_offs_out, void* d_lens_out, uint64_t* n_under, uint64_t* n_over,
+                                    uint32_t* max_read_len, void* stream) {
+  if (!ix || n < 0) return K4_ERR_PARAMS;
+  if (n_under) *n_under = 0;
+  if (n_over) *n_over = 0;
+  if (max_read_len) *max_read_len = 0;
+  if (n == 0) return K4_OK;
+  if (!d_offs1 || !d_lens1 || !d_offs_out || !d_lens_out || (pe && (!d_offs2 || !d_lens2))) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  K4_HIP(ix, hipSetDevice(ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  Buf tot;
+  K4_HIP(ix, tot.alloc(24));
+  K4_HIP(ix, hipMemsetAsync(tot.p, 0, 24, st));
+  hipLaunchKernelGGL(k4k_prepare_reads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pe ? 1 : 0, n,
+                     (uint32_t)std::max(min_len, 0), (uint32_t)std::max(max_len, 0), (const uint64_t*)d_offs1, (const uint32_t*)d_lens1,
+                     (const uint64_t*)d_offs2, (const uint32_t*)d_lens2, reads2_base, (uint64_t*)d_offs_out, (uint32_t*)d_lens_out,
+                     tot.as<unsigned long long>());
+  unsigned long long t[3];
+  K4_HIP(ix, hipMemcpyAsync(t, tot.p, 24, hipMemcpyDeviceToHost, st));
+  K4_HIP(ix, hipStreamSynchronize(st));
+  if (n_under) *n_under = t[0];
+  if (n_over) *n_over = t[1];
+  if (max_read_len) *max_read_len = (uint32_t)t[2];
+  return K4_OK;
+}
+
+// ---- SAM ----------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct K4SamArgs {
+  int pe;                       // 0: SE (rr + hits), 1: PE (k4_pe_read per read, reads interleaved)
+  int64_t n_reads;              // SE reads or 2 * pairs
+  const k4_read_result* rr;
+  const k4_hit* hits;
+  int max_ml;
+  const k4_pe_read* pr;
+  const uint8_t* reads;
+  const uint64_t* offs;
+  const uint32_t* lens;
+  const uint8_t* text[2];
+  const uint64_t* name_off[2];
+  const uint32_t* name_len[2];
+  const char* cnames;           // n_entries x K4_SAM_NAME_STRIDE
+  const uint8_t* cname_len;
+  uint32_t n_entries;
+};
+#define K4_SAM_NAME_STRIDE 96
+
+K4_DEV int k4d_sam_nar(const K4SamArgs& a, int64_t i) { return a.pe ? a.pr[i].nar : a.rr[i].nar; }
+K4_DEV k4_hit k4d_sam_hit(const K4SamArgs& a, int64_t i) { return a.pe ? a.pr[i].hit : a.hits[(size_t)i * a.max_ml]; }
+
+struct K4SamFields {
+  uint32_t flag, pos, mapq, len, pnext;
+  int32_t tlen;
+  bool mate_eq;
+};
+// ReportBAMread (KAligner.cpp:6041-6146,6231): FLAG, MAPQ = max(1, 254 * hitlen / readlen), mate fields
+K4_DEV K4SamFields k4d_sam_fields(const K4SamArgs& a, int64_t i, const k4_hit& h) {
+  K4SamFields f;
+  f.pos = h.match_loci + 1;
+  f.len = h.match_len;
+  const uint32_t rl = a.lens[i];
+  int mq = (int)(254 * ((double)h.match_len / (double)rl));
+  mq = mq < 1 ? 1 : mq > 254 ? 254 : mq;
+  f.mapq = (uint32_t)mq;
+  f.pnext = 0;
+  f.tlen = 0;
+  f.mate_eq = false;
+  if (!a.pe) {
+    f.flag = h.strand == '+' ? 0u : 0x10u;
+    return f;
+  }
+  const k4_pe_read me = a.pr[i], mt = a.pr[i ^ 1];
+  f.flag = 0x1u | 0x2u | ((i & 1) ? 0x80u : 0x40u) | (h.strand == '+' ? 0u : 0x10u);
+  if (me.pe_aligned && mt.pe_aligned && mt.nar == K4_NAR_ACCEPTED) {
+    if (mt.hit.strand != '+') f.flag |= 0x20u;
+    f.mate_eq = true;
+    f.pnext = mt.hit.match_loci + 1;
+    const int64_t s = h.match_loci, e = mt.hit.match_loci;
+    f.tlen = (int32_t)(s <= e ? (e - s) + mt.hit.match_len : (s - e) + h.match_len);
+  } else
+    f.flag |= 0x8u;
+  return f;
+}
+K4_DEV uint32_t k4d_udigits(uint32_t v) {
+  uint32_t d = 1;
+  while (v >= 10) { v /= 10; d++; }
+  return d;
+}
+K4_DEV uint32_t k4d_put_uint(char* p, uint32_t v) {  // returns digits written
+  const uint32_t d = k4d_udigits(v);
+  for (uint32_t q = d; q-- > 0;) { p[q] = (char)('0' + v % 10); v /= 10; }
+  return d;
+}
+
+struct IsAccepted {
+  K4SamArgs a;
+  __device__ bool operator()(uint32_t i) const { return k4d_sam_nar(a, i) == K4_NAR_ACCEPTED; }
+};
+
+// secondary key of SortHitMatch (len, strand, mismatches) and primary key (chrom, start)
+__global__ void __launch_bounds__(256) k4k_sam_key_minor(K4SamArgs a, const uint32_t* __restrict__ idx, uint64_t m, uint32_t* __restrict__ key) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const k4_hit h = k4d_sam_hit(a, idx[j]);
+  key[j] = ((uint32_t)h.match_len << 16) | ((uint32_t)h.strand << 8) | h.mismatches;
+}
+__global__ void __launch_bounds__(256) k4k_sam_key_major(K4SamArgs a, const uint32_t* __restrict__ idx, uint64_t m, uint64_t* __restrict__ key) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const k4_hit h = k4d_sam_hit(a, idx[j]);
+  key[j] = ((uint64_t)h.chrom_id << 32) | h.match_loci;
+}
+
+// statistics over every read (ReportAlignStats, KAligner.cpp:3600-3830): NAR histogram [0..20), '+' [20], '-' [21]
+__global__ void __launch_bounds__(256) k4k_sam_stats(K4SamArgs a, unsigned long long* __restrict__ st, uint8_t* __restrict__ chrom_hit) {
+  __shared__ unsigned int h[22];
+  if (threadIdx.x < 22) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_reads; i += stride) {
+    if (a.lens[i] == 0) continue;  // a slot whose read was not loaded (under / over length)
+    const int nar = k4d_sam_nar(a, i);
+    atomicAdd(&h[nar >= 0 && nar < 20 ? nar : 0], 1u);
+    if (nar == K4_NAR_ACCEPTED) {
+      const k4_hit hh = k4d_sam_hit(a, i);
+      atomicAdd(&h[hh.strand == '+' ? 20 : 21], 1u);
+      if (chrom_hit && hh.chrom_id <= a.n_entries) chrom_hit[hh.chrom_id] = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 22 && h[threadIdx.x]) atomicAdd(&st[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t i) {
+  const k4_hit h = k4d_sam_hit(a, i);
+  const K4SamFields f = k4d_sam_fields(a, i, h);
+  const int w = a.pe ? (int)(i & 1) : 0;
+  const int64_t rec = a.pe ? (i >> 1) : i;
+  uint32_t n = a.name_len[w][rec] + 1 + k4d_udigits(f.flag) + 1 + a.cname_len[h.chrom_id - 1] + 1 + k4d_udigits(f.pos) + 1 +
+               k4d_udigits(f.mapq) + 1 + k4d_udigits(f.len) + 1 /*M*/ + 1 + 1 /*RNEXT*/ + 1 + k4d_udigits(f.pnext) + 1;
+  n += (f.tlen < 0 ? 1 : 0) + k4d_udigits((uint32_t)(f.tlen < 0 ? -(int64_t)f.tlen : f.tlen)) + 1;
+  n += a.lens[i] + 1 + 1 /* '*' */ + 1 /* '\n' */;
+  return n;
+}
+__global__ void __launch_bounds__(256) k4k_sam_line_lens(K4SamArgs a, const uint32_t* __restrict__ order, uint64_t m, uint32_t* __restrict__ ll) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < m) ll[j] = k4d_sam_line_len(a, order[j]);
+}
+
+// one wave per line: QNAME FLAG RNAME POS MAPQ <len>M RNEXT PNEXT TLEN SEQ * (AddAlignment, SAMfile.cpp:2194-2377)
+__global__ void __launch_bounds__(64) k4k_sam_write(K4SamArgs a, const uint32_t* __restrict__ order, const uint64_t* __restrict__ loff,
+                                                    uint64_t m, char* __restrict__ out) {
+  __shared__ char mid[2][64];
+  __shared__ uint32_t midn[2];
+  const int lane = threadIdx.x;
+  for (uint64_t j = blockIdx.x; j < m; j += gridDim.x) {
+    const int64_t i = order[j];
+    const k4_hit h = k4d_sam_hit(a, i);
+    const int w = a.pe ? (int)(i & 1) : 0;
+    const int64_t rec = a.pe ? (i >> 1) : i;
+    __syncthreads();
+    if (lane == 0) {
+      const K4SamFields f = k4d_sam_fields(a, i, h);
+      char* p = mid[0];
+      uint32_t n = 0;
+      p[n++] = '\t'; n += k4d_put_uint(p + n, f.flag); p[n++] = '\t';
+      midn[0] = n;
+      p = mid[1];
+      n = 0;
+      p[n++] = '\t'; n += k4d_put_uint(p + n, f.pos);
+      p[n++] = '\t'; n += k4d_put_uint(p + n, f.mapq);
+      p[n++] = '\t'; n += k4d_put_uint(p + n, f.len); p[n++] = 'M';
+      p[n++] = '\t'; p[n++] = f.mate_eq ? '=' : '*';
+      p[n++] = '\t'; n += k4d_put_uint(p + n, f.pnext);
+      p[n++] = '\t';
+      if (f.tlen < 0) p[n++] = '-';
+      n += k4d_put_uint(p + n, (uint32_t)(f.tlen < 0 ? -(int64_t)f.tlen : f.tlen));
+      p[n++] = '\t';
+      midn[1] = n;
+    }
+    __syncthreads();
+    char* dst = out + loff[j];
+    const uint8_t* nm = a.text[w] + a.name_off[w][rec];
+    const uint32_t nl_ = a.name_len[w][rec];
+    for (uint32_t q = lane; q < nl_; q += 64) dst[q] = (char)nm[q];
+    dst += nl_;
+    for (uint32_t q = lane; q < midn[0]; q += 64) dst[q] = mid[0][q];
+    dst += midn[0];
+    const char* cn = a.cnames + (size_t)(h.chrom_id - 1) * K4_SAM_NAME_STRIDE;
+    const uint32_t cl = a.cname_len[h.chrom_id - 1];
+    for (uint32_t q = lane; q < cl; q += 64) dst[q] = cn[q];
+    dst += cl;
+    for (uint32_t q = lane; q < midn[1]; q += 64) dst[q] = mid[1][q];
+    dst += midn[1];
+    const uint8_t* s = a.reads + a.offs[i];
+    const uint32_t len = a.lens[i];
+    if (h.strand == '+')
+      for (uint32_t q = lane; q < len; q += 64) { const uint8_t b = s[q] & 7; dst[q] = "ACGTN"[b > 4 ? 4 : b]; }
+    else
+      for (uint32_t q = lane; q < len; q += 64) { const uint8_t b = s[len - 1 - q] & 7; dst[q] = b <= 3 ? "TGCA"[b] : 'N'; }  // :6279
+    dst += len;
+    if (lane == 0) { dst[0] = '\t'; dst[1] = '*'; dst[2] = '\n'; }
+  }
+}
+
+}  // namespace
+
+extern "C" void k4_free_device(void* p) { if (p) hipFree(p); }
+// thin device-memory helpers so that a host program over this ABI needs no HIP of its own
+extern "C" int k4_alloc_device(k4_index* ix, uint64_t bytes, void** p) {
+  if (!ix || !p) return K4_ERR_PARAMS;
+  *p = nullptr;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  K4_HIP(ix, hipMalloc(p, bytes ? bytes : 1));
+  return K4_OK;
+}
+extern "C" int k4_copy_to_device(k4_index* ix, void* d_dst, const void* src, uint64_t bytes) {
+  if (!ix || (bytes && (!d_dst || !src))) return K4_ERR_PARAMS;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  K4_HIP(ix, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  return K4_OK;
+}
+extern "C" int k4_copy_to_host(k4_index* ix, void* dst, const void* d_src, uint64_t bytes) {
+  if (!ix || (bytes && (!dst || !d_src))) return K4_ERR_PARAMS;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  K4_HIP(ix, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return K4_OK;
+}
+
+extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                                 const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens,
+                                 const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
+                                 uint8_t* chrom_hit, void* stream) {
+  if (!ix || !names || !d_sam || !sam_bytes) return K4_ERR_PARAMS;
+  *d_sam = nullptr;
+  *sam_bytes = 0;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (chrom_hit) memset(chrom_hit, 0, ix->d.n_entries + 1);
+  if (n_units < 0) return k4_fail(ix, K4_ERR_PARAMS, "negative count");
+  if (n_units == 0) return K4_OK;
+  const int64_t n_reads = pe ? 2 * n_units : n_units;
+  if (n_reads >= 0xFFFFFF00ll) return k4_fail(ix, K4_ERR_PARAMS, "at most 2^32-256 reads per call");
+  if ((pe && !d_pe) || (!pe && (!d_rr || !d_hits || max_ml < 1)) || !d_reads || !d_offs || !d_lens || !names->d_text[0] ||
+      !names->d_name_off[0] || !names->d_name_len[0] || (pe && (!names->d_text[1] || !names->d_name_off[1] || !names->d_name_len[1])))
+    return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  K4_HIP(ix, hipSetDevice(ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  // chromosome names on the device
+  const uint32_t ne = ix->d.n_entries;
+  Buf cn, cl;
+  {
+    std::vector<char> hn((size_t)ne * K4_SAM_NAME_STRIDE, 0);
+    std::vector<uint8_t> hl(ne);
+    for (uint32_t e = 0; e < ne; e++) {
+      const size_t l = strnlen(ix->entries[e].name, 80);
+      memcpy(&hn[(size_t)e * K4_SAM_NAME_STRIDE], ix->entries[e].name, l);
+      hl[e] = (uint8_t)l;
+    }
+    K4_HIP(ix, cn.alloc(hn.size()));
+    K4_HIP(ix, cl.alloc(hl.size()));
+    K4_HIP(ix, hipMemcpy(cn.p, hn.data(), hn.size(), hipMemcpyHostToDevice));
+    K4_HIP(ix, hipMemcpy(cl.p, hl.data(), hl.size(), hipMemcpyHostToDevice));
+  }
+  K4SamArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pe = pe ? 1 : 0; a.n_reads = n_reads; a.rr = (const k4_read_result*)d_rr; a.hits = (const k4_hit*)d_hits; a.max_ml = max_ml;
+  a.pr = (const k4_pe_read*)d_pe; a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
+  for (int w = 0; w < 2; w++) {
+    a.text[w] = (const uint8_t*)names->d_text[w]; a.name_off[w] = (const uint64_t*)names->d_name_off[w];
+    a.name_len[w] = (const uint32_t*)names->d_name_len[w];
+  }
+  a.cnames = cn.as<char>(); a.cname_len = cl.as<uint8_t>(); a.n_entries = ne;
+
+  Buf stb, chb, cnt, idx0, idx1, k32a, k32b, k64a, k64b, tmp, ll, lo;
+  K4_HIP(ix, stb.alloc(22 * 8));
+  K4_HIP(ix, chb.alloc(ne + 1));
+  K4_HIP(ix, cnt.alloc(8));
+  K4_HIP(ix, hipMemsetAsync(stb.p, 0, 22 * 8, st));
+  K4_HIP(ix, hipMemsetAsync(chb.p, 0, ne + 1, st));
+  hipLaunchKernelGGL(k4k_sam_stats, dim3(2048), dim3(256), 0, st, a, stb.as<unsigned long long>(), chb.as<uint8_t>());
+  // accepted reads, in load order
+  K4_HIP(ix, idx0.alloc((size_t)n_reads * 4));
+  {
+    rocprim::counting_iterator<uint32_t> all(0);
+    IsAccepted pred{a};
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::select(nullptr, tb, all, idx0.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)n_reads, pred, st));
+    K4_HIP(ix, tmp.alloc(tb));
+    K4_HIP(ix, rocprim::select(tmp.p, tb, all, idx0.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)n_reads, pred, st));
+  }
+  uint64_t m = 0;
+  K4_HIP(ix, hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, st));
+  K4_HIP(ix, hipStreamSynchronize(st));
+  unsigned long long hs[22];
+  K4_HIP(ix, hipMemcpy(hs, stb.p, sizeof(hs), hipMemcpyDeviceToHost));
+  if (stats) {
+    for (int k = 0; k < 20; k++) stats->nar[k] = hs[k];
+    stats->plus = hs[20];
+    stats->minus = hs[21];
+    stats->n_lines = m;
+  }
+  if (chrom_hit) K4_HIP(ix, hipMemcpy(chrom_hit, chb.p, ne + 1, hipMemcpyDeviceToHost));
+  if (m == 0) return K4_OK;
+  // SortHitMatch (KAligner.cpp:10969): chrom, start, len, strand, mismatches; equal keys keep load order.
+  // Two stable radix sorts: minor key first, then (chrom, start).
+  K4_HIP(ix, idx1.alloc(m * 4));
+  K4_HIP(ix, k32a.alloc(m * 4));
+  K4_HIP(ix, k32b.alloc(m * 4));
+  K4_HIP(ix, k64a.alloc(m * 8));
+  K4_HIP(ix, k64b.alloc(m * 8));
+  const unsigned mb = (unsigned)((m + 255) / 256);
+  hipLaunchKernelGGL(k4k_sam_key_minor, dim3(mb), dim3(256), 0, st, a, idx0.as<uint32_t>(), m, k32a.as<uint32_t>());
+  const uint32_t* order = nullptr;
+  {
+    rocprim::double_buffer<uint32_t> kb(k32a.as<uint32_t>(), k32b.as<uint32_t>());
+    rocprim::double_buffer<uint32_t> vb(idx0.as<uint32_t>(), idx1.as<uint32_t>());
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::radix_sort_pairs(nullptr, tb, kb, vb, (size_t)m, 0u, 32u, st));
+    Buf t2;
+    K4_HIP(ix, t2.alloc(tb));
+    K4_HIP(ix, rocprim::radix_sort_pairs(t2.p, tb, kb, vb, (size_t)m, 0u, 32u, st));
+    hipLaunchKernelGGL(k4k_sam_key_major, dim3(mb), dim3(256), 0, st, a, vb.current(), m, k64a.as<uint64_t>());
+    rocprim::double_buffer<uint64_t> kb2(k64a.as<uint64_t>(), k64b.as<uint64_t>());
+    size_t tb2 = 0;
+    K4_HIP(ix, rocprim::radix_sort_pairs(nullptr, tb2, kb2, vb, (size_t)m, 0u, 64u, st));
+    Buf t3;
+    K4_HIP(ix, t3.alloc(tb2));
+    K4_HIP(ix, rocprim::radix_sort_pairs(t3.p, tb2, kb2, vb, (size_t)m, 0u, 64u, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+    order = vb.current();
+  }
+  // line lengths -> offsets -> text
+  K4_HIP(ix, ll.alloc((m + 1) * 4));
+  K4_HIP(ix, lo.alloc((m + 1) * 8));
+  K4_HIP(ix, hipMemsetAsync(ll.as<uint32_t>() + m, 0, 4, st));
+  hipLaunchKernelGGL(k4k_sam_line_lens, dim3(mb), dim3(256), 0, st, a, order, m, ll.as<uint32_t>());
+  {
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, ll.as<uint32_t>(), lo.as<uint64_t>(), (uint64_t)0, (size_t)(m + 1),
+                                       rocprim::plus<uint64_t>(), st));
+    Buf t4;
+    K4_HIP(ix, t4.alloc(tb));
+    K4_HIP(ix, rocprim::exclusive_scan(t4.p, tb, ll.as<uint32_t>(), lo.as<uint64_t>(), (uint64_t)0, (size_t)(m + 1),
+                                       rocprim::plus<uint64_t>(), st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+  }
+  uint64_t total = 0;
+  K4_HIP(ix, hipMemcpy(&total, lo.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost));
+  char* out = nullptr;
+  K4_HIP(ix, hipMalloc(&out, total + 16));
+  hipLaunchKernelGGL(k4k_sam_write, dim3((unsigned)std::min<uint64_t>(m, 1u << 20)), dim3(64), 0, st, a, order, lo.as<uint64_t>(), m, out);
+  int rc = k4_check_hip(ix, hipGetLastError(), "SAM write");
+  if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(st), "SAM write");
+  if (rc != K4_OK) {
+    hipFree(out);
+    return rc;
+  }
+  *d_sam = out;
+  *sam_bytes = total;
+  return K4_OK;
+}

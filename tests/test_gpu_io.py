@@ -1,0 +1,228 @@
+"""GPU read ingest (FASTA/FASTQ text -> etSeqBase reads) and SAM emit against plain-Python restatements of what
+CKAligner::LoadRawReads (KAligner.cpp:11648-12421) and ReportBAMread / AddAlignment (KAligner.cpp:5957-6320,
+SAMfile.cpp:2194-2377) do.  The end-to-end check against the reference's own SAM files is
+test_gpu_parity.py::test_k4align_writes_the_reference_sam (k4align runs this pipeline)."""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+CODE = {ord(c): v for c, v in zip("aAcCgGtTuU", [0, 0, 1, 1, 2, 2, 3, 3, 3, 3])}
+
+
+def host_parse(text):
+    """records as LoadRawReads sees them: (first token of the descriptor cut at 127 bytes, etSeqBase codes)"""
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    recs = []
+    fastq = text[:1] == b"@"
+    enc = lambda s: [CODE.get(c, 4) for c in s if c not in b" \t\n\v\f\r"]  # noqa: E731
+    i = 0
+    if fastq:
+        while i + 3 < len(lines) or (i + 3 == len(lines) - 0 and False):
+            name = lines[i][1:].split()[0][:127] if lines[i][1:].split() else b""
+            recs.append((name, enc(lines[i + 1])))
+            i += 4
+        return recs
+    cur = None
+    for ln in lines:
+        if ln[:1] == b">":
+            tok = ln[1:].split()
+            cur = (tok[0][:127] if tok else b"", [])
+            recs.append(cur)
+        elif cur is not None:
+            cur[1].extend(enc(ln))
+    return recs
+
+
+def _check(ix, text, chunk=None):
+    p = ix.parse_fastx(text, chunk_bytes=chunk)
+    want = host_parse(text)
+    assert p["n"] == len(want)
+    reads = p["reads"].cpu().numpy()
+    offs, lens = p["offs"].cpu().numpy(), p["lens"].cpu().numpy()
+    noff, nlen = p["name_off"].cpu().numpy(), p["name_len"].cpu().numpy()
+    assert p["n_bases"] == sum(len(w[1]) for w in want)
+    assert p["max_len"] == max([len(w[1]) for w in want] + [0])
+    for r, (name, seq) in enumerate(want):
+        assert lens[r] == len(seq), r
+        assert reads[offs[r]:offs[r] + lens[r]].tolist() == seq, r
+        assert bytes(text[noff[r]:noff[r] + nlen[r]]) == name, r
+    return p
+
+
+PROBS = np.array([.2, .2, .2, .2, .03, .03, .03, .03, .01, .01, .01, .01, .01, .005, .01, .005])
+PROBS = PROBS / PROBS.sum()
+
+
+def _fasta(rng, n, wrap, crlf, trailing_nl=True):
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    alphabet = b"ACGTacgtNnRYKMU-"
+    for i in range(n):
+        L = int(rng.integers(0, 400))
+        seq = bytes(rng.choice(list(alphabet), size=L, p=PROBS).tolist())
+        name = b"read%d" % i + (b"x" * 150 if i % 17 == 3 else b"")
+        descr = b">" + name + (b" some descr\twith tabs" if i % 3 == 0 else b"")
+        out.append(descr)
+        if wrap:
+            out.extend(seq[j:j + wrap] for j in range(0, len(seq), wrap))
+        else:
+            out.append(seq)
+    t = eol.join(out)
+    return t + (eol if trailing_nl else b"")
+
+
+def _fastq(rng, n, crlf, trailing_nl=True):
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n):
+        L = int(rng.integers(1, 300))
+        seq = bytes(rng.choice(list(b"ACGTN"), size=L, p=[.24, .24, .24, .24, .04]).tolist())
+        qual = bytes(rng.integers(33, 74, size=L).astype(np.uint8).tolist())
+        if i % 5 == 0:
+            qual = b"@" + qual[1:]  # a quality line may begin with '@'
+        out += [b"@q%d/1 extra" % i, seq, b"+", qual]
+    t = eol.join(out)
+    return t + (eol if trailing_nl else b"")
+
+
+@pytest.fixture(scope="module")
+def k4():
+    import kit4b_amd
+
+    kit4b_amd.lib()  # raises if the HIP extension is missing: no fallback
+    return kit4b_amd
+
+
+@pytest.fixture(scope="module")
+def ix(k4, golden_dir):
+    x = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    yield x
+    x.close()
+
+
+@pytest.mark.parametrize("wrap,crlf,trail", [(0, False, True), (60, False, True), (70, True, True), (60, False, False), (0, True, False)])
+def test_fasta_ingest(ix, wrap, crlf, trail):
+    rng = np.random.default_rng(11 + wrap)
+    text = _fasta(rng, 700, wrap, crlf, trail)
+    _check(ix, text)
+    for chunk in (997, 4096, 50000):
+        _check(ix, text, chunk=chunk)
+
+
+@pytest.mark.parametrize("crlf,trail", [(False, True), (True, True), (False, False)])
+def test_fastq_ingest(ix, crlf, trail):
+    rng = np.random.default_rng(23)
+    text = _fastq(rng, 900, crlf, trail)
+    _check(ix, text)
+    for chunk in (1500, 8192, 100000):
+        _check(ix, text, chunk=chunk)
+
+
+def test_ingest_rejects_other_text(ix, k4):
+    with pytest.raises(k4.K4Error) as e:
+        ix.parse_fastx(b"hello world\nACGT\n")
+    assert e.value.code == -93  # eBSFerrNotFasta
+
+
+def _sam_lines_host(names, reads, out, hits, chrom_names, pe=None):
+    """the SAM body as k4align's host formatter (and ngskit4b) writes it"""
+    recs = []
+    for i, rd in enumerate(reads):
+        if pe is None:
+            nar, h = out["nar"][i], hits[i]
+        else:
+            nar, h = pe["nar"][i], pe["hit"][i]
+        if nar != 1:
+            continue
+        strand = chr(h["strand"])
+        flag, rnext, pnext, tlen = (0 if strand == "+" else 0x10), "*", 0, 0
+        if pe is not None:
+            m = pe[i ^ 1]
+            flag = 0x1 | 0x2 | (0x80 if i & 1 else 0x40) | (0 if strand == "+" else 0x10)
+            if pe["pe_aligned"][i] and m["pe_aligned"] and m["nar"] == 1:
+                if chr(m["hit"]["strand"]) != "+":
+                    flag |= 0x20
+                rnext, pnext = "=", int(m["hit"]["match_loci"]) + 1
+                s, e = int(h["match_loci"]), int(m["hit"]["match_loci"])
+                tlen = (e - s) + int(m["hit"]["match_len"]) if s <= e else (s - e) + int(h["match_len"])
+            else:
+                flag |= 0x8
+        seq = rd if strand == "+" else synth.revcomp(rd)
+        mapq = min(254, max(1, int(254 * (int(h["match_len"]) / len(rd)))))
+        key = (int(h["chrom_id"]), int(h["match_loci"]), int(h["match_len"]), int(h["strand"]), int(h["mismatches"]), i)
+        line = "%s\t%d\t%s\t%d\t%d\t%dM\t%s\t%d\t%d\t%s\t*\n" % (
+            names[i], flag, chrom_names[int(h["chrom_id"]) - 1], int(h["match_loci"]) + 1, mapq, int(h["match_len"]), rnext,
+            pnext, tlen, "".join("ACGTN"[min(int(b), 4)] for b in seq))
+        recs.append((key, line))
+    recs.sort(key=lambda t: t[0])
+    return "".join(l for _, l in recs).encode()
+
+
+def _fasta_of(reads, prefix):
+    return "".join(">%s%06d synthetic\n%s\n" % (prefix, i + 1, "".join(synth.BASES[b] for b in r)) for i, r in enumerate(reads)).encode()
+
+
+def test_sam_emit_se(ix, k4):
+    import torch
+
+    names_c, chroms = synth.golden_genome()
+    reads, _ = synth.make_reads(chroms, 6000, 100, seed=77, sub_lambda=1.2, n_prob=0.02)
+    reads += [np.array([0, 1, 2, 3] * 8, dtype=np.uint8)]  # 32 bp: under the length filter, must vanish from everything
+    text = _fasta_of(reads, "se")
+    p1 = ix.parse_fastx(text)
+    prep = ix.prepare_reads(p1, min_len=50, max_len=500)
+    assert prep["n_under"] == 1 and prep["n_over"] == 0 and prep["max_len"] == 100
+    n = prep["n_units"]
+    dev = prep["reads"].device
+    rr = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+    hits = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+    ix.set_max_iter(5000)
+    ix.reserve(n, 100, 1)
+    ix.kalign_batch_dev(kp, n, 100, prep["reads"].data_ptr(), prep["offs"].data_ptr(), prep["lens"].data_ptr(), rr.data_ptr(),
+                        hits.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    body, stats, chrom_hit = ix.format_sam(prep, p1, rr=rr, hits=hits, max_ml=1)
+    host = ix.kalign_batch(reads[:-1], max_subs=2)
+    names = ["se%06d" % (i + 1) for i in range(len(reads) - 1)]
+    want = _sam_lines_host(names, reads[:-1], host["out"], host["hits"][:, 0], names_c)
+    assert body == want
+    assert stats["n_lines"] == want.count(b"\n") == (host["out"]["nar"] == 1).sum()
+    assert sum(stats["nar"]) == len(reads) - 1
+    assert stats["nar"][1] == stats["plus"] + stats["minus"]
+    assert chrom_hit[1:].tolist() == [1 if (host["hits"][:, 0]["chrom_id"][host["out"]["nar"] == 1] == c + 1).any() else 0
+                                      for c in range(len(names_c))]
+
+
+@pytest.mark.parametrize("pe_mode", [1, 3])
+def test_sam_emit_pe(ix, k4, pe_mode):
+    import torch
+
+    names_c, chroms = synth.golden_genome()
+    pe1, pe2, _ = synth.make_pe_reads(chroms, 2500, 125, seed=900 + pe_mode, sub_lambda=1.6, random_mate_frac=0.05,
+                                      frag_min=260, frag_max=700)
+    p1 = ix.parse_fastx(_fasta_of(pe1, "a"))
+    p2 = ix.parse_fastx(_fasta_of(pe2, "b"))
+    prep = ix.prepare_reads(p1, p2, min_len=50, max_len=500)
+    n = prep["n_units"]
+    dev = prep["reads"].device
+    d_out = torch.zeros(2 * n * k4.PE_READ_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 10, 1, 0, 0)
+    pp = k4.PeParams(pe_mode, 220, 640, 0)
+    ix.set_max_iter(5000)
+    ix.kalign_pe_batch_dev(kp, pp, n, prep["max_len"], prep["reads"].data_ptr(), prep["offs"].data_ptr(), prep["lens"].data_ptr(),
+                           d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    body, stats, _ = ix.format_sam(prep, p1, p2, pe_recs=d_out)
+    host = ix.kalign_pe_batch(pe1, pe2, pe_mode=pe_mode, pair_min_len=220, pair_max_len=640, max_subs=2)
+    assert np.array_equal(d_out.cpu().numpy().view(k4.PE_READ_DTYPE), host)
+    inter = [x for pair in zip(pe1, pe2) for x in pair]
+    names = [("a%06d" if i % 2 == 0 else "b%06d") % (i // 2 + 1) for i in range(2 * n)]
+    want = _sam_lines_host(names, inter, None, None, names_c, pe=host)
+    assert body == want
+    assert stats["n_lines"] == (host["nar"] == 1).sum()
