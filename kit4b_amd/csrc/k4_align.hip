@@ -32,6 +32,7 @@
 #endif
 #define K4_CHUNK 512         // survivor slots a wave reserves per atomic
 #define K4_NO_READ 0xFFFFFFFFu  // hole in a survivor list
+#define K4_ROW_WORDS(nch) (2 * (nch) + 2)  // survivor row: forward + reverse-complement words, then the two offset-0 memos
 #ifndef K4_PF
 #define K4_PF 4  // k-mer table entries fetched ahead per strand pass
 #endif
@@ -187,6 +188,7 @@ struct K4Lane {
   uint32_t* ded;       // LDS: dedupe slot q at ded[q * 256]
   const uint32_t* sup; // LDS (block-shared): coarse exception bitmap, K4_SUP_WORDS words
   const uint64_t* ent; // LDS (block-shared): chromosome starts [0..K4_LDS_ENTRIES) then ends, when they fit
+  uint64_t* memo;      // LDS: what the offset-0 lookup of strand s found in the first phase, at memo[s * 256]
   static constexpr int NW = NCH + 1;
   K4_DEV uint64_t word(int s, int c) const { return rd[(s * NW + c) * 256]; }
   K4_DEV uint64_t chunk_at(int s, int o) const {  // 32 bases of strand s starting at base o
@@ -200,8 +202,20 @@ struct K4Lane {
 struct K4Probe {
   int cmp;   // core vs suffix: -1 probe<target, 0 match, 1 probe>target
   int mm;    // Hamming distance of the whole read against the read-aligned window
+  int fm;    // offset of the first mismatching base of the read (len when there is none)
   bool exc;  // window touches a non-ACGT symbol
 };
+
+// Offset-0 memo.  Every phase of AlignReads starts each strand pass with the core at offset 0, i.e. with the same first
+// k bases, so the same k-mer bucket; on a large genome that bucket is empty or a single suffix nearly always.  The first
+// phase records what it found: kind 1 = empty bucket; kind 2 = one suffix at pos whose window differs from the read
+// first at base fm (mm = Hamming distance of the whole read, 0xFF when the window was never fetched because the 16-base
+// signature already disagreed).  A later phase with core length cl then knows without any memory access that nothing
+// starts with its offset-0 core (empty, or fm < cl) or that exactly the suffix at pos does, with distance mm.
+#define K4_MEMO_NONE 0ull
+K4_DEV uint64_t k4d_memo_pack(int kind, uint64_t pos, int mm, int fm) {
+  return ((uint64_t)kind << 62) | ((uint64_t)(fm & 0x3FFF) << 48) | ((uint64_t)(mm & 0xFF) << 40) | (pos & 0xFFFFFFFFFFull);
+}
 
 // One suffix-array probe: the suffix at p is where core (offset o, length cl) of strand s would sit, so the read would
 // sit at left = p - o.  Fetch the window [left, left+len) once; derive both the core ordering and the distance.
@@ -218,6 +232,7 @@ K4_DEV K4Probe k4d_probe(const K4DevIndex& ix, const K4Lane<NCH>& ln, int s, int
   }
   r.cmp = 0;
   r.mm = 0;
+  r.fm = len;
   const uint32_t* wp = ix.ref2 + (left >> 4);
   uint32_t sh = (uint32_t)(left & 15) * 2;
   uint32_t wv[2 * NCH + 1];
@@ -242,7 +257,9 @@ K4_DEV K4Probe k4d_probe(const K4DevIndex& ix, const K4Lane<NCH>& ln, int s, int
       uint64_t refc = sh ? (hi << sh) | (wv[2 * c + 2] >> (32 - sh)) : hi;
       uint64_t rdc = ln.word(s, c);
       uint64_t x = rdc ^ refc;
-      r.mm += (int)k4d_mm_count(x & k4d_range_mask(0, len - 32 * c));
+      const uint64_t xr = x & k4d_range_mask(0, len - 32 * c);
+      r.mm += (int)k4d_mm_count(xr);
+      if (xr && r.fm == len) r.fm = 32 * c + (__clzll(xr) >> 1);
       uint64_t cm = k4d_range_mask(o - 32 * c, o + cl - 32 * c);
       if (!decided && (x & cm)) {
         r.cmp = (rdc & cm) < (refc & cm) ? -1 : 1;
@@ -254,7 +271,7 @@ K4_DEV K4Probe k4d_probe(const K4DevIndex& ix, const K4Lane<NCH>& ln, int s, int
 }
 
 // One LocateCoreMultiples call for one read (SfxArray.cpp:5806-6369), fast form.  Returns tHRslt or K4_NEED_SLOW.
-template <int EL, int NCH, typename KT>
+template <int EL, int NCH, typename KT, bool CAPTURE>
 K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, int allow_mm, int cl, int core_delta,
                         const K4ReadParams& rp, int* p_inst, int* p_low, int* p_nxt, k4_hit* hits,
                         uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand) {
@@ -284,6 +301,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
     int slides = 0;
     int o_next = 0;
     bool more = true;
+    bool first_group = true;  // its core 0 sits at offset 0: the memoised lookup
     while (more && !stop) {
       // The core offsets of a strand pass depend only on (len, cl, delta) (:5948-5959), so the k-mer table entries of
       // the next K4_PF cores are fetched together before any of them is searched: one memory round trip, not K4_PF.
@@ -303,16 +321,39 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
         }
       }
       more = cnt == K4_PF;
+      bool memo_hit = false, memo_pending = false;
+      int memo_mm = 0;
 #pragma unroll
       for (int j = 0; j < K4_PF; j++) {
         if (j < cnt) {
+          if (!CAPTURE && j == 0 && first_group && tshift == 0) {
+            const uint64_t mv = ln.memo[s * 256];
+            const int kind = (int)(mv >> 62), fm = (int)((mv >> 48) & 0x3FFF), mmv = (int)((mv >> 40) & 0xFF);
+            if (kind == 1 || (kind == 2 && fm < cl)) continue;                   // nothing starts with this core
+            if (kind == 2 && mmv != 0xFF) {                                      // exactly the suffix at pos does
+              lb0[0] = 0; lb1[0] = 1; ps0[0] = (KT)(mv & 0xFFFFFFFFFFull);
+              memo_hit = true; memo_mm = mmv;
+              continue;
+            }
+          }
           const uint64_t code = ln.chunk_at(s, oo[j]) >> (64 - 2 * kk);
           k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j]);
+          if (CAPTURE && j == 0 && first_group && tshift == 0) {
+            if (lb1[0] == lb0[0]) ln.memo[s * 256] = k4d_memo_pack(1, 0, 0, 0);
+            else memo_pending = lb1[0] == lb0[0] + 1;
+          }
           // a bucket of one suffix whose next bases already disagree with the core cannot hold a match: drop it here
           if (sizeof(KT) == 4 && tshift == 0 && lb1[j] == lb0[j] + 1 && cl > kk) {
             const int nb = min(16, cl - kk);
             const uint32_t cb = (uint32_t)(ln.chunk_at(s, oo[j] + kk) >> 32);
-            if ((cb ^ sig[j]) & (0xFFFFFFFFu << (32 - 2 * nb))) lb1[j] = lb0[j];
+            const uint32_t df = (cb ^ sig[j]) & (0xFFFFFFFFu << (32 - 2 * nb));
+            if (df) {
+              lb1[j] = lb0[j];
+              if (CAPTURE && j == 0 && first_group) {
+                ln.memo[s * 256] = k4d_memo_pack(2, (uint64_t)ps0[0], 0xFF, kk + (__clz(df) >> 1));
+                memo_pending = false;
+              }
+            }
           }
         }
       }
@@ -321,7 +362,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       uint32_t touch = 0;
 #pragma unroll
       for (int j = 0; j < K4_PF; j++)
-        if (j < cnt && tshift == 0 && lb1[j] > lb0[j]) touch |= ix.ref2[((int64_t)ps0[j] - oo[j]) >> 4];
+        if (j < cnt && tshift == 0 && lb1[j] > lb0[j] && !(j == 0 && memo_hit)) touch |= ix.ref2[((int64_t)ps0[j] - oo[j]) >> 4];
 
 #pragma unroll
       for (int j = 0; j < K4_PF; j++) {
@@ -340,8 +381,13 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           // pos0 belongs to the bucket of the exact k-mer: with a core shorter than k the interval spans several
           // buckets and the first of them may be empty (pos0 unset), so the suffix array is read instead
           const uint64_t p = (tshift == 0 && mid == (int64_t)lb0[j]) ? (uint64_t)ps0[j] : k4d_sa_at<EL>(ix, (uint64_t)mid);
-          const K4Probe pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p);
-          n_probe++;
+          K4Probe pr;
+          if (!CAPTURE && j == 0 && memo_hit) { pr.cmp = 0; pr.mm = memo_mm; pr.fm = len; pr.exc = false; }
+          else {
+            pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p);
+            n_probe++;
+            if (CAPTURE && j == 0 && memo_pending) ln.memo[s * 256] = k4d_memo_pack(2, p, pr.mm > 254 ? 254 : pr.mm, pr.fm);
+          }
           if (pr.exc) return K4_NEED_SLOW;  // (handling it here instead costs the hot path 8 % in registers: measured)
           if (pr.cmp > 0) lo = mid + 1;
           else {
@@ -407,6 +453,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
         if (st.inst > rp.max_hits && st.low == 0) stop = true;
       }
       if (touch == 0x5A5A5A5Au && len < 0) n_probe++;  // never true: only keeps the touch loads alive until here
+      first_group = false;
     }
   }
   return k4d_lcm_result(*p_inst, *p_low, p_nxt, st, rp.mm_delta, rp.max_hits, p_inst, p_low);
@@ -497,7 +544,8 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
   K4Lane<NCH> ln;
   ln.rd = lds + tid;
   ln.ded = reinterpret_cast<uint32_t*>(lds + 2 * NW * 256) + tid;
-  uint64_t* ent_l = lds + 2 * NW * 256 + (K4_DEDUP_CAP * 256) / 2;
+  ln.memo = lds + 2 * NW * 256 + (K4_DEDUP_CAP * 256) / 2 + tid;
+  uint64_t* ent_l = lds + 2 * NW * 256 + (K4_DEDUP_CAP * 256) / 2 + 2 * 256;
   uint32_t* sup_l = reinterpret_cast<uint32_t*>(ent_l + 2 * K4_LDS_ENTRIES);
   ln.ent = ent_l;
   ln.sup = sup_l;
@@ -556,7 +604,11 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
         }
         slow = fl != 0 && !skip;
       } else {
-        const uint64_t* row = in_rows + (int64_t)j * (2 * NCH);
+        const uint64_t* row = in_rows + (int64_t)j * K4_ROW_WORDS(NCH);
+        {
+          const k4_u64x2_a8 mv = *reinterpret_cast<const k4_u64x2_a8*>(row + 2 * NCH);
+          ln.memo[0] = mv.x; ln.memo[256] = mv.y;
+        }
         uint64_t rw[2 * NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {  // rows are 16-byte aligned: NCH 16-byte loads
@@ -586,7 +638,8 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
         k4_hit* hits = a.hits + i * a.max_hits;
         int inst = 0, low = 0, nxt = 0;
         const uint32_t c0 = n_lookup, c1 = n_probe, c2 = n_cand;
-        int rslt = k4d_lcm_fast<EL, NCH, KT>(a, ln, len, allow, cl, delta, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
+        if (FIRST) { ln.memo[0] = K4_MEMO_NONE; ln.memo[256] = K4_MEMO_NONE; }
+        int rslt = k4d_lcm_fast<EL, NCH, KT, FIRST>(a, ln, len, allow, cl, delta, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
         if (rslt == K4_NEED_SLOW) {  // the general kernel redoes (and tallies) this phase
           slow = true;
           n_lookup = c0; n_probe = c1; n_cand = c2;
@@ -613,7 +666,7 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
       if (survive) {
         const uint32_t slot = ch_cur + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         out_ids[slot] = (uint32_t)i;
-        uint64_t* row = out_rows + (int64_t)slot * (2 * NCH);
+        uint64_t* row = out_rows + (int64_t)slot * K4_ROW_WORDS(NCH);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
           k4_u64x2_a8 v;
@@ -621,6 +674,11 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
           v.x = w0 < NCH ? col[w0 * 256] : col[(NW + w0 - NCH) * 256];
           v.y = w1 < NCH ? col[w1 * 256] : col[(NW + w1 - NCH) * 256];
           *reinterpret_cast<k4_u64x2_a8*>(row + 2 * c) = v;
+        }
+        {
+          k4_u64x2_a8 mv;
+          mv.x = ln.memo[0]; mv.y = ln.memo[256];
+          *reinterpret_cast<k4_u64x2_a8*>(row + 2 * NCH) = mv;
         }
       }
       ch_cur += cnt;
@@ -957,7 +1015,7 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
     const size_t slots = (size_t)cap + (size_t)2048 * 4 * K4_CHUNK;
     for (int b = 0; b < 2; b++) {
       K4_HIP(ix, hipMalloc(&w.ids[b], slots * 4));
-      K4_HIP(ix, hipMalloc(&w.rows[b], slots * 2 * nch * 8));
+      K4_HIP(ix, hipMalloc(&w.rows[b], slots * K4_ROW_WORDS(nch) * 8));
     }
     K4_HIP(ix, hipMalloc(&w.slow_list, (size_t)cap * 4));
     K4_HIP(ix, hipMalloc(&w.slow_step, (size_t)cap));
@@ -991,7 +1049,7 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
 template <int EL, int NCH, typename KT>
 static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t st) {
   K4Workspace& w = ix->ws;
-  const size_t lds = (size_t)2 * (NCH + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4 + (size_t)2 * K4_LDS_ENTRIES * 8 +
+  const size_t lds = (size_t)2 * (NCH + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4 + (size_t)2 * 256 * 8 + (size_t)2 * K4_LDS_ENTRIES * 8 +
                      (size_t)K4_SUP_WORDS * 4 + 16;
   if (lds > 48 * 1024) {
     K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -25,7 +25,7 @@
 // entries   start/end offsets and ids of the chromosomes (tsSfxEntry), sorted by start.
 #define K4_EXC_SHIFT 8            // log2 of the exception-bitmap block size in bases
 #define K4_EXC_BLOCK (1 << K4_EXC_SHIFT)
-#define K4_SUP_WORDS 1024          // LDS-resident coarse exception bitmap: 32 Kbit, one bit per 2^sup_shift bases
+#define K4_SUP_WORDS 512           // LDS-resident coarse exception bitmap: 16 Kbit, one bit per 2^sup_shift bases
 #define K4_LDS_ENTRIES 128         // chromosome tables up to this size are searched in LDS
 #define K4_PAD_BASES 2048
 #define K4_PAD_WORDS (K4_PAD_BASES / 16)
