@@ -137,6 +137,90 @@ def make_pe_reads(seq, n_chrom, chrom_len, n_pairs, read_len, seed, dev, frag_mi
     return reads, truth
 
 
+def write_fasta(reads, path, dev):
+    """reads [m, L] u8 on the GPU -> FASTA file '>r%08d' + bases"""
+    m, L = reads.shape
+    W = 10 + L + 1
+    text = torch.empty((m, W), dtype=torch.uint8, device=dev)
+    text[:, 0] = ord(">")
+    text[:, 1] = ord("r")
+    idx = torch.arange(m, device=dev)
+    for d in range(8):
+        text[:, 2 + d] = ((idx // (10 ** (7 - d))) % 10 + 48).to(torch.uint8)
+    text[:, 9] = 10
+    text[:, 10:10 + L] = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)[reads.long()]
+    text[:, W - 1] = 10
+    text.cpu().numpy().tofile(path)
+
+
+def time_reference(ix, reads, pe, L, max_subs, cores, sample, dev, log_fn):
+    """The REAL reference (`oracle/_ref/ngskit4b kalign`, built from /root/reference by oracle/Makefile and shipped with the
+    snapshot) on the host cores, same index written as a .sfx file, first `sample` reads.  Returns the cpu_baseline dict
+    or None.  Alignment time = the log interval "Now aligning" -> "Alignment of ... completed" (KAligner.cpp:9393-9470);
+    it contains kit4b's own 5 s start-up sleep (:9432-9437), during which its worker threads already align."""
+    import datetime
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    ngs = os.path.join(ROOT, "oracle", "_ref", "ngskit4b")
+    if not os.path.exists(ngs):
+        return None
+    tmp = tempfile.mkdtemp(prefix="k4bench_")
+    try:
+        info = ix.info()
+        need = info["concat_len"] * (1 + info["sfx_el_size"]) + 3 * sample * (L + 80)
+        if shutil.disk_usage(tmp).free < need * 1.1:
+            log_fn("reference baseline skipped: %s has too little free space" % tmp)
+            return None
+        sfx = os.path.join(tmp, "g.sfx")
+        ix.write_sfx(sfx)
+        files = []
+        if pe:
+            f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
+            write_fasta(reads[0:sample:2], f1, dev)
+            write_fasta(reads[1:sample:2], f2, dev)
+            files = ["-i", f1, "-u", f2, "-U2", "-d200", "-D600"]
+        else:
+            f1 = os.path.join(tmp, "r.fa")
+            write_fasta(reads[:sample], f1, dev)
+            files = ["-i", f1]
+        logf = os.path.join(tmp, "ref.log")
+        t0 = time.time()
+        r = subprocess.run([ngs, "kalign", "-I", sfx, "-o", os.path.join(tmp, "ref.sam"), "-T", str(cores), "-F", logf,
+                            "-s%d" % max_subs] + files, capture_output=True, timeout=900)
+        wall = time.time() - t0
+        if r.returncode != 0:
+            log_fn("reference baseline failed: rc %d" % r.returncode)
+            return None
+        t_start = t_end = None
+        hist = {}
+        for ln in open(logf, errors="replace"):
+            m = re.match(r"\[(\w+ +\d+ [\d:.]+ \d+)\]", ln)
+            ts = datetime.datetime.strptime(m.group(1), "%b %d %H:%M:%S.%f %Y") if m else None
+            if ts and "Now aligning with minimum core size" in ln:
+                t_start = ts
+            if ts and re.search(r"Alignment of \d+ from \d+ loaded completed", ln):
+                t_end = ts
+            h = re.search(r"\)\s+(\d+) \((\w\w)\) ", ln)
+            if h:
+                hist[h.group(2)] = int(h.group(1))
+        if not (t_start and t_end):
+            return None
+        t_al = (t_end - t_start).total_seconds()
+        return {"value": sample / t_al / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "reference",
+                "sample": "first %d reads, oracle/_ref/ngskit4b kalign -s%d -T%d on the same index as a %.1f GB .sfx file; "
+                          "align phase %.1f s by its log (includes kit4b's 5 s start-up sleep, worker threads already "
+                          "running), whole run %.1f s" % (sample, max_subs, cores, os.path.getsize(sfx) / 1e9, t_al, wall),
+                "align_s": t_al, "wall_s": wall, "nar": {k: v for k, v in hist.items() if v}}
+    except Exception as e:  # the port's number is still reported
+        log_fn("reference baseline failed: %r" % (e,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +238,8 @@ def main():
     ap.add_argument("--kmer-k", type=int, default=0)
     ap.add_argument("--n-frac", type=float, default=0.0, help="fraction of reads given one N (general-kernel stress; not the BASELINE workload)")
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="upper bound on reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--ref-sample", type=int, default=8_000_000,
+                    help="reads given to the real reference binary (oracle/_ref/ngskit4b) when it is present (0 = skip)")
     args = ap.parse_args()
     wl = {"c2": (24, 50_000_000, 100, 2, False), "c3": (24, 50_000_000, 150, 2, True), "c5": (120, 40_000_000, 150, 3, True)}[args.workload]
     args.chroms = wl[0] if args.chroms is None else args.chroms
@@ -358,6 +444,18 @@ def main():
             parity_sample = {"reads": S, "result_mismatches": int((g_out != o_out).any(axis=1).sum()),
                              "hit_mismatches": int((g_hits != o_hits).any(axis=1).sum())}
         O.close(ho)
+        del seq_h, sa_h
+        # the reference itself, when its binary travelled with the snapshot: that number becomes cpu_baseline, the
+        # port's stays beside it (and is what the read-for-read comparison above ran against)
+        if args.ref_sample > 0:
+            Sr = min(args.ref_sample, n_reads) & ~1
+            ref = time_reference(ix, reads, pe, L, args.max_subs, cores, Sr, dev, lambda *a: log(rank, *a))
+            if ref is not None:
+                g_nar = torch.bincount(out[:Sr, 4].to(torch.int64), minlength=20).tolist()
+                ref["nar_equal_to_gpu"] = all(ref["nar"].get(k, 0) == g_nar[c] for k, c in
+                                              (("AA", 1), ("EN", 2), ("NL", 3), ("MH", 4), ("ML", 5), ("UP", 15)))
+                ref["port"] = cpu
+                cpu = ref
 
     if rank == 0:
         total_reads = n_reads * world * args.steps
