@@ -1,7 +1,8 @@
 """Full-scale check against the REAL reference on the GPU box's host cores (run through gpurun; needs oracle/_ref/ngskit4b,
 which travels with the snapshot):  3 Gbp index built on the GPU -> .sfx file -> `ngskit4b kalign -s2 -T<cores>` and
 `k4align` on the same FASTA -> SAM records compared, both timed.
-    python tools/ref_fullscale.py [n_reads=2000000] [chroms=24] [chrom_mbp=125] [threads=16]"""
+    python tools/ref_fullscale.py [n_reads=2000000] [chroms=24] [chrom_mbp=125] [threads=16] [pe_mode=0] [read_len=100]
+pe_mode 1..4: n_reads pairs of 2 x read_len, `-U<pe_mode> -d200 -D600` on both programs."""
 import json
 import os
 import re
@@ -23,10 +24,11 @@ n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 n_chrom = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 chrom_len = int(float(sys.argv[3]) * 1e6) if len(sys.argv) > 3 else 125_000_000
 threads = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+pe_mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 NGS = os.path.join(ROOT, "oracle", "_ref", "ngskit4b")
 K4ALIGN = os.path.join(ROOT, "kit4b_amd", "k4align")
 assert os.path.exists(NGS), "oracle/_ref/ngskit4b missing (make -C oracle ngskit4b where /root/reference exists)"
-L = 100
+L = int(sys.argv[6]) if len(sys.argv) > 6 else 100
 tmp = tempfile.mkdtemp(prefix="k4ref_")
 print("scratch", tmp, "free GB", shutil.disk_usage(tmp).free / 1e9, flush=True)
 dev = torch.device("cuda:0")
@@ -42,25 +44,24 @@ sfx = os.path.join(tmp, "g.sfx")
 t0 = time.time()
 ix.write_sfx(sfx)
 print("wrote %s (%.1f GB) in %.1fs" % (sfx, os.path.getsize(sfx) / 1e9, time.time() - t0), flush=True)
-reads, truth = bench.make_reads(seq, n_chrom, chrom_len, n_reads, L, bench.READS_SEED, dev)
-W = 10 + L + 1  # ">r%08d\n" + bases + "\n"
-text = torch.empty((n_reads, W), dtype=torch.uint8, device=dev)
-text[:, 0] = ord(">"); text[:, 1] = ord("r")
-idx = torch.arange(n_reads, device=dev)
-for d in range(8):
-    text[:, 2 + d] = ((idx // (10 ** (7 - d))) % 10 + 48).to(torch.uint8)
-text[:, 9] = 10
-text[:, 10:10 + L] = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)[reads.long()]
-text[:, W - 1] = 10
-fa = os.path.join(tmp, "reads.fa")
-text.cpu().numpy().tofile(fa)
+if pe_mode:
+    reads, truth = bench.make_pe_reads(seq, n_chrom, chrom_len, n_reads, L, bench.READS_SEED + 2, dev)
+    fa, fa2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
+    bench.write_fasta(reads[0::2], fa, dev)
+    bench.write_fasta(reads[1::2], fa2, dev)
+    in_args = ["-i", fa, "-u", fa2, "-U%d" % pe_mode, "-d200", "-D600"]
+else:
+    reads, truth = bench.make_reads(seq, n_chrom, chrom_len, n_reads, L, bench.READS_SEED, dev)
+    fa = os.path.join(tmp, "reads.fa")
+    bench.write_fasta(reads, fa, dev)
+    in_args = ["-i", fa]
 ix.close()
-del seq, sa, reads, text
+del seq, sa, reads
 torch.cuda.empty_cache()
 
 ref_sam, ref_log = os.path.join(tmp, "ref.sam"), os.path.join(tmp, "ref.log")
 t0 = time.time()
-r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log, "-s2", "-i", fa], capture_output=True)
+r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log, "-s2"] + in_args, capture_output=True)
 t_ref = time.time() - t0
 print("reference rc", r.returncode, "wall %.1fs" % t_ref, flush=True)
 log = open(ref_log, errors="replace").read() if os.path.exists(ref_log) else ""
@@ -69,7 +70,7 @@ print("\n".join(keep[-40:]), flush=True)
 
 gpu_sam = os.path.join(tmp, "gpu.sam")
 t0 = time.time()
-g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam, "-s2", "-i", fa], capture_output=True, text=True)
+g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam, "-s2"] + in_args, capture_output=True, text=True)
 t_gpu = time.time() - t0
 print("k4align rc", g.returncode, "wall %.1fs" % t_gpu)
 print(g.stderr[-1500:], flush=True)
@@ -88,11 +89,11 @@ hg, rg = body(gpu_sam)
 same_hdr = hr == hg
 same_order = rr == rg
 same_set = sorted(rr) == sorted(rg)
-out = {"reads": n_reads, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
+out = {"reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
        "reference_sam_records": len(rr), "k4align_sam_records": len(rg), "headers_equal": same_hdr,
        "records_equal_as_multiset": same_set, "records_equal_in_order": same_order}
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"summary": out, "reference_log_tail": keep[-40:], "k4align_stderr": g.stderr[-3000:]},
-          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale.json"), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s.json" % ("_pe%d" % pe_mode if pe_mode else "")), "w"), indent=1)
 shutil.rmtree(tmp, ignore_errors=True)
