@@ -148,7 +148,7 @@ def write_fasta(reads, path, dev):
     for d in range(8):
         text[:, 2 + d] = ((idx // (10 ** (7 - d))) % 10 + 48).to(torch.uint8)
     text[:, 9] = 10
-    text[:, 10:10 + L] = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)[reads.long()]
+    text[:, 10:10 + L] = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)[reads.long().clamp_(max=4)]
     text[:, W - 1] = 10
     text.cpu().numpy().tofile(path)
 

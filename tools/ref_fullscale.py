@@ -1,7 +1,8 @@
 """Full-scale check against the REAL reference on the GPU box's host cores (run through gpurun; needs oracle/_ref/ngskit4b,
 which travels with the snapshot):  3 Gbp index built on the GPU -> .sfx file -> `ngskit4b kalign -s2 -T<cores>` and
 `k4align` on the same FASTA -> SAM records compared, both timed.
-    python tools/ref_fullscale.py [n_reads=2000000] [chroms=24] [chrom_mbp=125] [threads=16] [pe_mode=0] [read_len=100]
+    python tools/ref_fullscale.py [n_reads=2000000] [chroms=24] [chrom_mbp=125] [threads=16] [pe_mode=0] [read_len=100] [repeats=0]
+repeats > 0: that many segment copies (high-copy families and pairs, 0-3 % diverged) and N runs are implanted first.
 pe_mode 1..4: n_reads pairs of 2 x read_len, `-U<pe_mode> -d200 -D600` on both programs."""
 import json
 import os
@@ -34,6 +35,37 @@ print("scratch", tmp, "free GB", shutil.disk_usage(tmp).free / 1e9, flush=True)
 dev = torch.device("cuda:0")
 seq = bench.make_genome(dev, n_chrom, chrom_len)
 n = seq.numel()
+n_rep = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+if n_rep:
+    g = torch.Generator(device=dev); g.manual_seed(4242)
+    fam_src = torch.randint(0, n_chrom * (chrom_len - 6000), (50,), device=dev, generator=g)
+    for r in range(n_rep):
+        ln = int(torch.randint(150, 5000, (1,), device=dev, generator=g))
+        if r % 2 == 0:
+            u = int(fam_src[r % 50])                       # a high-copy family
+        else:
+            u = int(torch.randint(0, n_chrom * (chrom_len - 6000), (1,), device=dev, generator=g))
+        c, o = divmod(u, chrom_len - 6000)
+        src = c * (chrom_len + 1) + o
+        v = int(torch.randint(0, n_chrom * (chrom_len - 6000), (1,), device=dev, generator=g))
+        c2, o2 = divmod(v, chrom_len - 6000)
+        dst = c2 * (chrom_len + 1) + o2
+        seg = seq[src:src + ln].clone()
+        rate = (r % 4) * 0.01
+        if rate:
+            mut = torch.rand(ln, device=dev, generator=g) < rate
+            seg = torch.where(mut & (seg < 4), (seg + torch.randint(1, 4, (ln,), device=dev, generator=g, dtype=torch.uint8)) % 4, seg)
+        if r % 3 == 0:
+            seg = torch.where(seg < 4, 3 - seg, seg).flip(0)    # inverted copy (N stays N)
+        seq[dst:dst + ln] = torch.where(seq[dst:dst + ln] == 7, seq[dst:dst + ln], seg)
+    for r in range(max(1, n_rep // 20)):                    # N runs
+        v = int(torch.randint(0, n_chrom * (chrom_len - 6000), (1,), device=dev, generator=g))
+        c2, o2 = divmod(v, chrom_len - 6000)
+        dst = c2 * (chrom_len + 1) + o2
+        ln = int(torch.randint(1, 300, (1,), device=dev, generator=g))
+        seq[dst:dst + ln] = 4
+    assert int(((seq > 4) & (seq != 7)).sum()) == 0
+    print("implanted %d repeat copies" % n_rep, flush=True)
 el = 4 if n < 4_000_000_000 else 5
 sa = torch.empty(n * el + 16, dtype=torch.uint8, device=dev)
 k4.build_sa_device(n, el, seq.data_ptr(), sa.data_ptr())
@@ -89,11 +121,11 @@ hg, rg = body(gpu_sam)
 same_hdr = hr == hg
 same_order = rr == rg
 same_set = sorted(rr) == sorted(rg)
-out = {"reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
+out = {"repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
        "reference_sam_records": len(rr), "k4align_sam_records": len(rg), "headers_equal": same_hdr,
        "records_equal_as_multiset": same_set, "records_equal_in_order": same_order}
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"summary": out, "reference_log_tail": keep[-40:], "k4align_stderr": g.stderr[-3000:]},
-          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s.json" % ("_pe%d" % pe_mode if pe_mode else "")), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", "_rep" if n_rep else "")), "w"), indent=1)
 shutil.rmtree(tmp, ignore_errors=True)
