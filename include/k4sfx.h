@@ -108,7 +108,9 @@ typedef struct {
   int32_t pmode;          /* -m 0 default,1 more,2 ultra,3 less sensitive (KAligner.cpp:9377-9393) */
   int32_t strand;         /* K4_STRAND_* */
   int32_t max_ml;         /* max(m_MaxMLmatches, PE ? cMaxMLPEmatches : 0) (KAligner.cpp:9604) */
-  int32_t pe_mode;        /* 0: SE classification, 1: PE classification (KAligner.cpp:9982-10023) */
+  int32_t pe_mode;        /* classification of a read with hits (KAligner.cpp:9907-10023): 0 SE, default MLMode (accepted,
+                           * first instance); 1 PE (accepted iff one instance, else multi-aligned with NumHits = instances);
+                           * 2 SE, MLMode eMLall (`-r5 -R<max_ml>`): accepted with NumHits = instances, every one reported */
   int32_t min_core_len;   /* 0: derive as LocateCoredApprox does (KAligner.cpp:9367-9393) */
   int32_t max_num_slides; /* 0: derive from pmode */
 } k4_kalign_params;
@@ -245,7 +247,8 @@ int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, const k4_pe_
  * k4_format_sam_dev    <- WriteBAMReadHits (:5718-5914) / ReportBAMread (:5957-6320) / SortHitMatch (:10969) /
  *                         CSAMfile::AddAlignment (SAMfile.cpp:2194-2377): the accepted reads as SAM lines in coordinate
  *                         order (chrom, start, len, strand, mismatches, then load order), in a buffer this call
- *                         allocates (*d_sam, release with k4_free_device); header lines are the caller's.  Also the
+ *                         allocates (*d_sam, release with k4_free_device); header lines are the caller's.  SE with
+ *                         max_ml > 1 (eMLall): a read contributes one line per reported instance (NumHits).  Also the
  *                         ReportAlignStats tallies and which chromosomes received a hit (for the @SQ rule of :5785-5821). */
 enum { K4_FASTA = 1, K4_FASTQ = 2 };
 typedef struct {

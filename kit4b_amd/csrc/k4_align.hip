@@ -164,7 +164,8 @@ K4_DEV void k4d_finalize(const K4AlignArgs& a, int64_t i, int len, const K4ReadP
   switch (rslt) {
     case K4_HR_NONE: r.inst = 0; r.low_mm = 0; r.nxt_mm = 0; break;
     case K4_HR_HITS:
-      if (!a.kp.pe_mode || inst == 1) { r.nar = K4_NAR_ACCEPTED; r.num_hits = 1; }
+      if (a.kp.pe_mode == 2) { r.nar = K4_NAR_ACCEPTED; r.num_hits = min(inst, rp.max_hits); }  // eMLall: every instance is reported (:9913-9931)
+      else if (!a.kp.pe_mode || inst == 1) { r.nar = K4_NAR_ACCEPTED; r.num_hits = 1; }
       else { r.nar = K4_NAR_MULTIALIGN; r.num_hits = inst; }
       break;
     case K4_HR_MMDELTA: r.nar = K4_NAR_MMDELTA; break;
@@ -1170,7 +1171,7 @@ static int resolve_kalign(k4_index* ix, const k4_kalign_params* p, k4_kalign_par
   if (!p) return K4_ERR_PARAMS;
   *out = *p;
   if (p->max_subs < 0 || p->max_subs > 15 || (p->min_edit_dist != 1 && p->min_edit_dist != 2) || p->max_ns < 0 ||
-      p->strand < 0 || p->strand > 2 || p->max_ml < 1 || p->max_ml > 4096)
+      p->strand < 0 || p->strand > 2 || p->max_ml < 1 || p->max_ml > 4096 || p->pe_mode < 0 || p->pe_mode > 2)
     return k4_fail(ix, K4_ERR_PARAMS, "kalign parameters out of range");
   int slides = 0;
   int mcl = k4_min_core_len(ix, p->pmode, &slides);

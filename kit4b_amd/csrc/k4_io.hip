@@ -314,8 +314,17 @@ struct K4SamArgs {
 };
 #define K4_SAM_NAME_STRIDE 96
 
+// A SAM line is addressed by v = read * vm + instance (vm = max_ml for SE, 1 for PE): with MLMode eMLall a read with
+// NumHits instances yields that many lines (CKAligner::WriteHitLoci, KAligner.cpp:6922-6990).
 K4_DEV int k4d_sam_nar(const K4SamArgs& a, int64_t i) { return a.pe ? a.pr[i].nar : a.rr[i].nar; }
-K4_DEV k4_hit k4d_sam_hit(const K4SamArgs& a, int64_t i) { return a.pe ? a.pr[i].hit : a.hits[(size_t)i * a.max_ml]; }
+K4_DEV int64_t k4d_sam_read(const K4SamArgs& a, int64_t v) { return a.pe ? v : v / a.max_ml; }
+K4_DEV k4_hit k4d_sam_hit(const K4SamArgs& a, int64_t v) { return a.pe ? a.pr[v].hit : a.hits[v]; }
+K4_DEV bool k4d_sam_reported(const K4SamArgs& a, int64_t v) {
+  if (a.pe) return a.pr[v].nar == K4_NAR_ACCEPTED;
+  const int64_t i = v / a.max_ml;
+  const k4_read_result r = a.rr[i];
+  return r.nar == K4_NAR_ACCEPTED && (int)(v - i * a.max_ml) < max(r.num_hits, 1);
+}
 
 struct K4SamFields {
   uint32_t flag, pos, mapq, len, pnext;
@@ -323,7 +332,8 @@ struct K4SamFields {
   bool mate_eq;
 };
 // ReportBAMread (KAligner.cpp:6041-6146,6231): FLAG, MAPQ = max(1, 254 * hitlen / readlen), mate fields
-K4_DEV K4SamFields k4d_sam_fields(const K4SamArgs& a, int64_t i, const k4_hit& h) {
+K4_DEV K4SamFields k4d_sam_fields(const K4SamArgs& a, int64_t v, const k4_hit& h) {
+  const int64_t i = k4d_sam_read(a, v);
   K4SamFields f;
   f.pos = h.match_loci + 1;
   f.len = h.match_len;
@@ -363,7 +373,7 @@ K4_DEV uint32_t k4d_put_uint(char* p, uint32_t v) {  // returns digits written
 
 struct IsAccepted {
   K4SamArgs a;
-  __device__ bool operator()(uint32_t i) const { return k4d_sam_nar(a, i) == K4_NAR_ACCEPTED; }
+  __device__ bool operator()(uint32_t v) const { return k4d_sam_reported(a, v); }
 };
 
 // secondary key of SortHitMatch (len, strand, mismatches) and primary key (chrom, start)
@@ -391,18 +401,23 @@ __global__ void __launch_bounds__(256) k4k_sam_stats(K4SamArgs a, unsigned long 
     const int nar = k4d_sam_nar(a, i);
     atomicAdd(&h[nar >= 0 && nar < 20 ? nar : 0], 1u);
     if (nar == K4_NAR_ACCEPTED) {
-      const k4_hit hh = k4d_sam_hit(a, i);
-      atomicAdd(&h[hh.strand == '+' ? 20 : 21], 1u);
-      if (chrom_hit && hh.chrom_id <= a.n_entries) chrom_hit[hh.chrom_id] = 1;
+      const int vm = a.pe ? 1 : a.max_ml;
+      for (int q = 0; q < vm; q++) {
+        if (!k4d_sam_reported(a, i * vm + q)) break;
+        const k4_hit hh = k4d_sam_hit(a, i * vm + q);
+        atomicAdd(&h[hh.strand == '+' ? 20 : 21], 1u);
+        if (chrom_hit && hh.chrom_id <= a.n_entries) chrom_hit[hh.chrom_id] = 1;
+      }
     }
   }
   __syncthreads();
   if (threadIdx.x < 22 && h[threadIdx.x]) atomicAdd(&st[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
-K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t i) {
-  const k4_hit h = k4d_sam_hit(a, i);
-  const K4SamFields f = k4d_sam_fields(a, i, h);
+K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t v) {
+  const k4_hit h = k4d_sam_hit(a, v);
+  const K4SamFields f = k4d_sam_fields(a, v, h);
+  const int64_t i = k4d_sam_read(a, v);
   const int w = a.pe ? (int)(i & 1) : 0;
   const int64_t rec = a.pe ? (i >> 1) : i;
   uint32_t n = a.name_len[w][rec] + 1 + k4d_udigits(f.flag) + 1 + a.cname_len[h.chrom_id - 1] + 1 + k4d_udigits(f.pos) + 1 +
@@ -423,13 +438,14 @@ __global__ void __launch_bounds__(64) k4k_sam_write(K4SamArgs a, const uint32_t*
   __shared__ uint32_t midn[2];
   const int lane = threadIdx.x;
   for (uint64_t j = blockIdx.x; j < m; j += gridDim.x) {
-    const int64_t i = order[j];
-    const k4_hit h = k4d_sam_hit(a, i);
+    const int64_t v = order[j];
+    const k4_hit h = k4d_sam_hit(a, v);
+    const int64_t i = k4d_sam_read(a, v);
     const int w = a.pe ? (int)(i & 1) : 0;
     const int64_t rec = a.pe ? (i >> 1) : i;
     __syncthreads();
     if (lane == 0) {
-      const K4SamFields f = k4d_sam_fields(a, i, h);
+      const K4SamFields f = k4d_sam_fields(a, v, h);
       char* p = mid[0];
       uint32_t n = 0;
       p[n++] = '\t'; n += k4d_put_uint(p + n, f.flag); p[n++] = '\t';
@@ -508,7 +524,8 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
   if (n_units < 0) return k4_fail(ix, K4_ERR_PARAMS, "negative count");
   if (n_units == 0) return K4_OK;
   const int64_t n_reads = pe ? 2 * n_units : n_units;
-  if (n_reads >= 0xFFFFFF00ll) return k4_fail(ix, K4_ERR_PARAMS, "at most 2^32-256 reads per call");
+  const int64_t n_virt = pe ? n_reads : n_reads * (int64_t)std::max(max_ml, 1);  // addressable SAM lines
+  if (n_virt >= 0xFFFFFF00ll) return k4_fail(ix, K4_ERR_PARAMS, "at most 2^32-256 reads x instances per call");
   if ((pe && !d_pe) || (!pe && (!d_rr || !d_hits || max_ml < 1)) || !d_reads || !d_offs || !d_lens || !names->d_text[0] ||
       !names->d_name_off[0] || !names->d_name_len[0] || (pe && (!names->d_text[1] || !names->d_name_off[1] || !names->d_name_len[1])))
     return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
@@ -548,14 +565,14 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
   K4_HIP(ix, hipMemsetAsync(chb.p, 0, ne + 1, st));
   hipLaunchKernelGGL(k4k_sam_stats, dim3(2048), dim3(256), 0, st, a, stb.as<unsigned long long>(), chb.as<uint8_t>());
   // accepted reads, in load order
-  K4_HIP(ix, idx0.alloc((size_t)n_reads * 4));
+  K4_HIP(ix, idx0.alloc((size_t)n_virt * 4));
   {
     rocprim::counting_iterator<uint32_t> all(0);
     IsAccepted pred{a};
     size_t tb = 0;
-    K4_HIP(ix, rocprim::select(nullptr, tb, all, idx0.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)n_reads, pred, st));
+    K4_HIP(ix, rocprim::select(nullptr, tb, all, idx0.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)n_virt, pred, st));
     K4_HIP(ix, tmp.alloc(tb));
-    K4_HIP(ix, rocprim::select(tmp.p, tb, all, idx0.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)n_reads, pred, st));
+    K4_HIP(ix, rocprim::select(tmp.p, tb, all, idx0.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)n_virt, pred, st));
   }
   uint64_t m = 0;
   K4_HIP(ix, hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, st));

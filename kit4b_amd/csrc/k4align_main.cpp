@@ -10,7 +10,7 @@
 //   statistics           CKAligner::ReportAlignStats :3600-3830 (NAR histogram, strand counts)
 //   SAM                  CKAligner::WriteBAMReadHits :5718-5914, ReportBAMread :5957-6320, SortHitMatch :10969,
 //                        CSAMfile::AddAlignment libkit4b/SAMfile.cpp:2194-2377 -> k4_format_sam_dev; header :1615,1667-1669,1799
-// Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L (plus -g <gpu>).
+// Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R (plus -g <gpu>).
 #include <zlib.h>
 #include <algorithm>
 #include <chrono>
@@ -27,6 +27,7 @@ struct Opts {
   std::string in1, in2, sfx, out;
   int max_subs = 5, min_edit = 1, pmode = 0, max_ns = 1, pe_mode = 0, pair_min = 100, pair_max = 1000, pair_strand = 0;
   int min_len = 50, max_len = 500;  // cDfltMinAcceptReadLen / cDfltMaxAcceptReadLen, KAligner.h:112-113
+  int ml_mode = 0, max_multi = 0;   // -r / -R (etMLMode, KAligner.h:250-258)
   int gpu = 0;
 };
 
@@ -107,7 +108,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-u mates] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-g gpu=0]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0|1|5] [-R maxmulti=5] [-g gpu=0]\n");
 }
 
 }  // namespace
@@ -133,6 +134,8 @@ int main(int argc, char** argv) {
       case 'E': o.pair_strand = 1; break;
       case 'l': o.min_len = atoi(val().c_str()); break;
       case 'L': o.max_len = atoi(val().c_str()); break;
+      case 'r': o.ml_mode = atoi(val().c_str()); break;
+      case 'R': o.max_multi = atoi(val().c_str()); break;
       case 'g': o.gpu = atoi(val().c_str()); break;
       case 'b': (void)val(); break;  // (batch size of earlier versions: the whole input is one device batch now)
       case 'T': case 'F': (void)val(); break;  // accepted and ignored (threads, log file)
@@ -141,6 +144,16 @@ int main(int argc, char** argv) {
   }
   if (o.in1.empty() || o.sfx.empty() || o.out.empty()) { usage(); return 1; }
   const bool pe = !o.in2.empty();
+  // multi-loci modes (KAlignerCL.cpp:686-707): 0 slough, 1 statistics only, 5 report every locus up to -R; the modes that
+  // pick or cluster one locus (2 random, 3/4 AssignMultiMatches) are not part of this path
+  if (o.ml_mode != 0 && o.ml_mode != 1 && o.ml_mode != 5) { fprintf(stderr, "k4align: -r%d is not supported (0, 1 and 5 are)\n", o.ml_mode); return 1; }
+  if (o.ml_mode != 0 && pe) { fprintf(stderr, "k4align: multiloci processing '-r%d' not supported in paired end processing\n", o.ml_mode); return 1; }
+  int max_ml = 1;
+  if (o.ml_mode != 0) {
+    max_ml = o.max_multi ? o.max_multi : 5;  // cDfltMaxMultiHits
+    const int lim = o.ml_mode == 5 ? 100000 : 500;  // cMaxAllHits / cMaxMultiHits
+    if (max_ml < 2 || max_ml > lim) { fprintf(stderr, "k4align: -R%d outside of range 2..%d\n", max_ml, lim); return 1; }
+  }
   if (pe && o.pe_mode == 0) o.pe_mode = 1;  // kalign: -u without -U defaults to orphan recovery
   if (!pe) o.pe_mode = 0;
 
@@ -182,14 +195,15 @@ int main(int argc, char** argv) {
   auto t_parse = std::chrono::steady_clock::now();
 
   // ---- align (ProcCoredApprox / ProcessPairedEnds) -----------------------------------------------------------------
-  k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, 1, 0, mcl, slides};
+  k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, max_ml, o.ml_mode == 5 ? 2 : o.ml_mode == 1 ? 1 : 0,
+                         mcl, slides};
   k4_pe_params pp = {o.pe_mode, o.pair_min, o.pair_max, o.pair_strand};
   void *d_rr = nullptr, *d_hits = nullptr, *d_pe = nullptr;
   if (n > 0 && max_len > 0) {
     if (!pe) {
       CK(k4_alloc_device(ix, (uint64_t)n * sizeof(k4_read_result), &d_rr));
-      CK(k4_alloc_device(ix, (uint64_t)n * sizeof(k4_hit), &d_hits));
-      CK(k4_reserve(ix, n, (int32_t)max_len, 1));
+      CK(k4_alloc_device(ix, (uint64_t)n * max_ml * sizeof(k4_hit), &d_hits));
+      CK(k4_reserve(ix, n, (int32_t)max_len, max_ml));
       CK(k4_kalign_batch_dev(ix, &kp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_rr, d_hits, nullptr));
     } else {
       CK(k4_alloc_device(ix, (uint64_t)2 * n * sizeof(k4_pe_read), &d_pe));
@@ -207,7 +221,7 @@ int main(int argc, char** argv) {
   memset(&stt, 0, sizeof(stt));
   std::vector<uint8_t> hit_chrom(info.n_entries + 1, 0);
   if (n > 0 && max_len > 0)
-    CK(k4_format_sam_dev(ix, pe ? 1 : 0, n, d_rr, d_hits, 1, d_pe, d_reads, d_offs, d_lens, &nm, &d_sam, &sam_bytes, &stt,
+    CK(k4_format_sam_dev(ix, pe ? 1 : 0, n, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, &nm, &d_sam, &sam_bytes, &stt,
                          hit_chrom.data(), nullptr));
   auto t1c = std::chrono::steady_clock::now();
 

@@ -650,7 +650,8 @@ static int align_read_with(const k4o_index* ix, const k4o_kalign_params* kp, int
       out->nar = K4O_NAR_NOHIT; out->low_mm = 0; out->inst = 0; out->nxt_mm = 0; /* tsReadHit fields as AlignRead leaves them */
       break;
     case K4O_HR_HITS: /* :9907-10025 */
-      if (!kp->pe_mode || inst == 1) { out->nar = K4O_NAR_ACCEPTED; out->num_hits = 1; }
+      if (kp->pe_mode == 2) { out->nar = K4O_NAR_ACCEPTED; out->num_hits = inst < max_ml ? inst : max_ml; } /* eMLall :9913-9931 */
+      else if (!kp->pe_mode || inst == 1) { out->nar = K4O_NAR_ACCEPTED; out->num_hits = 1; }
       else { out->nar = K4O_NAR_MULTIALIGN; out->num_hits = inst; }
       break;
     case K4O_HR_MMDELTA: out->nar = K4O_NAR_MMDELTA; break;        /* :10027-10039 */

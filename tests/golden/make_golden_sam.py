@@ -25,7 +25,10 @@ CASES = {
     "se_s2": (["-s2"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4321, n_prob=0.04, edge_frac=0.08, random_frac=0.04)[0]),
     "se_s0": (["-s0"], lambda ch: synth.make_reads(ch, 1500, 100, seed=4322, sub_lambda=0.4, edge_frac=0.05)[0]),
     "se_s5_e2_m1": (["-s5", "-e2", "-m1"], lambda ch: synth.make_reads(ch, 1500, 120, seed=4323, sub_lambda=2.5, n_prob=0.03)[0]),
+    # MLMode eMLall: every locus of a multi-aligned read is reported, up to -R
+    "se_r5_R12": (["-s2", "-r5", "-R12"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4324, n_prob=0.02, edge_frac=0.05)[0]),
 }
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # case names: regenerate just these (others keep their files)
 PE_CASES = {
     "pe_u2": (["-s2", "-U2", "-d200", "-D600"], dict(seed=99, n_prob=0.02, random_mate_frac=0.03)),
     "pe_u1": (["-s2", "-U1", "-d200", "-D600"], dict(seed=98, n_prob=0.02, random_mate_frac=0.03, sub_lambda=2.0)),
@@ -51,7 +54,11 @@ def main():
     names, chroms = synth.golden_genome()
     meta = {}
     with tempfile.TemporaryDirectory() as tmp:
+        if ONLY:
+            meta = json.load(open(os.path.join(HERE, "sam_cases.json")))
         for name, (args, gen) in CASES.items():
+            if ONLY and name not in ONLY:
+                continue
             fa = os.path.join(tmp, name + ".fa")
             synth.write_fasta(fa, gen(chroms))
             hist = run(tmp, name, args, ["-i", fa])
@@ -60,6 +67,8 @@ def main():
             meta[name] = dict(args=args, nar=hist)
             print(name, hist)
         for name, (args, kw) in PE_CASES.items():
+            if ONLY and name not in ONLY:
+                continue
             pe1, pe2, _ = synth.make_pe_reads(chroms, 2000, 150, **kw)
             f1, f2 = os.path.join(tmp, name + "_1.fa"), os.path.join(tmp, name + "_2.fa")
             synth.write_fasta(f1, pe1)

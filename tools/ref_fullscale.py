@@ -1,7 +1,8 @@
 """Full-scale check against the REAL reference on the GPU box's host cores (run through gpurun; needs oracle/_ref/ngskit4b,
 which travels with the snapshot):  3 Gbp index built on the GPU -> .sfx file -> `ngskit4b kalign -s2 -T<cores>` and
 `k4align` on the same FASTA -> SAM records compared, both timed.
-    python tools/ref_fullscale.py [n_reads=2000000] [chroms=24] [chrom_mbp=125] [threads=16] [pe_mode=0] [read_len=100] [repeats=0]
+    python tools/ref_fullscale.py [n_reads=2000000] [chroms=24] [chrom_mbp=125] [threads=16] [pe_mode=0] [read_len=100] [repeats=0] [extra="-r5 -R8"]
+extra: further options handed to both programs (e.g. the report-all multi-loci mode).
 repeats > 0: that many segment copies (high-copy families and pairs, 0-3 % diverged) and N runs are implanted first.
 pe_mode 1..4: n_reads pairs of 2 x read_len, `-U<pe_mode> -d200 -D600` on both programs."""
 import json
@@ -36,6 +37,7 @@ dev = torch.device("cuda:0")
 seq = bench.make_genome(dev, n_chrom, chrom_len)
 n = seq.numel()
 n_rep = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+extra = sys.argv[8].split() if len(sys.argv) > 8 else []
 if n_rep:
     g = torch.Generator(device=dev); g.manual_seed(4242)
     fam_src = torch.randint(0, n_chrom * (chrom_len - 6000), (50,), device=dev, generator=g)
@@ -93,7 +95,7 @@ torch.cuda.empty_cache()
 
 ref_sam, ref_log = os.path.join(tmp, "ref.sam"), os.path.join(tmp, "ref.log")
 t0 = time.time()
-r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log, "-s2"] + in_args, capture_output=True)
+r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log, "-s2"] + extra + in_args, capture_output=True)
 t_ref = time.time() - t0
 print("reference rc", r.returncode, "wall %.1fs" % t_ref, flush=True)
 log = open(ref_log, errors="replace").read() if os.path.exists(ref_log) else ""
@@ -102,7 +104,7 @@ print("\n".join(keep[-40:]), flush=True)
 
 gpu_sam = os.path.join(tmp, "gpu.sam")
 t0 = time.time()
-g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam, "-s2"] + in_args, capture_output=True, text=True)
+g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam, "-s2"] + extra + in_args, capture_output=True, text=True)
 t_gpu = time.time() - t0
 print("k4align rc", g.returncode, "wall %.1fs" % t_gpu)
 print(g.stderr[-1500:], flush=True)
@@ -121,11 +123,11 @@ hg, rg = body(gpu_sam)
 same_hdr = hr == hg
 same_order = rr == rg
 same_set = sorted(rr) == sorted(rg)
-out = {"repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
+out = {"extra_args": extra, "repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
        "reference_sam_records": len(rr), "k4align_sam_records": len(rg), "headers_equal": same_hdr,
        "records_equal_as_multiset": same_set, "records_equal_in_order": same_order}
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"summary": out, "reference_log_tail": keep[-40:], "k4align_stderr": g.stderr[-3000:]},
-          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", "_rep" if n_rep else "")), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep else "") + ("_" + "".join(extra).replace("-", "") if extra else ""))), "w"), indent=1)
 shutil.rmtree(tmp, ignore_errors=True)
