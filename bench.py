@@ -55,6 +55,37 @@ def make_genome(dev, n_chrom, chrom_len):
     return seq
 
 
+def implant_repeats(seq, n_chrom, chrom_len, n_rep, dev, seed=4242):
+    """Make the i.i.d. genome repetitive (not a BASELINE workload: stress for the dedupe / multi-hit / N paths): n_rep
+    segment copies of 150..5000 bp -- half from 50 high-copy source families, half one-off pairs -- diverged by 0..3 %,
+    every third inverted, plus n_rep/20 runs of N."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    span = chrom_len - 6000
+    fam_src = torch.randint(0, n_chrom * span, (50,), device=dev, generator=g)
+
+    def place(u):
+        c, o = divmod(int(u), span)
+        return c * (chrom_len + 1) + o
+
+    for r in range(n_rep):
+        ln = int(torch.randint(150, 5000, (1,), device=dev, generator=g))
+        src = place(fam_src[r % 50]) if r % 2 == 0 else place(torch.randint(0, n_chrom * span, (1,), device=dev, generator=g))
+        dst = place(torch.randint(0, n_chrom * span, (1,), device=dev, generator=g))
+        seg = seq[src:src + ln].clone()
+        rate = (r % 4) * 0.01
+        if rate:
+            mut = torch.rand(ln, device=dev, generator=g) < rate
+            seg = torch.where(mut & (seg < 4), (seg + torch.randint(1, 4, (ln,), device=dev, generator=g, dtype=torch.uint8)) % 4, seg)
+        if r % 3 == 0:
+            seg = torch.where(seg < 4, 3 - seg, seg).flip(0)  # inverted copy (N stays N)
+        seq[dst:dst + ln] = seg
+    for r in range(max(1, n_rep // 20)):
+        dst = place(torch.randint(0, n_chrom * span, (1,), device=dev, generator=g))
+        seq[dst:dst + int(torch.randint(1, 300, (1,), device=dev, generator=g))] = 4
+    assert int(((seq > 4) & (seq != 7)).sum()) == 0
+
+
 def mutate(r, g, dev):
     """In place: Poisson(1) substitutions truncated at 8, distinct uniform positions, new base != old.  Returns the counts."""
     m, read_len = r.shape
@@ -236,6 +267,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--max-subs", type=int, default=None)
     ap.add_argument("--kmer-k", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=0, help="implant this many repeat copies and N runs (stress; not the BASELINE workload)")
     ap.add_argument("--n-frac", type=float, default=0.0, help="fraction of reads given one N (general-kernel stress; not the BASELINE workload)")
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="upper bound on reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--ref-sample", type=int, default=8_000_000,
@@ -247,7 +279,8 @@ def main():
     args.read_len = wl[2] if args.read_len is None else args.read_len
     args.max_subs = wl[3] if args.max_subs is None else args.max_subs
     pe = wl[4]
-    std_cfg = (args.chroms, args.reads, args.read_len, args.max_subs) == wl[:4] and args.chrom_mbp == 125.0 and args.n_frac == 0
+    std_cfg = ((args.chroms, args.reads, args.read_len, args.max_subs) == wl[:4] and args.chrom_mbp == 125.0 and args.n_frac == 0
+               and args.repeats == 0)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -267,6 +300,8 @@ def main():
     L = args.read_len
     t0 = time.time()
     seq = make_genome(dev, n_chrom, chrom_len)
+    if args.repeats:
+        implant_repeats(seq, n_chrom, chrom_len, args.repeats, dev)
     n = seq.numel()
     torch.cuda.synchronize()
     log(rank, "genome %d x %d bp = %.3f Gbp in %.1fs" % (n_chrom, chrom_len, n_chrom * chrom_len / 1e9, time.time() - t0))
@@ -376,7 +411,7 @@ def main():
     ))
     if pe:
         good &= torch.where(ok, out_pe[:, 4] == 1, out_pe[:, 4] == 0)  # FlgPEAligned
-    truth_viol = int((~good).sum().item())
+    truth_viol = int((~good).sum().item()) if args.repeats == 0 else None  # (the property needs an i.i.d. genome)
 
     # (2) CPU baseline = the oracle on all host cores over a bounded sample, same index, same reads (rank 0, N=1 only)
     cpu = None

@@ -710,6 +710,7 @@ struct K4Slow {
   uint32_t cap;     // power of two
   uint32_t gen;
   int lane;
+  const uint64_t* ent;  // LDS copy of the entry table (starts, then ends at +K4_LDS_ENTRIES) or null
   bool small;       // first general pass: small tables, overflow defers the read to the pass with big tables
 };
 
@@ -788,19 +789,96 @@ K4_DEV int64_t k4d_first_exact_wave(const K4DevIndex& ix, const K4Slow& sc, int 
   return found == lo ? found + 1 : 0;
 }
 
-K4_DEV bool k4d_hash_insert_wave(K4Slow& sc, uint32_t id) {  // true when id is new in this strand pass (lane 0 works)
-  int isnew = 0;
-  if (sc.lane == 0) {
-    const uint64_t key = ((uint64_t)sc.gen << 32) | id;
-    uint32_t h = (id * 2654435761u) & (sc.cap - 1);
-    for (;;) {
-      const uint64_t v = sc.hash[h];
-      if ((uint32_t)(v >> 32) != sc.gen) { sc.hash[h] = key; isnew = 1; break; }
-      if (v == key) break;
-      h = (h + 1) & (sc.cap - 1);
+// Dedupe table of a strand pass (tsIdentNode, SfxArray.cpp:5946,6037-6058): open addressing on (generation, TargSeqID).
+// One insert per lane, concurrently: the ids of one batch are distinct (one SA run, one core offset), so the only
+// interaction between lanes is the race for a free slot, which the compare-and-swap settles.  Returns whether the id was
+// new in this strand pass and the slot it occupies (for k4d_hash_retract).
+K4_DEV bool k4d_hash_insert_lane(const K4Slow& sc, uint32_t id, uint32_t& slot) {
+  const unsigned long long key = ((unsigned long long)sc.gen << 32) | id;
+  unsigned long long* tab = reinterpret_cast<unsigned long long*>(sc.hash);
+  uint32_t h = (id * 2654435761u) & (sc.cap - 1);
+  for (;;) {
+    unsigned long long v = atomicAdd(&tab[h], 0ull);  // (an atomic read: sees the inserts of the other lanes)
+    if ((uint32_t)(v >> 32) != sc.gen) {
+      const unsigned long long old = atomicCAS(&tab[h], v, key);
+      if (old == v) { slot = h; return true; }
+      v = old;
+      if ((uint32_t)(v >> 32) != sc.gen) continue;  // (cannot happen: slots only move to the current generation)
+    }
+    if (v == key) { slot = h; return false; }
+    h = (h + 1) & (sc.cap - 1);
+  }
+}
+// an insert that the reference would not have made (its walk had already stopped): the slot stays occupied for this
+// generation so that probe chains through it stay intact, but holds the impossible id 0 (TargSeqID is 1 + offset)
+K4_DEV void k4d_hash_retract(const K4Slow& sc, uint32_t slot) {
+  atomicExch(reinterpret_cast<unsigned long long*>(sc.hash) + slot, (unsigned long long)sc.gen << 32);
+}
+
+// One lane: compare probe[j] with the target symbol at left + j for j in [jlo, jhi).  all_eq: every symbol equal and no
+// target EOS (CmpProbeTarg == 0 when the range is a core); mm: number of unequal symbols (N == N is equal, :6202-6234);
+// eos: the range holds a target EOS.  Exact symbols: when no 256-base block of the range is flagged the packed words are
+// fetched eight at a time (independent loads, one memory latency per 128 bases) -- the 2 Kbase pads make the over-read
+// safe; otherwise symbol by symbol through the nibble store.  stop_early: return at the first difference.
+K4_DEV void k4d_lane_range(const K4DevIndex& ix, const uint8_t* probe, int jlo, int jhi, uint64_t left, bool stop_early,
+                           bool& all_eq, bool& eos, int& mm) {
+  all_eq = true;
+  eos = false;
+  mm = 0;
+  if (jhi <= jlo) return;
+  const uint64_t g0 = left + (uint64_t)jlo, g1 = left + (uint64_t)jhi;
+  bool flagged = g1 > ix.n;
+  for (uint64_t bb = g0 >> K4_EXC_SHIFT; !flagged && bb <= ((g1 - 1) >> K4_EXC_SHIFT); bb++)
+    flagged = (ix.excbm[bb >> 5] >> (bb & 31)) & 1;
+  if (!flagged) {
+    const uint64_t w0 = g0 >> 4, w1 = (g1 - 1) >> 4;
+    int j = jlo;
+    for (uint64_t wb = w0; wb <= w1; wb += 8) {
+      uint32_t wv[8];
+      k4d_load_words<8>(ix.ref2 + wb, wv);
+      const uint64_t gend = min(g1, (wb + 8) << 4);
+      for (uint64_t g = left + (uint64_t)j; g < gend; g++, j++) {
+        const uint32_t t = (wv[(g >> 4) - wb] >> (30 - 2 * (uint32_t)(g & 15))) & 3;
+        if ((probe[j] & 0x0f) != t) {
+          all_eq = false;
+          mm++;
+          if (stop_early) return;
+        }
+      }
+    }
+    return;
+  }
+  for (int j = jlo; j < jhi; j++) {
+    const uint64_t g = left + (uint64_t)j;
+    const uint32_t t = g < ix.n ? k4d_ref_base(ix, g) : 7u;
+    if (t == 7) eos = true;
+    if ((probe[j] & 0x0f) != t) {  // (a target EOS never equals a probe symbol)
+      all_eq = false;
+      mm++;
+      if (stop_early) return;
     }
   }
-  return __shfl(isnew, 0, 64) != 0;
+}
+
+// MapChunkHit2Entry (libkit4b/SfxArray.cpp:2609-2654) over the LDS copy of the entry table when there is one
+K4_DEV int k4d_map_entry_slow(const K4DevIndex& ix, const uint64_t* ent_lds, uint64_t ofs, uint64_t& e_start, uint64_t& e_end) {
+  if (!ent_lds) {
+    const int e = k4d_map_entry(ix, ofs);
+    e_start = e >= 0 ? ix.ent_start[e] : 0;
+    e_end = e >= 0 ? ix.ent_end[e] : 0;
+    return e;
+  }
+  int lo = 0, hi = (int)ix.n_entries - 1;
+  while (hi >= lo) {
+    const int mid = (hi + lo) >> 1;
+    const uint64_t s = ent_lds[mid];
+    if (s > ofs) { hi = mid - 1; continue; }
+    const uint64_t ev = ent_lds[K4_LDS_ENTRIES + mid];
+    if (ev >= ofs) { e_start = s; e_end = ev; return mid; }
+    lo = mid + 1;
+  }
+  e_start = e_end = 0;
+  return -1;
 }
 
 template <int EL>
@@ -821,10 +899,11 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
   st.cur_hit = st.inst < rp.max_hits ? st.inst : -1;
   const int max_iter = ix.max_iter;
   const int64_t n = (int64_t)ix.n;
+  const int lane = sc.lane;
   int strand = rp.strand;
   char cur_strand = '+';
   // hits are stored by lane 0 only (every lane folds the same wave-uniform state)
-  k4_hit* hits_w = sc.lane == 0 ? hits : nullptr;
+  k4_hit* hits_w = lane == 0 ? hits : nullptr;
   if (strand == K4_STRAND_CRICK) { k4d_revcomp_wave(sc, len); cur_strand = '-'; }
   do {
     int cur_delta = core_delta;
@@ -841,53 +920,93 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
       int64_t t = k4d_first_exact_wave<EL>(ix, sc, o, cl, n_probe);
       if (t == 0) continue;
       t -= 1;
+      // The walk over the run of suffixes that start with the core (:5971-6321), 64 suffixes per step, one per lane: the
+      // memory-bound part (suffix element, core comparison, entry lookup, dedupe insert, Hamming distance) runs in
+      // parallel; what the reference's sequential loop makes order-dependent -- where the run ends, MaxIter and the node
+      // limit counting only new in-bounds candidates, the fold into (LowMMCnt, NxtLowMMCnt, instances, hits) and its
+      // early exit -- is then replayed in suffix order from the lanes' results.
       int iter = 0;
-      bool first = true;
-      while (!max_iter || iter < max_iter) {
-        if (n_nodes >= node_cap) break;
-        if (!first) {
-          if (t + 1 >= n) break;
-          const uint64_t p2 = k4d_sa_at<EL>(ix, (uint64_t)t + 1);
-          if ((int64_t)p2 + cl > n) break;
-          n_probe++;
-          if (k4d_cmp_wave(ix, sc, o, p2, cl) != 0) break;
-          t += 1;
-        }
-        first = false;
-        const uint64_t pos = k4d_sa_at<EL>(ix, (uint64_t)t);
-        if (pos < (uint64_t)o) continue;
+      bool run_over = false, done_all = false;
+      for (int64_t base = t; !run_over; base += 64) {
+        const int64_t idx = base + lane;
+        const bool is_first = idx == t;  // the suffix LocateFirstExact returned: taken without another comparison
+        const bool have = idx < n;
+        const uint64_t pos = have ? k4d_sa_at<EL>(ix, (uint64_t)idx) : 0;
+        const bool fits = have && (is_first || (int64_t)pos + cl <= n);
         const uint64_t left = pos - (uint64_t)o;
-        const int e = k4d_map_entry(ix, left);
-        if (e < 0 || left + (uint64_t)len - 1 > ix.ent_end[e]) continue;
-        const uint32_t targ_id = (uint32_t)(1 + pos - (uint32_t)o);
-        if (!k4d_hash_insert_wave(sc, targ_id)) continue;
-        n_nodes++;
+        bool core_ok = false, eos = false;
+        int mm = 0;
+        if (fits && !is_first) k4d_lane_range(ix, sc.probe, o, o + cl, left, true, core_ok, eos, mm);
+        if (is_first) core_ok = true;
+        const unsigned long long bad = __ballot(!(fits && core_ok));
+        const int r = bad ? __ffsll((long long)bad) - 1 : 64;  // run members in this batch: lanes [0, r)
+        // was the suffix that ended the run compared (a probe in the reference's count) or was it out of range?
+        const bool end_compared = r < 64 && __shfl((int)(fits ? 1 : 0), r, 64) != 0;
+        // filters of a member that precede the dedupe (:6019-6036): before the core offset, on a separator, over the entry end
+        int e = -1;
+        uint64_t e_start = 0, e_end = 0;
+        if (lane < r && pos >= (uint64_t)o) e = k4d_map_entry_slow(ix, sc.ent, left, e_start, e_end);
+        const bool in_bounds = lane < r && pos >= (uint64_t)o && e >= 0 && left + (uint64_t)len - 1 <= e_end;
+        bool isnew = false;
+        uint32_t slot = 0;
+        if (in_bounds) isnew = k4d_hash_insert_lane(sc, (uint32_t)(1 + pos - (uint32_t)o), slot);
+        unsigned long long newm = __ballot(isnew);
+        // the Hamming extension (:6200-6261) only for candidates that are new in this strand pass
+        if (isnew) {
+          bool all_eq;
+          k4d_lane_range(ix, sc.probe, 0, len, left, false, all_eq, eos, mm);
+        }
+        // MaxIter / node limit: both count new in-bounds candidates only; the walk stops before the suffix after the last
+        // one it may take
+        const uint32_t rem_iter = max_iter ? (uint32_t)(max_iter - iter) : 0xFFFFFFFFu;
+        const uint32_t remaining = min(rem_iter, node_cap - n_nodes);
+        int last = r - 1;  // last member the reference's loop reaches in this batch
+        bool hit_limit = false;
+        if ((uint32_t)__popcll(newm) >= remaining) {
+          unsigned long long mrem = newm;
+          for (uint32_t q = 1; q < remaining; q++) mrem &= mrem - 1;  // drop the lowest remaining-1 bits
+          last = __ffsll((long long)mrem) - 1;
+          hit_limit = true;
+          const unsigned long long beyond = last >= 63 ? 0ull : (~0ull << (last + 1));
+          if (isnew && ((beyond >> lane) & 1)) k4d_hash_retract(sc, slot);
+          newm &= ~beyond;
+        }
+        run_over = hit_limit || r < 64;
+        // replay in suffix order: only candidates that pass the order-independent part of the acceptance test can change
+        // the state; the rest just count
+        const unsigned long long foldm = __ballot(isnew && !eos && mm <= allow_mm) & newm;
+        unsigned long long todo = foldm;
+        int stop_lane = -1;
+        while (todo) {
+          const int c = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const int mm_c = __shfl(mm, c, 64);
+          if (mm_c >= st.nxt) continue;
+          const int e_c = __shfl(e, c, 64);
+          const uint32_t loci_c = (uint32_t)__shfl((int)(uint32_t)(left - e_start), c, 64);
+          k4d_fold(st, mm_c, hits_w, rp.max_hits, ix.ent_id[e_c], loci_c, len, cur_strand);
+          if (st.inst > rp.max_hits && st.low == 0) { stop_lane = c; break; }
+        }
+        if (stop_lane >= 0) {  // early exit of :6313-6321: candidates behind it were never examined
+          const unsigned long long upto = stop_lane >= 63 ? ~0ull : ((1ull << (stop_lane + 1)) - 1ull);
+          const uint32_t took = (uint32_t)__popcll(newm & upto);
+          iter += (int)took; n_cand += took; n_nodes += took;
+          n_probe += (uint32_t)(stop_lane + 1) - (uint32_t)((base == t) ? 1 : 0);
+          done_all = true;
+          break;
+        }
+        {
+          const uint32_t took = (uint32_t)__popcll(newm);
+          iter += (int)took; n_cand += took; n_nodes += took;
+          // probes the reference counted: every member reached after the first suffix, plus the comparison that ended the run
+          n_probe += (uint32_t)(last + 1) - (uint32_t)((base == t) ? 1 : 0) + (uint32_t)((!hit_limit && end_compared) ? 1 : 0);
+        }
         if (n_nodes >= node_cap && node_cap < (uint32_t)K4_MAX_IDENT_NODES && sc.small) {
           if (cur_strand == '-') k4d_revcomp_wave(sc, len);
           return K4_NEED_SLOW;
         }
-        iter++;
-        n_cand++;
-        // extension (:6200-6261): the scalar loop stops at a target EOS or once the count passes MaxTotMM / reaches
-        // NxtLowMMCnt; it is accepted iff it runs to the end, i.e. no EOS, count <= MaxTotMM and count < NxtLowMMCnt
-        int mm = 0;
-        bool eos = false;
-        for (int j0 = 0; j0 < len && !eos && mm <= allow_mm && mm < st.nxt; j0 += 64) {
-          const int j = j0 + sc.lane;
-          bool d = false, z = false;
-          if (j < len) {
-            const uint32_t tv = k4d_ref_base(ix, left + j);
-            z = tv == 7;
-            d = tv != (uint32_t)(sc.probe[j] & 0x0f);
-          }
-          eos = __ballot(z) != 0;
-          mm += (int)__popcll(__ballot(d));
-        }
-        if (eos || mm > allow_mm || mm >= st.nxt) continue;
-        k4d_fold(st, mm, hits_w, rp.max_hits, ix.ent_id[e], (uint32_t)(left - ix.ent_start[e]), len, cur_strand);
-        if (st.inst > rp.max_hits && st.low == 0) break;
       }
-      if (st.inst > rp.max_hits && st.low == 0) { strand = 3; break; }
+      if (done_all || (st.inst > rp.max_hits && st.low == 0)) { strand = 3; break; }
     }
     if (cur_strand == '+' && strand == K4_STRAND_BOTH) {
       k4d_revcomp_wave(sc, len);
@@ -907,12 +1026,21 @@ template <int EL>
 __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_waves, int pass, uint64_t* hash_base,
                                                      uint32_t hash_cap, uint32_t* gen_base) {
   __shared__ uint8_t probe_s[K4_MAX_READ_LEN + 64];
+  __shared__ uint64_t ent_s[2 * K4_LDS_ENTRIES];
   const uint32_t wave = blockIdx.x;
   const int lane = threadIdx.x;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0;
+  const bool ent_in_lds = a.ix.n_entries <= K4_LDS_ENTRIES;
+  if (ent_in_lds)
+    for (int q = lane; q < (int)a.ix.n_entries; q += 64) {
+      ent_s[q] = a.ix.ent_start[q];
+      ent_s[K4_LDS_ENTRIES + q] = a.ix.ent_end[q];
+    }
+  __syncthreads();
   if (wave < n_waves) {
     K4Slow sc;
     sc.probe = probe_s;
+    sc.ent = ent_in_lds ? ent_s : nullptr;
     sc.hash = hash_base + (size_t)wave * hash_cap;
     sc.cap = hash_cap;
     sc.gen = gen_base[wave];

@@ -39,34 +39,7 @@ n = seq.numel()
 n_rep = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 extra = sys.argv[8].split() if len(sys.argv) > 8 else []
 if n_rep:
-    g = torch.Generator(device=dev); g.manual_seed(4242)
-    fam_src = torch.randint(0, n_chrom * (chrom_len - 6000), (50,), device=dev, generator=g)
-    for r in range(n_rep):
-        ln = int(torch.randint(150, 5000, (1,), device=dev, generator=g))
-        if r % 2 == 0:
-            u = int(fam_src[r % 50])                       # a high-copy family
-        else:
-            u = int(torch.randint(0, n_chrom * (chrom_len - 6000), (1,), device=dev, generator=g))
-        c, o = divmod(u, chrom_len - 6000)
-        src = c * (chrom_len + 1) + o
-        v = int(torch.randint(0, n_chrom * (chrom_len - 6000), (1,), device=dev, generator=g))
-        c2, o2 = divmod(v, chrom_len - 6000)
-        dst = c2 * (chrom_len + 1) + o2
-        seg = seq[src:src + ln].clone()
-        rate = (r % 4) * 0.01
-        if rate:
-            mut = torch.rand(ln, device=dev, generator=g) < rate
-            seg = torch.where(mut & (seg < 4), (seg + torch.randint(1, 4, (ln,), device=dev, generator=g, dtype=torch.uint8)) % 4, seg)
-        if r % 3 == 0:
-            seg = torch.where(seg < 4, 3 - seg, seg).flip(0)    # inverted copy (N stays N)
-        seq[dst:dst + ln] = torch.where(seq[dst:dst + ln] == 7, seq[dst:dst + ln], seg)
-    for r in range(max(1, n_rep // 20)):                    # N runs
-        v = int(torch.randint(0, n_chrom * (chrom_len - 6000), (1,), device=dev, generator=g))
-        c2, o2 = divmod(v, chrom_len - 6000)
-        dst = c2 * (chrom_len + 1) + o2
-        ln = int(torch.randint(1, 300, (1,), device=dev, generator=g))
-        seq[dst:dst + ln] = 4
-    assert int(((seq > 4) & (seq != 7)).sum()) == 0
+    bench.implant_repeats(seq, n_chrom, chrom_len, n_rep, dev)
     print("implanted %d repeat copies" % n_rep, flush=True)
 el = 4 if n < 4_000_000_000 else 5
 sa = torch.empty(n * el + 16, dtype=torch.uint8, device=dev)
