@@ -711,6 +711,8 @@ struct K4Slow {
   uint32_t gen;
   int lane;
   const uint64_t* ent;  // LDS copy of the entry table (starts, then ends at +K4_LDS_ENTRIES) or null
+  uint64_t* pk;         // LDS: the probe in its current orientation as 2-bit words, MSB first, zero word behind the end
+  bool packed;          // pk is usable: the probe holds only A/C/G/T
   bool small;       // first general pass: small tables, overflow defers the read to the pass with big tables
 };
 
@@ -736,7 +738,8 @@ K4_DEV int k4d_cmp_wave(const K4DevIndex& ix, const K4Slow& sc, int o, uint64_t 
   return 0;
 }
 
-K4_DEV void k4d_revcomp_wave(const K4Slow& sc, int len) {  // CSeqTrans::ReverseComplement, SeqTrans.cpp:497-545
+K4_DEV void k4d_pack_probe_wave(K4Slow& sc, int len);
+K4_DEV void k4d_revcomp_wave(K4Slow& sc, int len) {  // CSeqTrans::ReverseComplement, SeqTrans.cpp:497-545
   // complement stops at the first symbol that is not a base / N / InDel / Undef (values > 6): reads hold 0..7 here
   int stop = len;
   for (int j0 = 0; j0 < len; j0 += 64) {
@@ -756,37 +759,7 @@ K4_DEV void k4d_revcomp_wave(const K4Slow& sc, int len) {  // CSeqTrans::Reverse
     sc.probe[len - 1 - x] = t;
   }
   __syncthreads();
-}
-
-// LocateFirstExact (SfxArray.cpp:7938-8058): index+1 of the lowest matching suffix or 0
-template <int EL>
-K4_DEV int64_t k4d_first_exact_wave(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, uint32_t& n_probe) {
-  int64_t lo = 0, hi = (int64_t)ix.n - 1;
-  const int kk = min((int)ix.k, cl);
-  bool acgt = true;
-  uint64_t code = 0;
-  for (int j = 0; j < kk; j++) {  // uniform: every lane reads the same LDS bytes
-    const uint32_t b = sc.probe[o + j] & 0x0f;
-    if (b > 3) { acgt = false; break; }
-    code = (code << 2) | b;
-  }
-  if (acgt) {
-    const int sh = 2 * ((int)ix.k - kk);
-    lo = (int64_t)k4d_ktab_lb(ix, code << sh);
-    hi = (int64_t)k4d_ktab_lb(ix, (code + 1) << sh) - 1;
-  }
-  int64_t found = -1;
-  while (lo <= hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    const int c = k4d_cmp_wave(ix, sc, o, k4d_sa_at<EL>(ix, (uint64_t)mid), cl);
-    n_probe++;
-    if (c > 0) lo = mid + 1;
-    else {
-      if (c == 0) found = mid;
-      hi = mid - 1;
-    }
-  }
-  return found == lo ? found + 1 : 0;
+  k4d_pack_probe_wave(sc, len);
 }
 
 // Dedupe table of a strand pass (tsIdentNode, SfxArray.cpp:5946,6037-6058): open addressing on (generation, TargSeqID).
@@ -798,7 +771,9 @@ K4_DEV bool k4d_hash_insert_lane(const K4Slow& sc, uint32_t id, uint32_t& slot) 
   unsigned long long* tab = reinterpret_cast<unsigned long long*>(sc.hash);
   uint32_t h = (id * 2654435761u) & (sc.cap - 1);
   for (;;) {
-    unsigned long long v = atomicAdd(&tab[h], 0ull);  // (an atomic read: sees the inserts of the other lanes)
+    // a plain (possibly stale) read is enough: a slot only ever moves from an older generation to the current one, so
+    // a stale "free" is caught by the compare-and-swap failing, and what it returns is then examined like a fresh read
+    unsigned long long v = tab[h];
     if ((uint32_t)(v >> 32) != sc.gen) {
       const unsigned long long old = atomicCAS(&tab[h], v, key);
       if (old == v) { slot = h; return true; }
@@ -881,6 +856,117 @@ K4_DEV int k4d_map_entry_slow(const K4DevIndex& ix, const uint64_t* ent_lds, uin
   return -1;
 }
 
+// probe bytes -> sc.pk (call after every change of sc.probe); sc.packed = no symbol above T
+K4_DEV void k4d_pack_probe_wave(K4Slow& sc, int len) {
+  const int nw = (len + 31) >> 5;
+  bool bad = false;
+  for (int w = sc.lane; w <= nw; w += 64) {
+    uint64_t acc = 0;
+    if (w < nw)
+      for (int q = 0; q < 32; q++) {
+        const int j = 32 * w + q;
+        uint32_t b = j < len ? (sc.probe[j] & 0x0f) : 0u;
+        if (b > 3) { bad = true; b = 0; }
+        acc = (acc << 2) | b;
+      }
+    sc.pk[w] = acc;
+  }
+  sc.packed = __ballot(bad) == 0;
+  __syncthreads();
+}
+K4_DEV uint64_t k4d_probe_chunk(const K4Slow& sc, int j) {  // 32 probe bases from base j
+  const int w = j >> 5, sh = 2 * (j & 31);
+  const uint64_t hi = sc.pk[w];
+  return sh ? (hi << sh) | (sc.pk[w + 1] >> (64 - sh)) : hi;
+}
+
+// CmpProbeTarg (SfxArray.cpp:2508-2525) by one lane: core [o, o+cl) of the probe against the suffix at pos; 0 equal,
+// 1 probe greater, -1 probe smaller (a target EOS, or the end of the block, sorts above every probe symbol)
+K4_DEV int k4d_lane_cmp(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, uint64_t pos) {
+  const uint8_t* probe = sc.probe;
+  if (sc.packed && pos + (uint64_t)cl <= ix.n && !k4d_any_exc(ix, (int64_t)pos, (int64_t)pos + cl)) {
+    for (int c = 0; 32 * c < cl; c++) {  // 32 bases per step: XOR of packed chunks, MSB-first order == symbol order
+      const uint64_t m = k4d_range_mask(0, cl - 32 * c);
+      const uint64_t rc = k4d_ref_chunk(ix, (int64_t)pos + 32 * c) & m, pc = k4d_probe_chunk(sc, o + 32 * c) & m;
+      if (rc != pc) return pc > rc ? 1 : -1;
+    }
+    return 0;
+  }
+  bool flagged = pos + (uint64_t)cl > ix.n;
+  for (uint64_t bb = pos >> K4_EXC_SHIFT; !flagged && bb <= ((pos + cl - 1) >> K4_EXC_SHIFT); bb++)
+    flagged = (ix.excbm[bb >> 5] >> (bb & 31)) & 1;
+  if (!flagged) {
+    const uint64_t w1 = (pos + cl - 1) >> 4;
+    int j = 0;
+    for (uint64_t wb = pos >> 4; wb <= w1; wb += 8) {
+      uint32_t wv[8];
+      k4d_load_words<8>(ix.ref2 + wb, wv);
+      const uint64_t gend = min(pos + (uint64_t)cl, (wb + 8) << 4);
+      for (uint64_t g = pos + (uint64_t)j; g < gend; g++, j++) {
+        const uint32_t t = (wv[(g >> 4) - wb] >> (30 - 2 * (uint32_t)(g & 15))) & 3;
+        const uint32_t pb = probe[o + j] & 0x0f;
+        if (pb != t) return pb > t ? 1 : -1;
+      }
+    }
+    return 0;
+  }
+  for (int j = 0; j < cl; j++) {
+    const uint64_t g = pos + (uint64_t)j;
+    const uint32_t t = g < ix.n ? k4d_ref_base(ix, g) : 7u;
+    const uint32_t pb = probe[o + j] & 0x0f;
+    if (t == 7) return -1;
+    if (pb != t) return pb > t ? 1 : -1;
+  }
+  return 0;
+}
+
+// LocateFirstExact (SfxArray.cpp:7938-8058): index+1 of the lowest suffix that starts with the core, or 0.  The k-mer
+// table narrows the range to the core's bucket; inside it the 64 lanes compare 64 evenly spaced suffixes at once, so a
+// bucket of up to 64 suffixes is settled in one round of memory accesses and one of 4096 in two (the reference's binary
+// search takes one dependent round per halving).
+template <int EL>
+K4_DEV int64_t k4d_first_exact_wave(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, uint32_t& n_probe) {
+  int64_t lo = 0, hi = (int64_t)ix.n - 1;
+  const int kk = min((int)ix.k, cl);
+  bool acgt = true;
+  uint64_t code = 0;
+  for (int j = 0; j < kk; j++) {  // uniform: every lane reads the same LDS bytes
+    const uint32_t b = sc.probe[o + j] & 0x0f;
+    if (b > 3) { acgt = false; break; }
+    code = (code << 2) | b;
+  }
+  if (acgt) {
+    const int sh = 2 * ((int)ix.k - kk);
+    lo = (int64_t)k4d_ktab_lb(ix, code << sh);
+    hi = (int64_t)k4d_ktab_lb(ix, (code + 1) << sh) - 1;
+  }
+  int64_t found = -1;
+  while (lo <= hi) {
+    const int64_t size = hi - lo + 1;
+    const int64_t step = (size + 63) / 64;
+    const int64_t pv = lo + (int64_t)sc.lane * step;  // this lane's pivot (ascending with the lane)
+    const bool have = pv <= hi;
+    int c = 1;
+    if (have) c = k4d_lane_cmp(ix, sc, o, cl, k4d_sa_at<EL>(ix, (uint64_t)pv));
+    const unsigned long long hm = __ballot(have);
+    n_probe += (uint32_t)__popcll(hm);
+    const unsigned long long le = __ballot(have && c <= 0);  // pivots whose suffix is not below the core
+    if (!le) {  // every pivot is below the core: what is left lies behind the last one
+      lo = lo + (int64_t)(__popcll(hm) - 1) * step + 1;
+      continue;
+    }
+    const int f = __ffsll((long long)le) - 1;
+    const int64_t pvf = lo + (int64_t)f * step;
+    if (step == 1) {  // every suffix of the range was a pivot: f is the lowest that is not below the core
+      if (__shfl(c, f, 64) == 0) found = pvf;
+      break;
+    }
+    if (f > 0) lo = lo + (int64_t)(f - 1) * step + 1;
+    hi = pvf;
+  }
+  return found >= 0 ? found + 1 : 0;
+}
+
 template <int EL>
 K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm, int cl, int core_delta,
                         const K4ReadParams& rp, int* p_inst, int* p_low, int* p_nxt, k4_hit* hits,
@@ -936,7 +1022,7 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
         const uint64_t left = pos - (uint64_t)o;
         bool core_ok = false, eos = false;
         int mm = 0;
-        if (fits && !is_first) k4d_lane_range(ix, sc.probe, o, o + cl, left, true, core_ok, eos, mm);
+        if (fits && !is_first) core_ok = k4d_lane_cmp(ix, sc, o, cl, pos) == 0;
         if (is_first) core_ok = true;
         const unsigned long long bad = __ballot(!(fits && core_ok));
         const int r = bad ? __ffsll((long long)bad) - 1 : 64;  // run members in this batch: lanes [0, r)
@@ -953,8 +1039,14 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
         unsigned long long newm = __ballot(isnew);
         // the Hamming extension (:6200-6261) only for candidates that are new in this strand pass
         if (isnew) {
-          bool all_eq;
-          k4d_lane_range(ix, sc.probe, 0, len, left, false, all_eq, eos, mm);
+          if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
+            for (int c = 0; 32 * c < len; c++)
+              mm += (int)k4d_mm_count((k4d_ref_chunk(ix, (int64_t)left + 32 * c) ^ k4d_probe_chunk(sc, 32 * c)) &
+                                      k4d_range_mask(0, len - 32 * c));
+          } else {
+            bool all_eq;
+            k4d_lane_range(ix, sc.probe, 0, len, left, false, all_eq, eos, mm);
+          }
         }
         // MaxIter / node limit: both count new in-bounds candidates only; the walk stops before the suffix after the last
         // one it may take
@@ -1024,9 +1116,12 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
 // the reference's own limits (list = huge_list, ctl[K4_CTL_HUGE]/[+1]).
 template <int EL>
 __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_waves, int pass, uint64_t* hash_base,
-                                                     uint32_t hash_cap, uint32_t* gen_base) {
-  __shared__ uint8_t probe_s[K4_MAX_READ_LEN + 64];
-  __shared__ uint64_t ent_s[2 * K4_LDS_ENTRIES];
+                                                     uint32_t hash_cap, uint32_t* gen_base, int max_len) {
+  // dynamic LDS, sized by the batch (k4_slow_lds_bytes): entry table copy | packed probe | probe bytes
+  extern __shared__ uint64_t slow_lds[];
+  uint64_t* ent_s = slow_lds;
+  uint64_t* pk_s = slow_lds + (a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES : 0);
+  uint8_t* probe_s = reinterpret_cast<uint8_t*>(pk_s + (max_len / 32 + 2));
   const uint32_t wave = blockIdx.x;
   const int lane = threadIdx.x;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0;
@@ -1041,6 +1136,8 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
     K4Slow sc;
     sc.probe = probe_s;
     sc.ent = ent_in_lds ? ent_s : nullptr;
+    sc.pk = pk_s;
+    sc.packed = false;
     sc.hash = hash_base + (size_t)wave * hash_cap;
     sc.cap = hash_cap;
     sc.gen = gen_base[wave];
@@ -1064,7 +1161,7 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
       const K4ReadParams rp = k4d_read_params(a, len);
       k4_hit* hits = a.hits + i * a.max_hits;
       int inst = 0, low = 0, nxt = 0, rslt = 0, allow = 0;
-      if (len < 1 || len > K4_MAX_READ_LEN || rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits) {
+      if (len < 1 || len > K4_MAX_READ_LEN || len > max_len || rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits) {
         if (lane == 0) k4d_finalize(a, i, len, rp, a.mode == 0 ? K4_ERR_PARAMS : K4_HR_FATAL, 0, 0, 0);
         continue;
       }
@@ -1072,6 +1169,7 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
       __syncthreads();
       for (int j = lane; j < len; j += 64) probe_s[j] = src[j] & 7;
       __syncthreads();
+      k4d_pack_probe_wave(sc, len);
       if (rp.tot_mm > 0) {
         for (allow = 0; allow <= rp.tot_mm; allow++) {
           int cl = len / (allow + rp.mm_delta);
@@ -1243,10 +1341,13 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
     default: rc = launch_steps<EL, 16, KT>(ix, a, n_steps, st); break;
   }
   if (rc != K4_OK) return rc;
-  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(K4_SLOW_WAVES), dim3(64), 0, st, a, (uint32_t)K4_SLOW_WAVES, 0, small_base,
-                     (uint32_t)K4_SMALL_HASH, gen_small);
-  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(K4_HUGE_WAVES), dim3(64), 0, st, a, (uint32_t)K4_HUGE_WAVES, 1, big_base,
-                     w.slow_hash_cap, gen_big);
+  const int slow_len = std::min(std::max(max_len, 1), K4_MAX_READ_LEN);
+  const size_t slow_lds = (size_t)(a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES : 0) * 8 + (size_t)(slow_len / 32 + 2) * 8 +
+                          (size_t)slow_len + 64;
+  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(K4_SLOW_WAVES), dim3(64), slow_lds, st, a, (uint32_t)K4_SLOW_WAVES, 0, small_base,
+                     (uint32_t)K4_SMALL_HASH, gen_small, slow_len);
+  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(K4_HUGE_WAVES), dim3(64), slow_lds, st, a, (uint32_t)K4_HUGE_WAVES, 1, big_base,
+                     w.slow_hash_cap, gen_big, slow_len);
   K4_HIP(ix, hipGetLastError());
   return K4_OK;
 }
