@@ -36,7 +36,12 @@
 #ifndef K4_PF
 #define K4_PF 4  // k-mer table entries fetched ahead per strand pass
 #endif
+#ifndef K4_SLOW_KB
+#define K4_SLOW_KB 1  // general kernel: suffixes per lane per walk step (measured: 2 and 4 cost occupancy and lose 25 %)
+#endif
+#ifndef K4_SLOW_WAVES
 #define K4_SLOW_WAVES 8192  // pass 0 of the general kernel: 32 waves per CU
+#endif
 #define K4_SMALL_HASH 4096  // entries of a pass-0 dedupe table (2047 candidates per strand pass)
 #define K4_HUGE_WAVES 256
 #define K4_CTL_HUGE 68  // ctl[68] huge count, ctl[69] huge head
@@ -1013,86 +1018,137 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
       // early exit -- is then replayed in suffix order from the lanes' results.
       int iter = 0;
       bool run_over = false, done_all = false;
-      for (int64_t base = t; !run_over; base += 64) {
-        const int64_t idx = base + lane;
-        const bool is_first = idx == t;  // the suffix LocateFirstExact returned: taken without another comparison
-        const bool have = idx < n;
-        const uint64_t pos = have ? k4d_sa_at<EL>(ix, (uint64_t)idx) : 0;
-        const bool fits = have && (is_first || (int64_t)pos + cl <= n);
-        const uint64_t left = pos - (uint64_t)o;
-        bool core_ok = false, eos = false;
-        int mm = 0;
-        if (fits && !is_first) core_ok = k4d_lane_cmp(ix, sc, o, cl, pos) == 0;
-        if (is_first) core_ok = true;
-        const unsigned long long bad = __ballot(!(fits && core_ok));
-        const int r = bad ? __ffsll((long long)bad) - 1 : 64;  // run members in this batch: lanes [0, r)
-        // was the suffix that ended the run compared (a probe in the reference's count) or was it out of range?
-        const bool end_compared = r < 64 && __shfl((int)(fits ? 1 : 0), r, 64) != 0;
-        // filters of a member that precede the dedupe (:6019-6036): before the core offset, on a separator, over the entry end
-        int e = -1;
-        uint64_t e_start = 0, e_end = 0;
-        if (lane < r && pos >= (uint64_t)o) e = k4d_map_entry_slow(ix, sc.ent, left, e_start, e_end);
-        const bool in_bounds = lane < r && pos >= (uint64_t)o && e >= 0 && left + (uint64_t)len - 1 <= e_end;
-        bool isnew = false;
-        uint32_t slot = 0;
-        if (in_bounds) isnew = k4d_hash_insert_lane(sc, (uint32_t)(1 + pos - (uint32_t)o), slot);
-        unsigned long long newm = __ballot(isnew);
-        // the Hamming extension (:6200-6261) only for candidates that are new in this strand pass
-        if (isnew) {
-          if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
-            for (int c = 0; 32 * c < len; c++)
-              mm += (int)k4d_mm_count((k4d_ref_chunk(ix, (int64_t)left + 32 * c) ^ k4d_probe_chunk(sc, 32 * c)) &
-                                      k4d_range_mask(0, len - 32 * c));
-          } else {
-            bool all_eq;
-            k4d_lane_range(ix, sc.probe, 0, len, left, false, all_eq, eos, mm);
+      constexpr int KB = K4_SLOW_KB;  // suffixes per lane per step: KB * 64 per step, their memory accesses in flight together
+      int kb_eff = 1;  // the first step looks at 64 suffixes (most runs are short), the following ones at KB * 64
+      for (int64_t base = t; !run_over; base += 64 * kb_eff, kb_eff = KB) {
+        uint64_t pos[KB];
+        bool fits[KB], core_ok[KB], isnew[KB];
+        int r[KB], e[KB], mm[KB];
+        uint32_t loci[KB], slot[KB];
+        bool endc[KB], eos[KB];
+        unsigned long long newm[KB];
+        // 1. suffix elements
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          const int64_t idx = base + 64 * k + lane;
+          const bool have = k < kb_eff && idx < n;
+          pos[k] = have ? k4d_sa_at<EL>(ix, (uint64_t)idx) : 0;
+          fits[k] = have && (idx == t || (int64_t)pos[k] + cl <= n);  // (:5981-5985 for the suffixes after the first)
+        }
+        // 2. does the suffix still start with the core?  (the one LocateFirstExact returned is taken as it is)
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          core_ok[k] = false;
+          if (k < kb_eff && base + 64 * k + lane == t) core_ok[k] = true;
+          else if (fits[k]) core_ok[k] = k4d_lane_cmp(ix, sc, o, cl, pos[k]) == 0;
+        }
+        // 3. where the run ends: members are lanes [0, r[k]) of sub-batch k, nothing behind the first non-member
+        bool ended = false;
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          r[k] = 0;
+          endc[k] = false;
+          const unsigned long long bad = __ballot(!(fits[k] && core_ok[k]));
+          if (!ended && k < kb_eff) {
+            r[k] = bad ? __ffsll((long long)bad) - 1 : 64;
+            // was the suffix that ended the run compared (a probe in the reference's count) or was it out of range?
+            endc[k] = r[k] < 64 && __shfl((int)(fits[k] ? 1 : 0), r[k], 64) != 0;
+            ended = r[k] < 64;
           }
         }
-        // MaxIter / node limit: both count new in-bounds candidates only; the walk stops before the suffix after the last
-        // one it may take
+        // 4. filters that precede the dedupe (:6019-6036: before the core offset, on a separator, over the entry end),
+        //    then the dedupe insert, all lanes at once
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          const uint64_t left = pos[k] - (uint64_t)o;
+          uint64_t e_start = 0, e_end = 0;
+          e[k] = -1;
+          const bool member = lane < r[k] && pos[k] >= (uint64_t)o;
+          if (member) e[k] = k4d_map_entry_slow(ix, sc.ent, left, e_start, e_end);
+          const bool in_bounds = member && e[k] >= 0 && left + (uint64_t)len - 1 <= e_end;
+          loci[k] = (uint32_t)(left - e_start);
+          isnew[k] = false;
+          slot[k] = 0;
+          if (in_bounds) isnew[k] = k4d_hash_insert_lane(sc, (uint32_t)(1 + pos[k] - (uint32_t)o), slot[k]);
+        }
+        // 5. MaxIter / node limit: both count new in-bounds candidates only; the walk stops before the suffix after the
+        //    last one it may take.  Inserts behind that point are retracted.
         const uint32_t rem_iter = max_iter ? (uint32_t)(max_iter - iter) : 0xFFFFFFFFu;
-        const uint32_t remaining = min(rem_iter, node_cap - n_nodes);
-        int last = r - 1;  // last member the reference's loop reaches in this batch
+        uint32_t remaining = min(rem_iter, node_cap - n_nodes);
         bool hit_limit = false;
-        if ((uint32_t)__popcll(newm) >= remaining) {
-          unsigned long long mrem = newm;
-          for (uint32_t q = 1; q < remaining; q++) mrem &= mrem - 1;  // drop the lowest remaining-1 bits
-          last = __ffsll((long long)mrem) - 1;
-          hit_limit = true;
-          const unsigned long long beyond = last >= 63 ? 0ull : (~0ull << (last + 1));
-          if (isnew && ((beyond >> lane) & 1)) k4d_hash_retract(sc, slot);
-          newm &= ~beyond;
+        int last[KB];  // last member of sub-batch k the reference's loop reaches (-1: none)
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          newm[k] = __ballot(isnew[k]);
+          last[k] = r[k] - 1;
+          if (hit_limit) {  // the walk ended in an earlier sub-batch
+            if (isnew[k]) k4d_hash_retract(sc, slot[k]);
+            newm[k] = 0; last[k] = -1; r[k] = 0; endc[k] = false;
+            continue;
+          }
+          const uint32_t c = (uint32_t)__popcll(newm[k]);
+          if (c >= remaining) {
+            unsigned long long mrem = newm[k];
+            for (uint32_t q = 1; q < remaining; q++) mrem &= mrem - 1;  // drop the lowest remaining-1 bits
+            last[k] = __ffsll((long long)mrem) - 1;
+            hit_limit = true;
+            const unsigned long long beyond = last[k] >= 63 ? 0ull : (~0ull << (last[k] + 1));
+            if (isnew[k] && ((beyond >> lane) & 1)) k4d_hash_retract(sc, slot[k]);
+            newm[k] &= ~beyond;
+            endc[k] = false;
+          } else
+            remaining -= c;
         }
-        run_over = hit_limit || r < 64;
-        // replay in suffix order: only candidates that pass the order-independent part of the acceptance test can change
-        // the state; the rest just count
-        const unsigned long long foldm = __ballot(isnew && !eos && mm <= allow_mm) & newm;
-        unsigned long long todo = foldm;
-        int stop_lane = -1;
-        while (todo) {
-          const int c = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          const int mm_c = __shfl(mm, c, 64);
-          if (mm_c >= st.nxt) continue;
-          const int e_c = __shfl(e, c, 64);
-          const uint32_t loci_c = (uint32_t)__shfl((int)(uint32_t)(left - e_start), c, 64);
-          k4d_fold(st, mm_c, hits_w, rp.max_hits, ix.ent_id[e_c], loci_c, len, cur_strand);
-          if (st.inst > rp.max_hits && st.low == 0) { stop_lane = c; break; }
+        run_over = hit_limit || ended;  // (ended is false when every sub-batch looked at was full of members)
+        // 6. the Hamming extension (:6200-6261) for the candidates that are new in this strand pass
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          mm[k] = 0;
+          eos[k] = false;
+          if ((newm[k] >> lane) & 1) {
+            const uint64_t left = pos[k] - (uint64_t)o;
+            if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
+              for (int c = 0; 32 * c < len; c++)
+                mm[k] += (int)k4d_mm_count((k4d_ref_chunk(ix, (int64_t)left + 32 * c) ^ k4d_probe_chunk(sc, 32 * c)) &
+                                           k4d_range_mask(0, len - 32 * c));
+            } else {
+              bool all_eq;
+              k4d_lane_range(ix, sc.probe, 0, len, left, false, all_eq, eos[k], mm[k]);
+            }
+          }
         }
-        if (stop_lane >= 0) {  // early exit of :6313-6321: candidates behind it were never examined
-          const unsigned long long upto = stop_lane >= 63 ? ~0ull : ((1ull << (stop_lane + 1)) - 1ull);
-          const uint32_t took = (uint32_t)__popcll(newm & upto);
-          iter += (int)took; n_cand += took; n_nodes += took;
-          n_probe += (uint32_t)(stop_lane + 1) - (uint32_t)((base == t) ? 1 : 0);
-          done_all = true;
-          break;
+        // 7. replay in suffix order: only candidates that pass the order-independent part of the acceptance test can
+        //    change the state; the rest just count
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          if (done_all) break;
+          unsigned long long todo = __ballot(((newm[k] >> lane) & 1) && !eos[k] && mm[k] <= allow_mm);
+          int stop_lane = -1;
+          while (todo) {
+            const int c = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int mm_c = __shfl(mm[k], c, 64);
+            if (mm_c >= st.nxt) continue;
+            const int e_c = __shfl(e[k], c, 64);
+            const uint32_t loci_c = (uint32_t)__shfl((int)loci[k], c, 64);
+            k4d_fold(st, mm_c, hits_w, rp.max_hits, ix.ent_id[e_c], loci_c, len, cur_strand);
+            if (st.inst > rp.max_hits && st.low == 0) { stop_lane = c; break; }
+          }
+          const uint32_t first_adj = (base == t && k == 0) ? 1u : 0u;  // the first suffix of the run is not a probe
+          if (stop_lane >= 0) {  // early exit of :6313-6321: candidates behind it were never examined
+            const unsigned long long upto = stop_lane >= 63 ? ~0ull : ((1ull << (stop_lane + 1)) - 1ull);
+            const uint32_t took = (uint32_t)__popcll(newm[k] & upto);
+            iter += (int)took; n_cand += took; n_nodes += took;
+            n_probe += (uint32_t)(stop_lane + 1) - first_adj;
+            done_all = true;
+          } else if (last[k] >= 0 || endc[k]) {
+            const uint32_t took = (uint32_t)__popcll(newm[k]);
+            iter += (int)took; n_cand += took; n_nodes += took;
+            // probes the reference counted: every member reached after the first suffix, plus the comparison that ended the run
+            n_probe += (uint32_t)(last[k] + 1) - (last[k] >= 0 ? first_adj : 0u) + (uint32_t)(endc[k] ? 1 : 0);
+          }
         }
-        {
-          const uint32_t took = (uint32_t)__popcll(newm);
-          iter += (int)took; n_cand += took; n_nodes += took;
-          // probes the reference counted: every member reached after the first suffix, plus the comparison that ended the run
-          n_probe += (uint32_t)(last + 1) - (uint32_t)((base == t) ? 1 : 0) + (uint32_t)((!hit_limit && end_compared) ? 1 : 0);
-        }
+        if (done_all) break;
         if (n_nodes >= node_cap && node_cap < (uint32_t)K4_MAX_IDENT_NODES && sc.small) {
           if (cur_strand == '-') k4d_revcomp_wave(sc, len);
           return K4_NEED_SLOW;
