@@ -67,15 +67,35 @@ __global__ void __launch_bounds__(256) k4k_fastx_records(K4FastxArgs a) {
   if (a.fastq) e1 = a.nl[hl + 1];
   else e1 = (uint64_t)r + 1 < a.n_hdr ? k4d_line_start(a.nl, a.hdr[r + 1]) : (uint32_t)a.text_bytes;
   if (e1 < s1) e1 = s1;
-  uint32_t n = 0;
-  for (uint32_t q = s1; q < e1; q++) n += !k4d_is_space(a.text[q]);
   if (a.fastq && a.text[k4d_line_start(a.nl, hl + 2)] != '+') bad = true;
   a.seq_off[r] = s1;
   a.seq_span[r] = e1 - s1;
-  a.lens[r] = n;
-  atomicAdd(&a.tot[0], (unsigned long long)n);
-  atomicMax(&a.tot[1], (unsigned long long)n);
   if (bad) atomicAdd(&a.tot[2], 1ull);
+}
+
+// one wave per record: bases = bytes of the sequence span that are not white space (coalesced along the span)
+__global__ void __launch_bounds__(64) k4k_fastx_count(const uint8_t* __restrict__ text, const uint32_t* __restrict__ seq_off,
+                                                      const uint32_t* __restrict__ seq_span, int64_t n_rec,
+                                                      uint32_t* __restrict__ lens, unsigned long long* __restrict__ tot) {
+  const int lane = threadIdx.x;
+  unsigned long long sum = 0;
+  uint32_t mx = 0;
+  for (int64_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
+    const uint8_t* src = text + seq_off[r];
+    const uint32_t span = seq_span[r];
+    uint32_t n = 0;
+    for (uint32_t q = 0; q < span; q += 64) {
+      const bool keep = q + lane < span && !k4d_is_space(src[q + lane]);
+      n += (uint32_t)__popcll(__ballot(keep));
+    }
+    if (lane == 0) lens[r] = n;
+    sum += n;
+    mx = max(mx, n);
+  }
+  if (lane == 0) {  // (the tallies are wave-uniform)
+    if (sum) atomicAdd(&tot[0], sum);
+    if (mx) atomicMax(&tot[1], (unsigned long long)mx);
+  }
 }
 
 // one wave per record: the sequence bytes of its span, white space squeezed out, as etSeqBase codes
@@ -98,12 +118,49 @@ __global__ void __launch_bounds__(64) k4k_fastx_encode(const uint8_t* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) k4k_count_newlines(const uint8_t* __restrict__ text, uint64_t n, unsigned long long* __restrict__ out) {
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  uint32_t c = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) c += text[i] == '\n';
+// Line ends in two passes over 4 KB tiles (256 threads x 16 bytes): newlines per tile, then -- after a scan of the tile
+// counts -- their offsets, in text order (exclusive scan of the per-thread counts inside the block).
+#define K4_NL_TILE 4096
+K4_DEV uint32_t k4d_nl_mask(const uint8_t* __restrict__ text, uint64_t n, uint64_t base) {
+  uint32_t m = 0;
+  if (base + 16 <= n) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) m |= (uint32_t)(text[base + q] == '\n') << q;
+  } else
+    for (int q = 0; q < 16; q++)
+      if (base + q < n) m |= (uint32_t)(text[base + q] == '\n') << q;
+  return m;
+}
+__global__ void __launch_bounds__(256) k4k_nl_tiles(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t ws[4];
+  const uint64_t base = (uint64_t)blockIdx.x * K4_NL_TILE + (uint64_t)threadIdx.x * 16;
+  uint32_t c = __popc(k4d_nl_mask(text, n, base));
   for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ void __launch_bounds__(256) k4k_nl_scatter(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_off,
+                                                      uint32_t* __restrict__ nl) {
+  __shared__ uint32_t ws[4];
+  const uint64_t base = (uint64_t)blockIdx.x * K4_NL_TILE + (uint64_t)threadIdx.x * 16;
+  uint32_t m = k4d_nl_mask(text, n, base);
+  const uint32_t c = __popc(m);
+  uint32_t inc = c;  // inclusive scan inside the wave
+  const int lane = threadIdx.x & 63;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t v = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += v;
+  }
+  if (lane == 63) ws[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint32_t off = tile_off[blockIdx.x] + inc - c;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += ws[w];
+  while (m) {
+    const int q = __ffs(m) - 1;
+    m &= m - 1;
+    nl[off++] = (uint32_t)(base + q);
+  }
 }
 
 struct IsHeaderLine {  // FASTA: the line starts with '>'
@@ -140,27 +197,33 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
     if (!format) return k4_fail(ix, K4_ERR_NOT_FASTA, "input is neither FASTA ('>') nor FASTQ ('@')");
   }
   const bool fastq = format == K4_FASTQ;
-  Buf tot, nlb, hdrb, tmp, cnt, so, ss;
+  Buf tot, nlb, hdrb, tmp, cnt, so, ss, tcnt, toff;
   K4_HIP(ix, tot.alloc(32));
   K4_HIP(ix, cnt.alloc(8));
   K4_HIP(ix, hipMemsetAsync(tot.p, 0, 32, st));
-  hipLaunchKernelGGL(k4k_count_newlines, dim3(4096), dim3(256), 0, st, text, text_bytes, tot.as<unsigned long long>() + 3);
-  unsigned long long n_nl = 0;
+  const uint64_t n_tiles = (text_bytes + K4_NL_TILE - 1) / K4_NL_TILE;
+  K4_HIP(ix, tcnt.alloc((n_tiles + 1) * 4));
+  K4_HIP(ix, toff.alloc((n_tiles + 1) * 4));
+  K4_HIP(ix, hipMemsetAsync(tcnt.as<uint32_t>() + n_tiles, 0, 4, st));
+  hipLaunchKernelGGL(k4k_nl_tiles, dim3((unsigned)n_tiles), dim3(256), 0, st, text, text_bytes, tcnt.as<uint32_t>());
+  {
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, tcnt.as<uint32_t>(), toff.as<uint32_t>(), 0u, (size_t)(n_tiles + 1),
+                                       rocprim::plus<uint32_t>(), st));
+    K4_HIP(ix, tmp.alloc(tb));
+    K4_HIP(ix, rocprim::exclusive_scan(tmp.p, tb, tcnt.as<uint32_t>(), toff.as<uint32_t>(), 0u, (size_t)(n_tiles + 1),
+                                       rocprim::plus<uint32_t>(), st));
+  }
+  uint32_t n_nl32 = 0;
   uint8_t last = 0;
-  K4_HIP(ix, hipMemcpyAsync(&n_nl, tot.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, st));
+  K4_HIP(ix, hipMemcpyAsync(&n_nl32, toff.as<uint32_t>() + n_tiles, 4, hipMemcpyDeviceToHost, st));
   K4_HIP(ix, hipMemcpyAsync(&last, text + text_bytes - 1, 1, hipMemcpyDeviceToHost, st));
   K4_HIP(ix, hipStreamSynchronize(st));
+  const unsigned long long n_nl = n_nl32;
   // line ends: every '\n', plus the end of the text when the final chunk's last line is unterminated
   uint64_t n_lines = n_nl;
   K4_HIP(ix, nlb.alloc((n_nl + 2) * 4));
-  {
-    rocprim::counting_iterator<uint32_t> idx(0);
-    auto flags = rocprim::make_transform_iterator(text, IsNewline());
-    size_t tb = 0;
-    K4_HIP(ix, rocprim::select(nullptr, tb, idx, flags, nlb.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)text_bytes, st));
-    K4_HIP(ix, tmp.alloc(tb));
-    K4_HIP(ix, rocprim::select(tmp.p, tb, idx, flags, nlb.as<uint32_t>(), cnt.as<uint64_t>(), (size_t)text_bytes, st));
-  }
+  hipLaunchKernelGGL(k4k_nl_scatter, dim3((unsigned)n_tiles), dim3(256), 0, st, text, text_bytes, toff.as<uint32_t>(), nlb.as<uint32_t>());
   if (final_chunk && last != '\n') {
     const uint32_t endp = (uint32_t)text_bytes;
     K4_HIP(ix, hipMemcpyAsync(nlb.as<uint32_t>() + n_nl, &endp, 4, hipMemcpyHostToDevice, st));
@@ -215,6 +278,8 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
   a.seq_off = so.as<uint32_t>(); a.seq_span = ss.as<uint32_t>(); a.lens = (uint32_t*)d_lens;
   a.name_off = (uint64_t*)d_name_off; a.name_len = (uint32_t*)d_name_len; a.tot = tot.as<unsigned long long>();
   hipLaunchKernelGGL(k4k_fastx_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k4k_fastx_count, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 18)), dim3(64), 0, st, text, so.as<uint32_t>(),
+                     ss.as<uint32_t>(), n_rec, (uint32_t*)d_lens, tot.as<unsigned long long>());
   {
     size_t tb = 0;
     K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, (const uint32_t*)d_lens, (uint64_t*)d_offs, reads_base, (size_t)n_rec,
@@ -247,19 +312,27 @@ __global__ void __launch_bounds__(256) k4k_prepare_reads(int pe, int64_t n, uint
                                                          uint64_t base2, uint64_t* __restrict__ oo, uint32_t* __restrict__ lo,
                                                          unsigned long long* __restrict__ tot) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t a = l1[i], b = pe ? l2[i] : a;
-  const bool under = a < min_len || b < min_len;      // sloughed, KAligner.cpp:12024-12060
-  const bool over = !under && (a > max_len || b > max_len);
-  const bool keep = !under && !over;
-  if (under) atomicAdd(&tot[0], 1ull);
-  if (over) atomicAdd(&tot[1], 1ull);
-  if (keep) atomicMax(&tot[2], (unsigned long long)max(a, b));
-  if (pe) {
-    oo[2 * i] = o1[i]; lo[2 * i] = keep ? a : 0;
-    oo[2 * i + 1] = o2[i] + base2; lo[2 * i + 1] = keep ? b : 0;
-  } else {
-    oo[i] = o1[i]; lo[i] = keep ? a : 0;
+  const bool valid = i < n;  // (no early return: the wave reductions below need every lane)
+  const uint32_t a = valid ? l1[i] : 0u, b = valid ? (pe ? l2[i] : a) : 0u;
+  const bool under = valid && (a < min_len || b < min_len);  // sloughed, KAligner.cpp:12024-12060
+  const bool over = valid && !under && (a > max_len || b > max_len);
+  const bool keep = valid && !under && !over;
+  if (valid) {
+    if (pe) {
+      oo[2 * i] = o1[i]; lo[2 * i] = keep ? a : 0;
+      oo[2 * i + 1] = o2[i] + base2; lo[2 * i + 1] = keep ? b : 0;
+    } else {
+      oo[i] = o1[i]; lo[i] = keep ? a : 0;
+    }
+  }
+  // one atomic per wave and tally
+  const unsigned long long mu = __ballot(under), mo = __ballot(over);
+  uint32_t mx = keep ? max(a, b) : 0u;
+  for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+  if ((threadIdx.x & 63) == 0) {
+    if (mu) atomicAdd(&tot[0], (unsigned long long)__popcll(mu));
+    if (mo) atomicAdd(&tot[1], (unsigned long long)__popcll(mo));
+    if (mx) atomicMax(&tot[2], (unsigned long long)mx);
   }
 }
 }  // namespace
@@ -431,26 +504,32 @@ __global__ void __launch_bounds__(256) k4k_sam_line_lens(K4SamArgs a, const uint
   if (j < m) ll[j] = k4d_sam_line_len(a, order[j]);
 }
 
-// one wave per line: QNAME FLAG RNAME POS MAPQ <len>M RNEXT PNEXT TLEN SEQ * (AddAlignment, SAMfile.cpp:2194-2377)
+// 16 lanes per line, four lines per wave: QNAME FLAG RNAME POS MAPQ <len>M RNEXT PNEXT TLEN SEQ * (AddAlignment,
+// SAMfile.cpp:2194-2377).  The group's first lane formats the numeric fields into LDS, then the 16 lanes copy the pieces.
 __global__ void __launch_bounds__(64) k4k_sam_write(K4SamArgs a, const uint32_t* __restrict__ order, const uint64_t* __restrict__ loff,
                                                     uint64_t m, char* __restrict__ out) {
-  __shared__ char mid[2][64];
-  __shared__ uint32_t midn[2];
-  const int lane = threadIdx.x;
-  for (uint64_t j = blockIdx.x; j < m; j += gridDim.x) {
-    const int64_t v = order[j];
-    const k4_hit h = k4d_sam_hit(a, v);
-    const int64_t i = k4d_sam_read(a, v);
-    const int w = a.pe ? (int)(i & 1) : 0;
-    const int64_t rec = a.pe ? (i >> 1) : i;
+  __shared__ char mid[4][2][64];
+  __shared__ uint32_t midn[4][2];
+  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+  for (uint64_t jb = (uint64_t)blockIdx.x * 4; jb < m; jb += (uint64_t)gridDim.x * 4) {
+    const uint64_t j = jb + grp;
+    const bool on = j < m;
+    int64_t v = 0, i = 0;
+    k4_hit h;
+    memset(&h, 0, sizeof(h));
+    if (on) {
+      v = order[j];
+      h = k4d_sam_hit(a, v);
+      i = k4d_sam_read(a, v);
+    }
     __syncthreads();
-    if (lane == 0) {
+    if (on && gl == 0) {
       const K4SamFields f = k4d_sam_fields(a, v, h);
-      char* p = mid[0];
+      char* p = mid[grp][0];
       uint32_t n = 0;
       p[n++] = '\t'; n += k4d_put_uint(p + n, f.flag); p[n++] = '\t';
-      midn[0] = n;
-      p = mid[1];
+      midn[grp][0] = n;
+      p = mid[grp][1];
       n = 0;
       p[n++] = '\t'; n += k4d_put_uint(p + n, f.pos);
       p[n++] = '\t'; n += k4d_put_uint(p + n, f.mapq);
@@ -461,30 +540,34 @@ __global__ void __launch_bounds__(64) k4k_sam_write(K4SamArgs a, const uint32_t*
       if (f.tlen < 0) p[n++] = '-';
       n += k4d_put_uint(p + n, (uint32_t)(f.tlen < 0 ? -(int64_t)f.tlen : f.tlen));
       p[n++] = '\t';
-      midn[1] = n;
+      midn[grp][1] = n;
     }
     __syncthreads();
+    if (!on) continue;
+    const int w = a.pe ? (int)(i & 1) : 0;
+    const int64_t rec = a.pe ? (i >> 1) : i;
     char* dst = out + loff[j];
     const uint8_t* nm = a.text[w] + a.name_off[w][rec];
     const uint32_t nl_ = a.name_len[w][rec];
-    for (uint32_t q = lane; q < nl_; q += 64) dst[q] = (char)nm[q];
+    for (uint32_t q = gl; q < nl_; q += 16) dst[q] = (char)nm[q];
     dst += nl_;
-    for (uint32_t q = lane; q < midn[0]; q += 64) dst[q] = mid[0][q];
-    dst += midn[0];
+    const uint32_t n0 = midn[grp][0], n1 = midn[grp][1];
+    for (uint32_t q = gl; q < n0; q += 16) dst[q] = mid[grp][0][q];
+    dst += n0;
     const char* cn = a.cnames + (size_t)(h.chrom_id - 1) * K4_SAM_NAME_STRIDE;
     const uint32_t cl = a.cname_len[h.chrom_id - 1];
-    for (uint32_t q = lane; q < cl; q += 64) dst[q] = cn[q];
+    for (uint32_t q = gl; q < cl; q += 16) dst[q] = cn[q];
     dst += cl;
-    for (uint32_t q = lane; q < midn[1]; q += 64) dst[q] = mid[1][q];
-    dst += midn[1];
+    for (uint32_t q = gl; q < n1; q += 16) dst[q] = mid[grp][1][q];
+    dst += n1;
     const uint8_t* s = a.reads + a.offs[i];
     const uint32_t len = a.lens[i];
     if (h.strand == '+')
-      for (uint32_t q = lane; q < len; q += 64) { const uint8_t b = s[q] & 7; dst[q] = "ACGTN"[b > 4 ? 4 : b]; }
+      for (uint32_t q = gl; q < len; q += 16) { const uint8_t b = s[q] & 7; dst[q] = "ACGTN"[b > 4 ? 4 : b]; }
     else
-      for (uint32_t q = lane; q < len; q += 64) { const uint8_t b = s[len - 1 - q] & 7; dst[q] = b <= 3 ? "TGCA"[b] : 'N'; }  // :6279
+      for (uint32_t q = gl; q < len; q += 16) { const uint8_t b = s[len - 1 - q] & 7; dst[q] = b <= 3 ? "TGCA"[b] : 'N'; }  // :6279
     dst += len;
-    if (lane == 0) { dst[0] = '\t'; dst[1] = '*'; dst[2] = '\n'; }
+    if (gl == 0) { dst[0] = '\t'; dst[1] = '*'; dst[2] = '\n'; }
   }
 }
 
@@ -634,7 +717,7 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
   K4_HIP(ix, hipMemcpy(&total, lo.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost));
   char* out = nullptr;
   K4_HIP(ix, hipMalloc(&out, total + 16));
-  hipLaunchKernelGGL(k4k_sam_write, dim3((unsigned)std::min<uint64_t>(m, 1u << 20)), dim3(64), 0, st, a, order, lo.as<uint64_t>(), m, out);
+  hipLaunchKernelGGL(k4k_sam_write, dim3((unsigned)std::min<uint64_t>((m + 3) / 4, 1u << 20)), dim3(64), 0, st, a, order, lo.as<uint64_t>(), m, out);
   int rc = k4_check_hip(ix, hipGetLastError(), "SAM write");
   if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(st), "SAM write");
   if (rc != K4_OK) {
