@@ -110,7 +110,9 @@ typedef struct {
   int32_t max_ml;         /* max(m_MaxMLmatches, PE ? cMaxMLPEmatches : 0) (KAligner.cpp:9604) */
   int32_t pe_mode;        /* classification of a read with hits (KAligner.cpp:9907-10023): 0 SE, default MLMode (accepted,
                            * first instance); 1 PE (accepted iff one instance, else multi-aligned with NumHits = instances);
-                           * 2 SE, MLMode eMLall (`-r5 -R<max_ml>`): accepted with NumHits = instances, every one reported */
+                           * 2 SE, MLMode eMLall (`-r5 -R<max_ml>`): accepted with NumHits = instances, every one reported;
+                           * 3 = 2 with reads over the limit treated as if exactly max_ml matched (`-X`, :9856-9861);
+                           * 4 = 3 through CSfxArray::LocateBestMatches (`-N`, SfxArray.cpp:6836-7205) instead of AlignReads */
   int32_t min_core_len;   /* 0: derive as LocateCoredApprox does (KAligner.cpp:9367-9393) */
   int32_t max_num_slides; /* 0: derive from pmode */
 } k4_kalign_params;

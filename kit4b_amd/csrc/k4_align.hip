@@ -162,14 +162,15 @@ K4_DEV void k4d_finalize(const K4AlignArgs& a, int64_t i, int len, const K4ReadP
     a.rslt[i] = rslt; a.inst[i] = inst; a.low[i] = low; a.nxt[i] = nxt;
     return;
   }
-  // CKAligner::AlignRead classification, KAligner.cpp:9854,9890-10079 (SE default MLMode / PE)
+  // CKAligner::AlignRead classification, KAligner.cpp:9854,9890-10079 (SE default MLMode / PE / eMLall)
   k4_read_result r;
   if (inst > rp.max_hits) inst = rp.max_hits + 1;
+  if (a.kp.pe_mode >= 3 && rslt == K4_HR_HITINSTS) { inst = rp.max_hits; rslt = K4_HR_HITS; }  // -X / -N clamp, :9856-9861
   r.hit_rslt = rslt; r.inst = inst; r.low_mm = low; r.nxt_mm = nxt; r.nar = K4_NAR_NOHIT; r.num_hits = 0;
   switch (rslt) {
     case K4_HR_NONE: r.inst = 0; r.low_mm = 0; r.nxt_mm = 0; break;
     case K4_HR_HITS:
-      if (a.kp.pe_mode == 2) { r.nar = K4_NAR_ACCEPTED; r.num_hits = min(inst, rp.max_hits); }  // eMLall: every instance is reported (:9913-9931)
+      if (a.kp.pe_mode >= 2) { r.nar = K4_NAR_ACCEPTED; r.num_hits = min(inst, rp.max_hits); }  // eMLall: every instance is reported (:9913-9931)
       else if (!a.kp.pe_mode || inst == 1) { r.nar = K4_NAR_ACCEPTED; r.num_hits = 1; }
       else { r.nar = K4_NAR_MULTIALIGN; r.num_hits = inst; }
       break;
@@ -609,6 +610,7 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
           }
         }
         slow = fl != 0 && !skip;
+        if (a.mode == 1 && a.kp.pe_mode == 4 && !skip) slow = true;  // -N: LocateBestMatches lives in the general kernel
       } else {
         const uint64_t* row = in_rows + (int64_t)j * K4_ROW_WORDS(NCH);
         {
@@ -1167,6 +1169,128 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
   return k4d_lcm_result(*p_inst, *p_low, p_nxt, st, rp.mm_delta, rp.max_hits, p_inst, p_low);
 }
 
+// LocateBestMatches (SfxArray.cpp:6836-7205; CKAligner's -N): at most max_hits alignments with no more than max_tot_mm
+// mismatches, kept sorted by mismatches.  One wave per read, every lane runs the same control flow; lane 0 keeps the hit
+// list.  Returns 0, 1..max_hits, or max_hits + 1 when further matches were sloughed (K4_NEED_SLOW: small table outgrown).
+template <int EL>
+K4_DEV int k4d_best_slow(const K4AlignArgs& a, K4Slow& sc, int len, int max_tot_mm, int cl, int core_delta,
+                         const K4ReadParams& rp, int* p_inst, k4_hit* hits, uint32_t& n_lookup, uint32_t& n_probe,
+                         uint32_t& n_cand) {
+  const K4DevIndex& ix = a.ix;
+  const int max_hits = rp.max_hits, max_iter = ix.max_iter;
+  const int64_t n = (int64_t)ix.n;
+  int inst = 0;
+  bool sloughed = false;
+  int strand = rp.strand;
+  char cur_strand = '+';
+  if (strand == K4_STRAND_CRICK) { k4d_revcomp_wave(sc, len); cur_strand = '-'; }
+  do {
+    int cur_delta = core_delta, slides = 0;
+    uint32_t n_nodes = 0;
+    sc.gen++;
+    const uint32_t node_cap = min((uint32_t)K4_MAX_IDENT_NODES, sc.cap / 2 - 1);
+    for (int o = 0; slides < rp.max_slides && o <= len - cl && cur_delta > cl / 3 && n_nodes < node_cap; slides++, o += cur_delta) {
+      if (o + cl + cur_delta > len) cur_delta = len - (o + cl);
+      n_lookup++;
+      int64_t t = k4d_first_exact_wave<EL>(ix, sc, o, cl, n_probe);
+      if (t == 0) continue;
+      t -= 1;
+      int iter = 0;
+      bool first = true;
+      uint32_t num_copies = 0;
+      while (!max_iter || iter < max_iter) {
+        if (n_nodes >= node_cap) break;
+        if (!first) {
+          if (t + 1 >= n) break;
+          const uint64_t p2 = k4d_sa_at<EL>(ix, (uint64_t)t + 1);
+          if ((int64_t)p2 + cl > n) break;
+          if (iter == 100 && !num_copies) {  // :6969-6976 too many copies of this core: give it up
+            int64_t lo = t, hi = n - 1;       // LocateLastExact: the last suffix that still starts with the core
+            while (lo < hi) {
+              const int64_t mid = lo + (hi - lo + 1) / 2;
+              n_probe++;
+              if (k4d_lane_cmp(ix, sc, o, cl, k4d_sa_at<EL>(ix, (uint64_t)mid)) == 0) lo = mid; else hi = mid - 1;
+            }
+            num_copies = (uint32_t)(1 + (lo + 1) - t);
+            if (max_iter && num_copies > (uint32_t)max_iter) break;
+          }
+          n_probe++;
+          if (k4d_lane_cmp(ix, sc, o, cl, p2) != 0) break;
+          t += 1;
+        }
+        first = false;
+        const uint64_t pos = k4d_sa_at<EL>(ix, (uint64_t)t);
+        if (pos < (uint64_t)o) continue;
+        const uint64_t left = pos - (uint64_t)o;
+        if (left + (uint64_t)len > ix.n) continue;  // :7034 (no entry test here: a separator shows up as EOS below)
+        int isnew = 0;
+        if (sc.lane == 0) {
+          uint32_t slot;
+          isnew = k4d_hash_insert_lane(sc, (uint32_t)(1 + pos - (uint32_t)o), slot) ? 1 : 0;
+        }
+        if (!__shfl(isnew, 0, 64)) continue;
+        n_nodes++;
+        if (n_nodes >= node_cap && node_cap < (uint32_t)K4_MAX_IDENT_NODES && sc.small) {
+          if (cur_strand == '-') k4d_revcomp_wave(sc, len);
+          return K4_NEED_SLOW;
+        }
+        iter++;
+        n_cand++;
+        int mm = 0;
+        bool eos = false, all_eq;
+        if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
+          for (int c = 0; 32 * c < len; c++)
+            mm += (int)k4d_mm_count((k4d_ref_chunk(ix, (int64_t)left + 32 * c) ^ k4d_probe_chunk(sc, 32 * c)) &
+                                    k4d_range_mask(0, len - 32 * c));
+        } else
+          k4d_lane_range(ix, sc.probe, 0, len, left, false, all_eq, eos, mm);
+        if (eos || mm > max_tot_mm) continue;  // :7060-7127
+        // :7129-7176 sorted insert (lane 0 owns the list), then every lane learns the new state
+        int st_inst = inst, st_mm = max_tot_mm, st_sl = sloughed ? 1 : 0;
+        if (sc.lane == 0) {
+          int cur = -1;
+          if (inst) {
+            if (inst == max_hits) st_sl = 1;
+            int b;
+            for (b = 0; b < inst; b++)
+              if ((int)hits[b].mismatches > mm) {
+                cur = b;
+                if (b + 1 < max_hits)
+                  for (int q = min(inst, max_hits - 1); q > b; q--) hits[q] = hits[q - 1];
+                break;
+              }
+            if (b == inst && inst < max_hits) cur = inst;
+          } else
+            cur = 0;
+          if (cur >= 0) {
+            uint64_t e_start = 0, e_end = 0;
+            const int e = k4d_map_entry_slow(ix, sc.ent, left, e_start, e_end);
+            if (e >= 0) {
+              k4d_store_hit(&hits[cur], ix.ent_id[e], (uint32_t)(left - e_start), len, cur_strand, mm);
+              if (inst < max_hits) st_inst = inst + 1;
+              else st_mm = (int)hits[inst - 1].mismatches;  // :7171-7175 only better ones from now on
+            }
+          }
+        }
+        inst = __shfl(st_inst, 0, 64);
+        max_tot_mm = __shfl(st_mm, 0, 64);
+        sloughed = __shfl(st_sl, 0, 64) != 0;
+      }
+      if (inst == max_hits && max_tot_mm == 0 && !sloughed) { strand = 3; break; }
+    }
+    if (cur_strand == '+' && strand == K4_STRAND_BOTH) {
+      k4d_revcomp_wave(sc, len);
+      cur_strand = '-';
+      strand = K4_STRAND_CRICK;
+    } else
+      strand = 3;
+  } while (!(inst == max_hits && max_tot_mm == 0 && !sloughed) && strand != 3);
+  if (cur_strand == '-') k4d_revcomp_wave(sc, len);
+  *p_inst = inst;
+  if (inst == 0) return 0;
+  return sloughed ? inst + 1 : inst;
+}
+
 // persistent waves pull read ids from their list until it is drained (every wave reaches the exit test).
 // pass 0: many waves with small dedupe tables (list = slow_list, ctl[0]/[1]); pass 1: few waves with tables sized for
 // the reference's own limits (list = huge_list, ctl[K4_CTL_HUGE]/[+1]).
@@ -1226,6 +1350,20 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
       for (int j = lane; j < len; j += 64) probe_s[j] = src[j] & 7;
       __syncthreads();
       k4d_pack_probe_wave(sc, len);
+      if (a.mode == 1 && a.kp.pe_mode == 4) {  // -N (KAligner.cpp:9776-9796): LocateBestMatches instead of AlignReads
+        const int r = k4d_best_slow<EL>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, hits, n_lookup, n_probe, n_cand);
+        if (r == K4_NEED_SLOW) {
+          n_lookup = r0; n_probe = r1; n_cand = r2;
+          if (lane == 0) {
+            const uint32_t slot = atomicAdd(&a.ctl[K4_CTL_HUGE], 1u);
+            a.huge_list[slot] = (uint32_t)i;
+            a.huge_step[slot] = (uint8_t)from_phase;
+          }
+          continue;
+        }
+        if (lane == 0) k4d_finalize(a, i, len, rp, r == 0 ? K4_HR_NONE : K4_HR_HITS, inst, 0, 0);
+        continue;
+      }
       if (rp.tot_mm > 0) {
         for (allow = 0; allow <= rp.tot_mm; allow++) {
           int cl = len / (allow + rp.mm_delta);
@@ -1456,7 +1594,7 @@ static int resolve_kalign(k4_index* ix, const k4_kalign_params* p, k4_kalign_par
   if (!p) return K4_ERR_PARAMS;
   *out = *p;
   if (p->max_subs < 0 || p->max_subs > 15 || (p->min_edit_dist != 1 && p->min_edit_dist != 2) || p->max_ns < 0 ||
-      p->strand < 0 || p->strand > 2 || p->max_ml < 1 || p->max_ml > 4096 || p->pe_mode < 0 || p->pe_mode > 2)
+      p->strand < 0 || p->strand > 2 || p->max_ml < 1 || p->max_ml > 4096 || p->pe_mode < 0 || p->pe_mode > 4)
     return k4_fail(ix, K4_ERR_PARAMS, "kalign parameters out of range");
   int slides = 0;
   int mcl = k4_min_core_len(ix, p->pmode, &slides);

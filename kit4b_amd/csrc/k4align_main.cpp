@@ -10,7 +10,7 @@
 //   statistics           CKAligner::ReportAlignStats :3600-3830 (NAR histogram, strand counts)
 //   SAM                  CKAligner::WriteBAMReadHits :5718-5914, ReportBAMread :5957-6320, SortHitMatch :10969,
 //                        CSAMfile::AddAlignment libkit4b/SAMfile.cpp:2194-2377 -> k4_format_sam_dev; header :1615,1667-1669,1799
-// Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R (plus -g <gpu>).
+// Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R -X -N (plus -g <gpu>).
 #include <zlib.h>
 #include <algorithm>
 #include <chrono>
@@ -28,6 +28,7 @@ struct Opts {
   int max_subs = 5, min_edit = 1, pmode = 0, max_ns = 1, pe_mode = 0, pair_min = 100, pair_max = 1000, pair_strand = 0;
   int min_len = 50, max_len = 500;  // cDfltMinAcceptReadLen / cDfltMaxAcceptReadLen, KAligner.h:112-113
   int ml_mode = 0, max_multi = 0;   // -r / -R (etMLMode, KAligner.h:250-258)
+  bool clamp = false, best = false; // -X / -N (KAlignerCL.cpp:278-280)
   int gpu = 0;
 };
 
@@ -108,7 +109,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-u mates] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0|1|5] [-R maxmulti=5] [-g gpu=0]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0|1|5] [-R maxmulti=5] [-X] [-N] [-g gpu=0]\n");
 }
 
 }  // namespace
@@ -136,6 +137,8 @@ int main(int argc, char** argv) {
       case 'L': o.max_len = atoi(val().c_str()); break;
       case 'r': o.ml_mode = atoi(val().c_str()); break;
       case 'R': o.max_multi = atoi(val().c_str()); break;
+      case 'X': o.clamp = true; break;
+      case 'N': o.best = true; break;
       case 'g': o.gpu = atoi(val().c_str()); break;
       case 'b': (void)val(); break;  // (batch size of earlier versions: the whole input is one device batch now)
       case 'T': case 'F': (void)val(); break;  // accepted and ignored (threads, log file)
@@ -148,6 +151,7 @@ int main(int argc, char** argv) {
   // pick or cluster one locus (2 random, 3/4 AssignMultiMatches) are not part of this path
   if (o.ml_mode != 0 && o.ml_mode != 1 && o.ml_mode != 5) { fprintf(stderr, "k4align: -r%d is not supported (0, 1 and 5 are)\n", o.ml_mode); return 1; }
   if (o.ml_mode != 0 && pe) { fprintf(stderr, "k4align: multiloci processing '-r%d' not supported in paired end processing\n", o.ml_mode); return 1; }
+  if ((o.clamp || o.best) && o.ml_mode != 5) { fprintf(stderr, "k4align: -X / -N are supported together with -r5 only\n"); return 1; }
   int max_ml = 1;
   if (o.ml_mode != 0) {
     max_ml = o.max_multi ? o.max_multi : 5;  // cDfltMaxMultiHits
@@ -195,7 +199,8 @@ int main(int argc, char** argv) {
   auto t_parse = std::chrono::steady_clock::now();
 
   // ---- align (ProcCoredApprox / ProcessPairedEnds) -----------------------------------------------------------------
-  k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, max_ml, o.ml_mode == 5 ? 2 : o.ml_mode == 1 ? 1 : 0,
+  k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, max_ml,
+                         o.ml_mode == 5 ? (o.best ? 4 : o.clamp ? 3 : 2) : o.ml_mode == 1 ? 1 : 0,
                          mcl, slides};
   k4_pe_params pp = {o.pe_mode, o.pair_min, o.pair_max, o.pair_strand};
   void *d_rr = nullptr, *d_hits = nullptr, *d_pe = nullptr;

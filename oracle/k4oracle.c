@@ -556,6 +556,113 @@ int k4o_locate_core_multiples(const k4o_index* ix, int max_tot_mm, int core_len,
   return K4O_HR_HITS;
 }
 
+/* ---- LocateBestMatches, SfxArray.cpp:6836-7205: at most max_hits alignments with no more than max_tot_mm mismatches,
+ * kept sorted by mismatches; returns 0 (none), 1..max_hits, or max_hits+1 when further matches were sloughed;
+ * *p_inst = alignments in hits[].  hits needs room for max_hits + 1 records (the reference's own memmove spills one). */
+static int64_t locate_last_exact(const k4o_index* ix, const uint8_t* probe, int probe_len, int64_t first_idx) {
+  /* LocateLastExact (:8226-8340) as the reference calls it here: index+1 of the last suffix that starts with the probe;
+   * first_idx is a suffix known to match */
+  int64_t lo = first_idx, hi = (int64_t)ix->n - 1;
+  while (lo < hi) { /* largest index whose suffix still equals the probe */
+    int64_t mid = lo + (hi - lo + 1) / 2;
+    if (cmp_probe_targ(probe, ix->seq + k4o_sa_at(ix, mid), probe_len) == 0) lo = mid; else hi = mid - 1;
+  }
+  return lo + 1;
+}
+
+int k4o_locate_best_matches(const k4o_index* ix, int max_tot_mm, int core_len, int core_delta, int max_slides, int strand,
+                            uint8_t* probe, int probe_len, int max_hits, int* p_inst, k4o_hit* hits, int cur_max_iter,
+                            k4o_counters* ctr) {
+  if (ix->n == 0) return -1;
+  const int64_t n = (int64_t)ix->n;
+  int inst = 0, sloughed = 0;
+  if (p_inst) *p_inst = 0;
+  char cur_strand = '+';
+  if (strand == K4O_STRAND_CRICK) { k4o_revcomp(probe, probe_len); cur_strand = '-'; }
+  idset ids;
+  idset_init(&ids);
+  do {
+    int cur_delta = core_delta, slides = 0;
+    uint32_t n_nodes = 0;
+    idset_clear(&ids);
+    for (int ofs = 0; slides < max_slides && ofs <= probe_len - core_len && cur_delta > core_len / 3 &&
+                      n_nodes < K4O_MAX_IDENT_NODES;
+         slides++, ofs += cur_delta) {
+      if (ofs + core_len + cur_delta > probe_len) cur_delta = probe_len - (ofs + core_len);
+      int64_t t = k4o_locate_first_exact(ix, probe + ofs, core_len, 0, n - 1, ctr);
+      if (t == 0) continue;
+      t -= 1;
+      int iter = 0, first = 1;
+      uint32_t num_copies = 0;
+      while (!cur_max_iter || iter < cur_max_iter) {
+        if (n_nodes >= K4O_MAX_IDENT_NODES) break;
+        if (!first) {
+          if (t + 1 >= n || k4o_sa_at(ix, t + 1) + core_len > n) break;
+          if (iter == 100 && !num_copies) { /* :6969-6976 too many copies of this core: give it up */
+            int64_t last = locate_last_exact(ix, probe + ofs, core_len, t);
+            num_copies = last > 0 ? (uint32_t)(1 + last - t) : 0;
+            if (cur_max_iter && num_copies > (uint32_t)cur_max_iter) break;
+          }
+          if (cmp_probe_targ(probe + ofs, ix->seq + k4o_sa_at(ix, t + 1), core_len) != 0) break;
+          t += 1;
+        }
+        first = 0;
+        int64_t pos = k4o_sa_at(ix, t);
+        if (pos < (int64_t)(uint32_t)ofs) continue;
+        int64_t left = pos - ofs;
+        if ((uint64_t)left + (uint32_t)probe_len > ix->n) continue; /* :7034 */
+        uint32_t targ_id = (uint32_t)(1 + pos - (uint32_t)ofs);
+        if (!idset_insert(&ids, targ_id)) continue;
+        n_nodes++;
+        iter++;
+        if (ctr) ctr->n_cand++;
+        const uint8_t* tb = ix->seq + left;
+        int mm = 0, i;
+        for (i = 0; i < probe_len; i++) { /* :7060-7125 */
+          uint8_t tv = tb[i] & 0x0f, pv = probe[i] & 0x0f;
+          if (tv == K4O_EOS) break;
+          if (pv == tv) continue;
+          if (++mm > max_tot_mm) break;
+        }
+        if (i != probe_len) continue;
+        /* :7129-7176 keep the hits sorted by mismatches, at most max_hits of them */
+        int cur = -1;
+        if (inst) {
+          if (inst == max_hits) sloughed = 1;
+          int b;
+          for (b = 0; b < inst; b++)
+            if (hits[b].mismatches > mm) {
+              cur = b;
+              if (b + 1 < max_hits) memmove(&hits[b + 1], &hits[b], sizeof(k4o_hit) * (size_t)(inst - b));
+              break;
+            }
+          if (b == inst && inst < max_hits) cur = inst;
+        } else
+          cur = 0;
+        if (cur >= 0) {
+          const k4o_entry* e = map_chunk_hit2entry(ix, (uint64_t)left);
+          if (e == NULL) continue; /* (cannot happen: the window holds no separator) */
+          store_hit(&hits[cur], e, left, cur_strand, probe_len, mm);
+          if (inst < max_hits) inst += 1;
+          else max_tot_mm = hits[inst - 1].mismatches; /* :7171-7175 only better ones from now on */
+        }
+      }
+      if (inst == max_hits && max_tot_mm == 0 && !sloughed) { strand = 3; break; }
+    }
+    if (cur_strand == '+' && strand == K4O_STRAND_BOTH) {
+      k4o_revcomp(probe, probe_len);
+      cur_strand = '-';
+      strand = K4O_STRAND_CRICK;
+    } else
+      strand = 3;
+  } while (!(inst == max_hits && max_tot_mm == 0 && !sloughed) && strand != 3);
+  idset_free(&ids);
+  if (cur_strand == '-') k4o_revcomp(probe, probe_len);
+  if (p_inst) *p_inst = inst;
+  if (inst == 0) return 0;
+  return sloughed ? inst + 1 : inst;
+}
+
 /* ---- AlignReads, SfxArray.cpp:7838-7933 (microInDelLen = MaxSpliceJunctLen = MinChimericLen = 0) -- */
 int k4o_align_reads(const k4o_index* ix, int tot_mm, int core_len, int core_delta, int max_slides, int min_core_len,
                     int mm_delta, int strand, int* inst, int* low, int* nxt, uint8_t* probe, int probe_len,
@@ -640,9 +747,20 @@ static int align_read_with(const k4o_index* ix, const k4o_kalign_params* kp, int
   int inst = 0, low = 0, nxt = 0;
   int max_ml = kp->max_ml < 1 ? 1 : kp->max_ml;
   memset(hits, 0, sizeof(k4o_hit) * (size_t)max_ml);
-  int r = k4o_align_reads(ix, tot_mm, core_len, core_delta, slides, min_core_len, kp->min_edit_dist, kp->strand, &inst,
-                          &low, &nxt, scratch, read_len, max_ml, hits, ctr);
+  int r;
+  if (kp->pe_mode == 4) { /* -N: LocateBestMatches instead of AlignReads, :9776-9796 */
+    k4o_hit* tmp = (k4o_hit*)calloc((size_t)max_ml + 1, sizeof(k4o_hit));
+    r = k4o_locate_best_matches(ix, tot_mm, core_len, core_delta, slides, kp->strand, scratch, read_len, max_ml, &inst, tmp,
+                                ix->max_iter, ctr);
+    memcpy(hits, tmp, sizeof(k4o_hit) * (size_t)max_ml);
+    for (int q = inst; q < max_ml; q++) memset(&hits[q], 0, sizeof(k4o_hit));
+    free(tmp);
+    r = r == 0 ? K4O_HR_NONE : (r >= 1 ? K4O_HR_HITS : r);
+  } else
+    r = k4o_align_reads(ix, tot_mm, core_len, core_delta, slides, min_core_len, kp->min_edit_dist, kp->strand, &inst,
+                        &low, &nxt, scratch, read_len, max_ml, hits, ctr);
   if (inst > max_ml) inst = max_ml + 1; /* :9854 */
+  if (kp->pe_mode >= 3 && r == K4O_HR_HITINSTS) { inst = max_ml; r = K4O_HR_HITS; } /* -X / -N clamp, :9856-9861 */
   out->hit_rslt = r;
   out->inst = inst; out->low_mm = low; out->nxt_mm = nxt;
   switch (r) {
@@ -650,7 +768,7 @@ static int align_read_with(const k4o_index* ix, const k4o_kalign_params* kp, int
       out->nar = K4O_NAR_NOHIT; out->low_mm = 0; out->inst = 0; out->nxt_mm = 0; /* tsReadHit fields as AlignRead leaves them */
       break;
     case K4O_HR_HITS: /* :9907-10025 */
-      if (kp->pe_mode == 2) { out->nar = K4O_NAR_ACCEPTED; out->num_hits = inst < max_ml ? inst : max_ml; } /* eMLall :9913-9931 */
+      if (kp->pe_mode >= 2) { out->nar = K4O_NAR_ACCEPTED; out->num_hits = inst < max_ml ? inst : max_ml; } /* eMLall :9913-9931 */
       else if (!kp->pe_mode || inst == 1) { out->nar = K4O_NAR_ACCEPTED; out->num_hits = 1; }
       else { out->nar = K4O_NAR_MULTIALIGN; out->num_hits = inst; }
       break;

@@ -27,6 +27,9 @@ CASES = {
     "se_s5_e2_m1": (["-s5", "-e2", "-m1"], lambda ch: synth.make_reads(ch, 1500, 120, seed=4323, sub_lambda=2.5, n_prob=0.03)[0]),
     # MLMode eMLall: every locus of a multi-aligned read is reported, up to -R
     "se_r5_R12": (["-s2", "-r5", "-R12"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4324, n_prob=0.02, edge_frac=0.05)[0]),
+    # the same with reads over the limit clamped to -R (-X), and with LocateBestMatches instead of AlignReads (-N)
+    "se_r5_R6_X": (["-s2", "-r5", "-R6", "-X"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4325, n_prob=0.02, edge_frac=0.05)[0]),
+    "se_r5_R8_N": (["-s3", "-r5", "-R8", "-N"], lambda ch: synth.make_reads(ch, 3000, 110, seed=4326, sub_lambda=1.5, n_prob=0.02, edge_frac=0.05)[0]),
 }
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # case names: regenerate just these (others keep their files)
 PE_CASES = {

@@ -217,7 +217,9 @@ def _kalign_args(args):
         elif a.startswith("-d"): pe["pair_min_len"] = int(a[2:])
         elif a.startswith("-D"): pe["pair_max_len"] = int(a[2:])
         elif a.startswith("-R"): kw["max_ml"] = int(a[2:])
-        elif a == "-r5": kw["pe_mode"] = 2  # MLMode eMLall: every instance reported
+        elif a == "-r5": kw["pe_mode"] = max(kw.get("pe_mode", 0), 2)  # MLMode eMLall: every instance reported
+        elif a == "-X": kw["pe_mode"] = max(kw.get("pe_mode", 0), 3)   # ... reads over the -R limit clamped to it
+        elif a == "-N": kw["pe_mode"] = 4                               # ... through LocateBestMatches
     return kw, pe
 
 

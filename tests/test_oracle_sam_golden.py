@@ -26,7 +26,9 @@ def kalign_args(args):
         elif a.startswith("-d"): pe["pair_min_len"] = int(a[2:])
         elif a.startswith("-D"): pe["pair_max_len"] = int(a[2:])
         elif a.startswith("-R"): kw["max_ml"] = int(a[2:])
-        elif a == "-r5": kw["pe_mode"] = 2  # MLMode eMLall: every instance reported
+        elif a == "-r5": kw["pe_mode"] = max(kw.get("pe_mode", 0), 2)  # MLMode eMLall: every instance reported
+        elif a == "-X": kw["pe_mode"] = max(kw.get("pe_mode", 0), 3)   # ... reads over the -R limit clamped to it
+        elif a == "-N": kw["pe_mode"] = 4                               # ... through LocateBestMatches
     return kw, pe
 
 
@@ -56,7 +58,7 @@ def test_se_matches_reference_sam(oracle, golden_dir, case):
     r = oracle.kalign_batch(h, reads, **kw)
     names, reads, res = expand_all_hits(names, reads, r["out"], r["hits"])
     _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
-    if kw.get("pe_mode") == 2:  # the reference's own tallies are per reported locus in this mode (KAligner.cpp:571-600)
+    if kw.get("pe_mode", 0) >= 2:  # the reference's own tallies are per reported locus in this mode (KAligner.cpp:571-600)
         assert CASES[case]["nar"]["AA"] == len(recs) == sum(1 for x in res if x["nar"] == 1)
         assert (r["out"]["num_hits"] > 1).sum() > 5
     else:
