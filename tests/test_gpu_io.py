@@ -226,3 +226,36 @@ def test_sam_emit_pe(ix, k4, pe_mode):
     want = _sam_lines_host(names, inter, None, None, names_c, pe=host)
     assert body == want
     assert stats["n_lines"] == (host["nar"] == 1).sum()
+
+
+def test_k4align_edge_inputs(golden_dir, tmp_path):
+    """empty input, input where every read is under the length filter, FASTQ input: header-only or ordinary SAM, no crash"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "kit4b_amd", "k4align")
+    sfx = os.path.join(golden_dir, "g1.sfx")
+
+    def run(text, *extra):
+        f = tmp_path / "in.fx"
+        f.write_bytes(text)
+        out = tmp_path / "out.sam"
+        p = subprocess.run([exe, "-I", sfx, "-o", str(out), "-s2", "-i", str(f)] + list(extra), capture_output=True, text=True,
+                           timeout=120)
+        return p, out.read_text().splitlines() if out.exists() else None
+
+    p, lines = run(b"")
+    assert p.returncode == 0, p.stderr
+    assert lines and all(l.startswith("@") for l in lines) and sum(l.startswith("@SQ") for l in lines) == 5
+    p, lines = run(b">a\nACGTACGTACGT\n>b\nACGT\n")
+    assert p.returncode == 0, p.stderr
+    assert all(l.startswith("@") for l in lines) and "2 under length" in p.stderr
+    names, chroms = synth.golden_genome()
+    rd = chroms[1][1000:1100]
+    seq = "".join(synth.BASES[b] for b in rd).encode()
+    p, lines = run(b"@q1 x\n" + seq + b"\n+\n" + b"I" * 100 + b"\n")
+    assert p.returncode == 0, p.stderr
+    recs = [l for l in lines if not l.startswith("@")]
+    assert len(recs) == 1 and recs[0].split("\t")[:4] == ["q1", "0", "chr2", "1001"]
+    p, _ = run(b">a\n" + seq + b"\n", "-r2")
+    assert p.returncode != 0 and "not supported" in p.stderr
