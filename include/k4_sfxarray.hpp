@@ -9,6 +9,7 @@
 //   * AlignReads() forwards one read as a batch of 1; throughput callers use AlignReadsBatch() / KAlignBatch()
 #ifndef K4_SFXARRAY_HPP
 #define K4_SFXARRAY_HPP
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -56,6 +57,20 @@ class CSfxArray {
   int m_Device;
   int m_MaxIter;
   std::deque<std::string> m_Errs;
+  std::vector<uint16_t> m_IdentFlags;  // per entry, the flags half of tsSfxEntry.fBlockID (SfxArray.cpp:2048-2079)
+
+  bool LoadIdentFlags() {
+    if (!m_pIdx) return false;
+    if (m_IdentFlags.empty()) {
+      const int n = GetNumEntries();
+      m_IdentFlags.resize((size_t)n, 0);
+      for (int e = 1; e <= n; e++) {
+        k4_entry ent;
+        if (k4_get_entry(m_pIdx, (uint32_t)e, &ent) == K4_OK) m_IdentFlags[(size_t)e - 1] = (uint16_t)((ent.fblock_id >> 8) & 0xffff);
+      }
+    }
+    return true;
+  }
 
   int Fail(int rc) {
     const char* m = m_pIdx ? k4_last_error(m_pIdx) : k4_global_error();
@@ -83,6 +98,7 @@ class CSfxArray {
     (void)bFlush;
     if (m_pIdx) k4_close(m_pIdx);
     m_pIdx = nullptr;
+    m_IdentFlags.clear();
     return 0;
   }
   int Close(bool bFlush = true) { return Reset(bFlush); }  // SfxArray.h:548
@@ -155,6 +171,27 @@ class CSfxArray {
   }
   k4_index* Handle(void) { return m_pIdx; }
 
+  // per-entry flags (SfxArray.h:959-965): kept on the host, they never reach the device
+  void InitAllIdentFlags(uint16_t Flags = 0) {
+    if (LoadIdentFlags()) std::fill(m_IdentFlags.begin(), m_IdentFlags.end(), Flags);
+  }
+  uint16_t GetIdentFlags(uint32_t EntryID) {
+    if (!LoadIdentFlags() || EntryID < 1 || EntryID > m_IdentFlags.size()) return (uint16_t)K4_ERR_ENTRY;
+    return m_IdentFlags[EntryID - 1];
+  }
+  uint16_t SetResetIdentFlags(uint32_t EntryID, uint16_t SetFlags = 0, uint16_t ResetFlags = 0) {  // returns the flags before the call
+    if (SetFlags == 0 && ResetFlags == 0) return GetIdentFlags(EntryID);
+    if (!LoadIdentFlags() || EntryID < 1 || EntryID > m_IdentFlags.size()) return (uint16_t)K4_ERR_ENTRY;
+    const uint16_t prev = m_IdentFlags[EntryID - 1];
+    m_IdentFlags[EntryID - 1] = (uint16_t)((prev | SetFlags) & ~ResetFlags);
+    return prev;
+  }
+  int GetColorspaceSeq(int EntryID, uint32_t Loci, etSeqBase* pRetSeq, uint32_t Len) {  // SOLiD only; IsSOLiD() is false here
+    (void)EntryID; (void)Loci; (void)pRetSeq; (void)Len;
+    m_Errs.push_back("CSfxArray::GetColorspaceSeq: colourspace indexes are outside the accelerated path");
+    return K4_ERR_UNSUPPORTED;
+  }
+
   // CSfxArray::AlignReads, SfxArray.h:614-634 -- identical parameter list.
   int AlignReads(uint32_t ExtdProcFlags, uint32_t ReadID, int MinChimericLen, int TotMM, int CoreLen, int CoreDelta,
                  int MaxNumCoreSlides, int MinCoreLen, int MMDelta, eALStrand Align2Strand, int microInDelLen,
@@ -181,6 +218,53 @@ class CSfxArray {
     *pLowHitInstances = inst; *pLowMMCnt = low; *pNxtLowMMCnt = nxt;
     int nvalid = (rslt >= eHRhits && rslt <= eHRHitInsts) ? (inst < MaxHits ? inst : MaxHits) : 0;
     for (int i = 0; i < nvalid; i++) Expand(hits[(size_t)i], &pHits[i]);
+    return rslt;
+  }
+
+  // CSfxArray::LocateBestMatches, SfxArray.h:793-806 -- identical parameter list (CKAligner's -N, KAligner.cpp:9779).
+  // Returns 0 (no match), 1..MaxHits, or MaxHits+1 when further matches were sloughed.
+  int LocateBestMatches(uint32_t ReadID, int MaxTotMM, int CoreLen, int CoreDelta, int MaxNumCoreSlides, eALStrand Align2Strand,
+                        etSeqBase* pProbeSeq, int ProbeLen, int MaxHits, int* pHitInstances, tsHitLoci* pHits, int CurMaxIter,
+                        int NumAllocdIdentNodes, tsIdentNode* pAllocsIdentNodes) {
+    (void)ReadID; (void)NumAllocdIdentNodes; (void)pAllocsIdentNodes;
+    if (!m_pIdx) return K4_ERR_INTERNAL;
+    if (pHitInstances) *pHitInstances = 0;
+    if (Align2Strand == eALSnone) return 0;
+    const int prev_iter = CurMaxIter != m_MaxIter ? k4_set_max_iter(m_pIdx, CurMaxIter) : -1;
+    k4_align_params p = {MaxTotMM, CoreLen, CoreDelta, MaxNumCoreSlides, 0, 1, (int32_t)Align2Strand, MaxHits};
+    uint64_t off = 0;
+    uint32_t len = (uint32_t)ProbeLen;
+    int32_t rslt = 0, inst = 0;
+    std::vector<k4_hit> hits((size_t)MaxHits);
+    int rc = k4_best_matches_batch(m_pIdx, &p, 1, pProbeSeq, &off, &len, &rslt, &inst, hits.data());
+    if (prev_iter >= 0) k4_set_max_iter(m_pIdx, prev_iter);
+    if (rc != K4_OK) return Fail(rc);
+    if (pHitInstances) *pHitInstances = inst;
+    for (int i = 0; i < inst && i < MaxHits; i++) Expand(hits[(size_t)i], &pHits[i]);
+    return rslt;
+  }
+
+  // CSfxArray::AlignPairedRead, SfxArray.h:880-896 -- identical parameter list (CKAligner's mate rescue,
+  // KAligner.cpp:3372-3386,3476-3490).  -1 errors, 0 no match, 1 placed with mismatches only.
+  int AlignPairedRead(bool b3primeExtend, bool bAntisense, uint32_t ChromID, uint32_t StartLoci, uint32_t EndLoci, int MinInsertSize,
+                      int MaxInsertSize, int MaxAllowedMM, int MinHamming, int ReadLen, int MinChimericLen, int CoreLen,
+                      int CoreDelta, int MaxNumCoreSlides, etSeqBase* pRead, tsHitLoci* pAlign) {
+    (void)MinHamming; (void)CoreLen; (void)CoreDelta; (void)MaxNumCoreSlides;  // (used by the seeded branch for windows >= 1000 only)
+    if (!m_pIdx) return -1;
+    if (MinChimericLen > 0) {
+      m_Errs.push_back("CSfxArray::AlignPairedRead: chimeric trimming is outside the accelerated path");
+      return K4_ERR_UNSUPPORTED;
+    }
+    k4_rescue_task t;
+    std::memset(&t, 0, sizeof(t));
+    t.chrom_id = ChromID; t.start_loci = StartLoci; t.end_loci = EndLoci; t.read_len = (uint32_t)ReadLen; t.read_off = 0;
+    t.b3prime_extend = b3primeExtend ? 1 : 0; t.antisense = bAntisense ? 1 : 0;
+    t.min_insert = MinInsertSize; t.max_insert = MaxInsertSize; t.max_allowed_mm = MaxAllowedMM;
+    int32_t rslt = 0;
+    k4_hit h;
+    int rc = k4_mate_rescue_batch(m_pIdx, 1, &t, pRead, (uint64_t)ReadLen, &rslt, &h);
+    if (rc != K4_OK) return Fail(rc);
+    if (rslt == 1 && pAlign) Expand(h, pAlign);
     return rslt;
   }
 

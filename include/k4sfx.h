@@ -186,6 +186,15 @@ int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n_reads
                         const void* d_reads, const void* d_offs, const void* d_lens, void* d_out, void* d_hits,
                         void* stream);
 int k4_min_core_len(const k4_index* ix, int pmode, int* max_num_slides); /* <- LocateCoredApprox, KAligner.cpp:9367-9393 */
+/* k4_best_matches_batch <- CSfxArray::LocateBestMatches (SfxArray.h:793, SfxArray.cpp:6836-7205; CKAligner's `-N`) for
+ * n_reads reads: at most p->max_hits alignments with no more than p->tot_mm mismatches, sorted by mismatches; rslt = the
+ * call's return value (0 none, 1..max_hits, max_hits+1 when further matches were sloughed), inst = alignments in the
+ * read's hit slots.  mm_delta and min_core_len of *p are not used; MaxIter is the index's (k4_set_max_iter). */
+int k4_best_matches_batch(k4_index* ix, const k4_align_params* p, int64_t n_reads, const uint8_t* reads, const uint64_t* offs,
+                          const uint32_t* lens, int32_t* rslt, int32_t* inst, k4_hit* hits);
+int k4_best_matches_batch_dev(k4_index* ix, const k4_align_params* p, int64_t n_reads, int32_t max_read_len,
+                              const void* d_reads, const void* d_offs, const void* d_lens, void* d_rslt, void* d_inst,
+                              void* d_hits, void* stream);
 
 /* ---- paired ends -----------------------------------------------------------------------------------------
  * k4_mate_rescue_batch <- CSfxArray::AlignPairedRead (SfxArray.h:880, SfxArray.cpp:8571-8767; MinChimericLen 0, insert

@@ -100,7 +100,7 @@ ABI_SYMBOLS = [
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
     "k4_get_kernel_times", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
-    "k4_copy_to_device", "k4_copy_to_host",
+    "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
 ]
 
 
@@ -145,6 +145,8 @@ def lib():
     L.k4_align_reads_batch.argtypes = [vp, C.POINTER(AlignParams), i64] + [vp] * 8
     L.k4_align_reads_batch_dev.argtypes = [vp, C.POINTER(AlignParams), i64, C.c_int32] + [vp] * 9
     L.k4_kalign_batch.argtypes = [vp, C.POINTER(KalignParams), i64] + [vp] * 5
+    L.k4_best_matches_batch.argtypes = [vp, C.POINTER(AlignParams), i64] + [vp] * 6
+    L.k4_best_matches_batch_dev.argtypes = [vp, C.POINTER(AlignParams), i64, C.c_int32] + [vp] * 7
     L.k4_kalign_batch_dev.argtypes = [vp, C.POINTER(KalignParams), i64, C.c_int32] + [vp] * 6
     L.k4_min_core_len.argtypes = [vp, i32, C.POINTER(C.c_int)]
     L.k4_get_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -311,6 +313,18 @@ class SfxIndex:
                                             lens.ctypes.data, rslt.ctypes.data, inst.ctypes.data, low.ctypes.data,
                                             nxt.ctypes.data, hits.ctypes.data))
         return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits)
+
+    def best_matches_batch(self, reads, tot_mm, core_len, core_delta, max_core_slides, strand=STRAND_BOTH, max_hits=5):
+        """CSfxArray::LocateBestMatches over a batch: rslt (the call's return value), inst, hits[n, max_hits]."""
+        cat, offs, lens = _flatten(reads)
+        n = len(lens)
+        p = AlignParams(tot_mm, core_len, core_delta, max_core_slides, 0, 1, strand, max_hits)
+        rslt = np.zeros(n, dtype=np.int32)
+        inst = np.zeros(n, dtype=np.int32)
+        hits = np.zeros((n, max_hits), dtype=HIT_DTYPE)
+        self._ck(lib().k4_best_matches_batch(self.h, C.byref(p), n, cat.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                                             rslt.ctypes.data, inst.ctypes.data, hits.ctypes.data))
+        return dict(rslt=rslt, inst=inst, hits=hits)
 
     def kalign_batch(self, reads, max_subs=5, min_edit_dist=1, max_ns=1, pmode=0, strand=STRAND_BOTH, max_ml=1,
                      pe_mode=0, min_core_len=0, max_num_slides=0):

@@ -54,6 +54,7 @@ struct K4AlignArgs {
   const uint32_t* lens;
   int64_t n_reads;
   int32_t mode;       // 0: AlignReads with uniform parameters, 1: CKAligner::AlignRead
+  int32_t best;       // mode 0 only: LocateBestMatches instead of AlignReads (every read runs in the general kernel)
   k4_align_params ap;
   k4_kalign_params kp;  // min_core_len / max_num_slides already resolved
   int32_t* rslt;
@@ -159,7 +160,9 @@ K4_DEV void k4d_finalize(const K4AlignArgs& a, int64_t i, int len, const K4ReadP
   int nvalid = (rslt == K4_HR_HITS || rslt == K4_HR_MMDELTA || rslt == K4_HR_HITINSTS) ? min(inst, rp.max_hits) : 0;
   for (int q = nvalid; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&hits[q]) = make_uint4(0, 0, 0, 0);
   if (a.mode == 0) {
-    a.rslt[i] = rslt; a.inst[i] = inst; a.low[i] = low; a.nxt[i] = nxt;
+    a.rslt[i] = rslt; a.inst[i] = inst;
+    if (a.low) a.low[i] = low;  // (the LocateBestMatches entry points have no low / nxt outputs)
+    if (a.nxt) a.nxt[i] = nxt;
     return;
   }
   // CKAligner::AlignRead classification, KAligner.cpp:9854,9890-10079 (SE default MLMode / PE / eMLall)
@@ -610,7 +613,7 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
           }
         }
         slow = fl != 0 && !skip;
-        if (a.mode == 1 && a.kp.pe_mode == 4 && !skip) slow = true;  // -N: LocateBestMatches lives in the general kernel
+        if (((a.mode == 1 && a.kp.pe_mode == 4) || a.best) && !skip) slow = true;  // LocateBestMatches lives in the general kernel
       } else {
         const uint64_t* row = in_rows + (int64_t)j * K4_ROW_WORDS(NCH);
         {
@@ -1350,7 +1353,7 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
       for (int j = lane; j < len; j += 64) probe_s[j] = src[j] & 7;
       __syncthreads();
       k4d_pack_probe_wave(sc, len);
-      if (a.mode == 1 && a.kp.pe_mode == 4) {  // -N (KAligner.cpp:9776-9796): LocateBestMatches instead of AlignReads
+      if ((a.mode == 1 && a.kp.pe_mode == 4) || a.best) {  // -N (KAligner.cpp:9776-9796): LocateBestMatches instead of AlignReads
         const int r = k4d_best_slow<EL>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, hits, n_lookup, n_probe, n_cand);
         if (r == K4_NEED_SLOW) {
           n_lookup = r0; n_probe = r1; n_cand = r2;
@@ -1361,7 +1364,13 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
           }
           continue;
         }
-        if (lane == 0) k4d_finalize(a, i, len, rp, r == 0 ? K4_HR_NONE : K4_HR_HITS, inst, 0, 0);
+        if (lane == 0) {
+          if (a.mode == 0) {  // the raw call: its own return value and instance count; unused slots zeroed
+            for (int q = inst; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&hits[q]) = make_uint4(0, 0, 0, 0);
+            a.rslt[i] = r; a.inst[i] = inst;
+          } else
+            k4d_finalize(a, i, len, rp, r == 0 ? K4_HR_NONE : K4_HR_HITS, inst, 0, 0);
+        }
         continue;
       }
       if (rp.tot_mm > 0) {
@@ -1590,6 +1599,24 @@ extern "C" int k4_align_reads_batch_dev(k4_index* ix, const k4_align_params* p, 
   return run_dev(ix, a, max_len, stream);
 }
 
+// CSfxArray::LocateBestMatches for n reads (SfxArray.h:793): rslt = its return value (0, 1..max_hits, max_hits+1 when
+// matches were sloughed), inst = alignments in the read's max_hits hit slots, sorted by mismatches
+extern "C" int k4_best_matches_batch_dev(k4_index* ix, const k4_align_params* p, int64_t n, int32_t max_len, const void* d_reads,
+                                         const void* d_offs, const void* d_lens, void* d_rslt, void* d_inst, void* d_hits,
+                                         void* stream) {
+  if (!ix) return K4_ERR_PARAMS;
+  int rc = check_align_params(ix, p);
+  if (rc != K4_OK) return rc;
+  if (n < 0 || (n > 0 && (!d_reads || !d_offs || !d_lens || !d_rslt || !d_inst || !d_hits))) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  K4AlignArgs a;
+  memset(&a, 0, sizeof(a));
+  a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
+  a.n_reads = n; a.mode = 0; a.best = 1; a.ap = *p;
+  a.rslt = (int32_t*)d_rslt; a.inst = (int32_t*)d_inst;  // (low / nxt are not outputs of this call and stay null)
+  a.hits = (k4_hit*)d_hits; a.max_hits = p->max_hits;
+  return run_dev(ix, a, max_len, stream);
+}
+
 static int resolve_kalign(k4_index* ix, const k4_kalign_params* p, k4_kalign_params* out) {
   if (!p) return K4_ERR_PARAMS;
   *out = *p;
@@ -1682,6 +1709,28 @@ extern "C" int k4_align_reads_batch(k4_index* ix, const k4_align_params* p, int6
   K4_HIP(ix, hipMemcpyAsync(inst, o + n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(low, o + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(nxt, o + 3 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipStreamSynchronize(ix->stream));
+  return K4_OK;
+}
+
+extern "C" int k4_best_matches_batch(k4_index* ix, const k4_align_params* p, int64_t n, const uint8_t* reads, const uint64_t* offs,
+                                     const uint32_t* lens, int32_t* rslt, int32_t* inst, k4_hit* hits) {
+  if (!ix) return K4_ERR_PARAMS;
+  int rc = check_align_params(ix, p);
+  if (rc != K4_OK) return rc;
+  if (n < 0 || (n > 0 && (!reads || !offs || !lens || !rslt || !inst || !hits))) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  if (n == 0) return K4_OK;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  int max_len = 1;
+  rc = stage_in(ix, n, reads, offs, lens, p->max_hits, &max_len, 16);
+  if (rc != K4_OK) return rc;
+  K4Workspace& w = ix->ws;
+  int32_t* o = w.d_out4;
+  rc = k4_best_matches_batch_dev(ix, p, n, max_len, w.d_reads, w.d_offs, w.d_lens, o, o + n, w.d_hits, ix->stream);
+  if (rc != K4_OK) return rc;
+  K4_HIP(ix, hipMemcpyAsync(rslt, o, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(inst, o + n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipStreamSynchronize(ix->stream));
   return K4_OK;

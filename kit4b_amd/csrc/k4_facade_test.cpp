@@ -47,6 +47,29 @@ int main(int argc, char** argv) {
   tsHitLoci Hit;
   Rslt = pSfx->AlignReads(0, 1, 50, 2, 33, 33, 8, 8, 1, eALSboth, 0, 0, &Inst, &Low, &Nxt, Probe.data(), 100, 1, &Hit, 16, Nodes);
   printf("chimeric rslt %d msgs %d\n", Rslt, pSfx->NumErrMsgs());
+  while (pSfx->NumErrMsgs()) pSfx->GetErrMsg();
+  // LocateBestMatches (CKAligner's -N, KAligner.cpp:9779) and AlignPairedRead (mate rescue, :3372) keep their signatures
+  {
+    if (pSfx->GetSeq(2, 1200, Probe.data(), 100) != 100) return 4;
+    std::vector<etSeqBase> P = Probe;
+    P[40] = (P[40] + 1) % 4;
+    int HitInst = 0;
+    tsHitLoci Best[4];
+    Rslt = pSfx->LocateBestMatches(1, 2, 33, 33, 8, eALSboth, P.data(), 100, 4, &HitInst, Best, pSfx->GetMaxIter(), 16, Nodes);
+    printf("best rslt %d inst %d chrom %u loci %llu strand %c mm %u\n", Rslt, HitInst, Best[0].Seg[0].ChromID,
+           (unsigned long long)Best[0].Seg[0].MatchLoci, Best[0].Seg[0].Strand, Best[0].Seg[0].Mismatches);
+    // the mate of a read at chr2:1000-1099 ('+'): fragment 300 long, so the mate (antisense) ends at 1299
+    std::vector<etSeqBase> Mate(100), Rc(100);
+    if (pSfx->GetSeq(2, 1200, Mate.data(), 100) != 100) return 4;
+    for (int k = 0; k < 100; k++) Rc[k] = Mate[99 - k] <= 3 ? 3 - Mate[99 - k] : Mate[99 - k];
+    tsHitLoci Pair;
+    Rslt = pSfx->AlignPairedRead(true, true, 2, 1000, 1099, 200, 600, 5, 1, 100, 0, 0, 0, 0, Rc.data(), &Pair);
+    printf("pair rslt %d chrom %u loci %llu strand %c mm %u\n", Rslt, Pair.Seg[0].ChromID, (unsigned long long)Pair.Seg[0].MatchLoci,
+           Pair.Seg[0].Strand, Pair.Seg[0].Mismatches);
+  }
+  printf("flags %u", (unsigned)pSfx->GetIdentFlags(1));
+  printf(" prev %u", (unsigned)pSfx->SetResetIdentFlags(1, 0x01, 0x00));
+  printf(" now %u solid %d\n", (unsigned)pSfx->GetIdentFlags(1), pSfx->IsSOLiD() ? 1 : 0);
   delete pSfx;
   return 0;
 }

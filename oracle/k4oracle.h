@@ -89,6 +89,9 @@ int64_t k4o_locate_first_exact(const k4o_index* ix, const uint8_t* probe, int pr
 int k4o_locate_core_multiples(const k4o_index* ix, int max_tot_mm, int core_len, int core_delta, int max_slides,
                               int mm_delta, int strand, int* inst, int* low, int* nxt, uint8_t* probe,
                               int probe_len, int max_hits, k4o_hit* hits, k4o_counters* ctr); /* :5806-6369 */
+int k4o_locate_best_matches(const k4o_index* ix, int max_tot_mm, int core_len, int core_delta, int max_slides, int strand,
+                            uint8_t* probe, int probe_len, int max_hits, int* inst, k4o_hit* hits /* max_hits + 1 */,
+                            int cur_max_iter, k4o_counters* ctr);                    /* :6836-7205 */
 int k4o_align_reads(const k4o_index* ix, int tot_mm, int core_len, int core_delta, int max_slides, int min_core_len,
                     int mm_delta, int strand, int* inst, int* low, int* nxt, uint8_t* probe, int probe_len,
                     int max_hits, k4o_hit* hits, k4o_counters* ctr);          /* SfxArray.cpp:7838-7933 */

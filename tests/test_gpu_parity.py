@@ -363,7 +363,43 @@ def test_csfxarray_facade_program(k4, golden_dir):
                 assert ("chrom 2 loci %d strand + mm %d len 100" % (loci, subs)) in l, l
             n += 1
     assert n == 16
-    assert lines[-1] == "chimeric rslt -3 msgs 1"
+    assert "chimeric rslt -3 msgs 1" in lines
+    assert "best rslt 1 inst 1 chrom 2 loci 1200 strand + mm 1" in lines      # LocateBestMatches, same signature
+    assert "pair rslt 1 chrom 2 loci 1200 strand - mm 0" in lines              # AlignPairedRead, same signature
+    assert lines[-1] == "flags 0 prev 0 now 1 solid 0"
+
+
+def test_best_matches_raw_call_vs_oracle(k4, oracle, golden_dir):
+    """k4_best_matches_batch (CSfxArray::LocateBestMatches) against the oracle's restatement, which the reference's own
+    `-N` SAM pins (tests/golden/sam_se_r5_R8_N.*): return value, instance count and the sorted hit list."""
+    import ctypes as C
+
+    names, chroms = synth.golden_genome()
+    reads, _ = synth.make_reads(chroms, 2500, 100, seed=8181, sub_lambda=1.6, n_prob=0.02, edge_frac=0.05)
+    ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    ho = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    for max_iter, max_hits, tot_mm in ((5000, 6, 3), (40, 3, 2), (5000, 1, 0)):
+        ix.set_max_iter(max_iter)
+        oracle.set_max_iter(ho, max_iter)
+        g = ix.best_matches_batch(reads, tot_mm, 25, 25, 8, max_hits=max_hits)
+        L = oracle.L
+        L.k4o_locate_best_matches.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                                                             C.c_void_p, C.c_int, C.c_void_p]
+        for i, rd in enumerate(reads):
+            buf = np.ascontiguousarray(rd, dtype=np.uint8).copy()
+            hits = np.zeros(max_hits + 1, dtype=g["hits"].dtype)
+            inst = C.c_int(0)
+            r = L.k4o_locate_best_matches(ho, tot_mm, 25, 25, 8, 0, buf.ctypes.data, len(buf), max_hits, C.byref(inst),
+                                          hits.ctypes.data, max_iter, None)
+            assert (r, inst.value) == (int(g["rslt"][i]), int(g["inst"][i])), (i, r, inst.value, g["rslt"][i], g["inst"][i])
+            assert np.array_equal(hits[: inst.value], g["hits"][i][: inst.value]), i
+            assert not g["hits"][i][inst.value:].view(np.uint8).any()
+        if max_hits > 1:
+            assert (g["inst"] > 1).sum() > 3
+        else:
+            assert (g["rslt"] == 2).sum() > 3  # one slot only: further matches were sloughed
+    ix.close()
+    oracle.close(ho)
 
 
 def test_cores_shorter_than_the_kmer_table(k4, oracle, golden_dir):
