@@ -46,6 +46,23 @@ typedef struct TAG_tsHitLoci {  // libkit4b/SfxArray.h:251-260 (50 bytes)
   tsSegLoci Seg[2];
 } tsHitLoci;
 #pragma pack()
+#pragma pack(4)
+typedef struct TAG_sSfxHeaderV3 {  // libkit4b/SfxArray.h:194-207 (1224 bytes)
+  uint8_t Magic[4];
+  int32_t Version;
+  uint32_t Attributes;
+  uint64_t FileLen;
+  uint64_t EntriesOfs;
+  uint32_t EntriesSize;
+  uint32_t NumSfxBlocks;
+  uint64_t SfxBlockSize;
+  uint64_t SfxBlockOfs;
+  uint8_t szDatasetName[81];
+  uint8_t szDescription[1024];
+  uint8_t szTitle[64];
+} tsSfxHeaderV3;
+#pragma pack()
+static_assert(sizeof(tsSfxHeaderV3) == 1224, "tsSfxHeaderV3 layout must match libkit4b");
 typedef struct TAG_sIdentNode {  // libkit4b/SfxArray.h:144-147 (caller scratch; unused here)
   uint32_t TargSeqID;
   struct TAG_sIdentNode* pNxt;
@@ -185,6 +202,10 @@ class CSfxArray {
     const uint16_t prev = m_IdentFlags[EntryID - 1];
     m_IdentFlags[EntryID - 1] = (uint16_t)((prev | SetFlags) & ~ResetFlags);
     return prev;
+  }
+  int GetSfxHeader(tsSfxHeaderV3* pSfxHeader) {  // SfxArray.h:551
+    if (!m_pIdx || !pSfxHeader) return K4_ERR_PARAMS;
+    return k4_get_sfx_header(m_pIdx, pSfxHeader);
   }
   int GetColorspaceSeq(int EntryID, uint32_t Loci, etSeqBase* pRetSeq, uint32_t Len) {  // SOLiD only; IsSOLiD() is false here
     (void)EntryID; (void)Loci; (void)pRetSeq; (void)Len;

@@ -158,6 +158,7 @@ int k4_get_ident(const k4_index* ix, const char* name);   /* <- CSfxArray::GetId
 int k4_set_max_iter(k4_index* ix, int max_iter);          /* <- CSfxArray::SetMaxIter, SfxArray.h:556 */
 int k4_get_seq(const k4_index* ix, uint32_t entry_id, uint32_t loci, uint8_t* out, uint32_t len); /* <- GetSeq, SfxArray.h:996 */
 int k4_write_sfx(const k4_index* ix, const char* sfx_path); /* <- CSfxArray::Finalise/Flush2Disk, SfxArray.cpp:892 */
+int k4_get_sfx_header(const k4_index* ix, void* out_1224);  /* <- CSfxArray::GetSfxHeader: tsSfxHeaderV3, SfxArray.h:194-207 */
 
 /* ---- suffix-array construction on the GPU -----------------------------------
  * <- CSfxArray::AddEntry + Finalise -> QSortSeq (SfxArray.cpp:1518,1758,9739): same suffix order

@@ -67,6 +67,9 @@ int main(int argc, char** argv) {
     printf("pair rslt %d chrom %u loci %llu strand %c mm %u\n", Rslt, Pair.Seg[0].ChromID, (unsigned long long)Pair.Seg[0].MatchLoci,
            Pair.Seg[0].Strand, Pair.Seg[0].Mismatches);
   }
+  tsSfxHeaderV3 Hdr;
+  pSfx->GetSfxHeader(&Hdr);
+  printf("header %.3s version %d blocks %u dataset %s\n", (const char*)Hdr.Magic, Hdr.Version, Hdr.NumSfxBlocks, (const char*)Hdr.szDatasetName);
   printf("flags %u", (unsigned)pSfx->GetIdentFlags(1));
   printf(" prev %u", (unsigned)pSfx->SetResetIdentFlags(1, 0x01, 0x00));
   printf(" now %u solid %d\n", (unsigned)pSfx->GetIdentFlags(1), pSfx->IsSOLiD() ? 1 : 0);

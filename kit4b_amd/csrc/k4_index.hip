@@ -543,6 +543,7 @@ extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out)
     d.end_ofs = rd<uint64_t>(p + 103);
   }
   int rc = k4_open_host(n, el, b + 20, b + 20 + n, ne, ents.data(), dataset, device, kmer_k, out);
+  if (rc == K4_OK && *out) (*out)->raw_header.assign(f, f + 1224);
   return done(rc);
 }
 
@@ -646,15 +647,11 @@ extern "C" int k4_get_seq(const k4_index* ix, uint32_t entry_id, uint32_t loci, 
 }
 
 // CSfxArray::Flush2Disk (SfxArray.cpp:892): header, block (sequence + suffix array), entries
-extern "C" int k4_write_sfx(const k4_index* cix, const char* path) {
-  if (!cix || !path) return K4_ERR_PARAMS;
-  k4_index* ix = const_cast<k4_index*>(cix);
+// tsSfxHeaderV3 (libkit4b/SfxArray.h:194-207, 1224 bytes, pack(4)) for an index that did not come from a file
+static void make_header(const k4_index* ix, uint8_t* hdr) {
   const uint64_t n = ix->d.n;
   const uint32_t el = ix->d.el, ne = ix->d.n_entries;
-  FILE* fp = fopen(path, "wb");
-  if (!fp) return k4_fail(ix, K4_ERR_CREATE_FILE, "unable to create %s", path);
-  uint8_t hdr[1224];
-  memset(hdr, 0, sizeof(hdr));
+  memset(hdr, 0, 1224);
   memcpy(hdr, "sfx5", 4);
   uint32_t ver = 5, attr = 0, nblocks = 1, entries_size = 8 + 111 * ne;
   uint64_t block_ofs = 1224, block_size = 20 + n + n * el, entries_ofs = block_ofs + block_size;
@@ -665,6 +662,25 @@ extern "C" int k4_write_sfx(const k4_index* cix, const char* path) {
   strncpy((char*)hdr + 52, ix->dataset.c_str(), 80);
   strncpy((char*)hdr + 133, "k4sfx MI355X index", 1023);
   strncpy((char*)hdr + 1157, "k4sfx", 63);
+}
+
+// CSfxArray::GetSfxHeader (SfxArray.h:551): the 1224-byte file header -- as read for an index opened from a file
+extern "C" int k4_get_sfx_header(const k4_index* ix, void* out_1224) {
+  if (!ix || !out_1224) return K4_ERR_PARAMS;
+  if (ix->raw_header.size() == 1224) memcpy(out_1224, ix->raw_header.data(), 1224);
+  else make_header(ix, (uint8_t*)out_1224);
+  return K4_OK;
+}
+
+extern "C" int k4_write_sfx(const k4_index* cix, const char* path) {
+  if (!cix || !path) return K4_ERR_PARAMS;
+  k4_index* ix = const_cast<k4_index*>(cix);
+  const uint64_t n = ix->d.n;
+  const uint32_t el = ix->d.el, ne = ix->d.n_entries;
+  FILE* fp = fopen(path, "wb");
+  if (!fp) return k4_fail(ix, K4_ERR_CREATE_FILE, "unable to create %s", path);
+  uint8_t hdr[1224];
+  make_header(ix, hdr);
   fwrite(hdr, 1, sizeof(hdr), fp);
   uint8_t bh[20];
   uint32_t bid = 1;
