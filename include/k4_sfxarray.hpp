@@ -13,10 +13,12 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "k4sfx.h"
 
+#ifndef K4_HAVE_KIT4B_TYPES  // (defined when libkit4b's own headers already provide these types: oracle/k4_dropin.h)
 typedef uint8_t etSeqBase;  // libkit4b/commdefs.h:87
 enum { eBaseA = 0, eBaseC, eBaseG, eBaseT, eBaseN, eBaseUndef, eBaseInDel, eBaseEOS };
 
@@ -62,18 +64,20 @@ typedef struct TAG_sSfxHeaderV3 {  // libkit4b/SfxArray.h:194-207 (1224 bytes)
   uint8_t szTitle[64];
 } tsSfxHeaderV3;
 #pragma pack()
-static_assert(sizeof(tsSfxHeaderV3) == 1224, "tsSfxHeaderV3 layout must match libkit4b");
 typedef struct TAG_sIdentNode {  // libkit4b/SfxArray.h:144-147 (caller scratch; unused here)
   uint32_t TargSeqID;
   struct TAG_sIdentNode* pNxt;
 } tsIdentNode;
-static_assert(sizeof(tsSegLoci) == 23 && sizeof(tsHitLoci) == 50, "tsHitLoci layout must match libkit4b");
+#endif  // K4_HAVE_KIT4B_TYPES
+static_assert(sizeof(tsSegLoci) == 23 && sizeof(tsHitLoci) == 50 && sizeof(tsSfxHeaderV3) == 1224, "layouts must match libkit4b");
 
 class CSfxArray {
   k4_index* m_pIdx;
   int m_Device;
   int m_MaxIter;
   std::deque<std::string> m_Errs;
+  std::mutex m_Mtx;  // CKAligner calls AlignReads / AlignPairedRead from many threads on one object; an
+                     // index handle runs one batch at a time, so the single-read calls are serialised here
   std::vector<uint16_t> m_IdentFlags;  // per entry, the flags half of tsSfxEntry.fBlockID (SfxArray.cpp:2048-2079)
 
   bool LoadIdentFlags() {
@@ -172,6 +176,7 @@ class CSfxArray {
     return name;
   }
   uint32_t GetSeq(int EntryID, uint32_t Loci, etSeqBase* pRetSeq, uint32_t Len) {  // SfxArray.h:996
+    std::lock_guard<std::mutex> lock(m_Mtx);
     return m_pIdx ? (uint32_t)k4_get_seq(m_pIdx, (uint32_t)EntryID, Loci, pRetSeq, Len) : 0;
   }
   int GetBase(int EntryID, uint32_t Loci) {  // SfxArray.h:992
@@ -234,6 +239,7 @@ class CSfxArray {
     uint32_t len = (uint32_t)ProbeLen;
     int32_t rslt = 0, inst = 0, low = 0, nxt = 0;
     std::vector<k4_hit> hits((size_t)MaxHits);
+    std::lock_guard<std::mutex> lock(m_Mtx);
     int rc = k4_align_reads_batch(m_pIdx, &p, 1, pProbeSeq, &off, &len, &rslt, &inst, &low, &nxt, hits.data());
     if (rc != K4_OK) return Fail(rc);
     *pLowHitInstances = inst; *pLowMMCnt = low; *pNxtLowMMCnt = nxt;
@@ -251,6 +257,7 @@ class CSfxArray {
     if (!m_pIdx) return K4_ERR_INTERNAL;
     if (pHitInstances) *pHitInstances = 0;
     if (Align2Strand == eALSnone) return 0;
+    std::lock_guard<std::mutex> lock(m_Mtx);
     const int prev_iter = CurMaxIter != m_MaxIter ? k4_set_max_iter(m_pIdx, CurMaxIter) : -1;
     k4_align_params p = {MaxTotMM, CoreLen, CoreDelta, MaxNumCoreSlides, 0, 1, (int32_t)Align2Strand, MaxHits};
     uint64_t off = 0;
@@ -283,6 +290,7 @@ class CSfxArray {
     t.min_insert = MinInsertSize; t.max_insert = MaxInsertSize; t.max_allowed_mm = MaxAllowedMM;
     int32_t rslt = 0;
     k4_hit h;
+    std::lock_guard<std::mutex> lock(m_Mtx);
     int rc = k4_mate_rescue_batch(m_pIdx, 1, &t, pRead, (uint64_t)ReadLen, &rslt, &h);
     if (rc != K4_OK) return Fail(rc);
     if (rslt == 1 && pAlign) Expand(h, pAlign);
