@@ -18,7 +18,7 @@
 #include <vector>
 #include "k4sfx.h"
 
-#ifndef K4_HAVE_KIT4B_TYPES  // (defined when libkit4b's own headers already provide these types: oracle/k4_dropin.h)
+#ifndef K4_HAVE_KIT4B_TYPES  // (define it when libkit4b's own headers already provide these types)
 typedef uint8_t etSeqBase;  // libkit4b/commdefs.h:87
 enum { eBaseA = 0, eBaseC, eBaseG, eBaseT, eBaseN, eBaseUndef, eBaseInDel, eBaseEOS };
 
