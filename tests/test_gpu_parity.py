@@ -644,3 +644,32 @@ def test_c5_scale_15gbp_se_and_pe_truth(k4):
         assert (o1["nar"][neither] != 1).all() and (o2["nar"][neither] != 1).all()
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("case", ["se_s2", "pe_u1", "se_r5_R8_N", "se_r5_R6_X"])
+def test_reference_sam_on_5byte_index_with_64bit_table(k4, golden_dir, g1_el5_path, monkeypatch, case):
+    """The same golden SAMs through the layouts a >= 2^32-symbol block uses: 5-byte suffix elements and (forced) 64-bit
+    k-mer table fields -- the EL=5 / 64-bit instantiations of the step, general, pairing and rescue kernels."""
+    monkeypatch.setenv("K4_FORCE_KTAB64", "1")
+    kw, pe = _kalign_args(SAM_CASES[case]["args"])
+    ix = k4.SfxIndex.open(g1_el5_path)
+    assert ix.info()["sfx_el_size"] == 5
+    ix.set_max_iter(5000)
+    _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    if case.startswith("se_"):
+        names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % case))
+        r = ix.kalign_batch(reads, **kw)
+        from test_oracle_sam_golden import expand_all_hits
+
+        names, reads, res = expand_all_hits(names, reads, r["out"], r["hits"])
+        got = samutil.sam_records(names, reads, res, CHROMS)
+    else:
+        n1, r1 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_1.fa.xz" % case))
+        n2, r2 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_2.fa.xz" % case))
+        out = ix.kalign_pe_batch(r1, r2, **pe, **kw)
+        names = [x for p in zip(n1, n2) for x in p]
+        reads = [x for p in zip(r1, r2) for x in p]
+        res = [dict(nar=int(o["nar"]), hit=o["hit"], pe_aligned=int(o["pe_aligned"])) for o in out]
+        got = samutil.sam_records(names, reads, res, CHROMS, paired=True)
+    assert sorted(got) == sorted(recs)
+    ix.close()
