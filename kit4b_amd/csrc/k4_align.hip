@@ -54,6 +54,7 @@ struct K4AlignArgs {
   const uint32_t* lens;
   int64_t n_reads;
   int32_t mode;       // 0: AlignReads with uniform parameters, 1: CKAligner::AlignRead
+  int32_t sparse_hits; // hit slots that hold no reported instance are left as they are (internal callers that never read them)
   int32_t best;       // mode 0 only: LocateBestMatches instead of AlignReads (every read runs in the general kernel)
   k4_align_params ap;
   k4_kalign_params kp;  // min_core_len / max_num_slides already resolved
@@ -158,7 +159,8 @@ K4_DEV void k4d_finalize(const K4AlignArgs& a, int64_t i, int len, const K4ReadP
                          int low, int nxt) {
   k4_hit* hits = a.hits + i * a.max_hits;
   int nvalid = (rslt == K4_HR_HITS || rslt == K4_HR_MMDELTA || rslt == K4_HR_HITINSTS) ? min(inst, rp.max_hits) : 0;
-  for (int q = nvalid; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&hits[q]) = make_uint4(0, 0, 0, 0);
+  if (!a.sparse_hits)
+    for (int q = nvalid; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&hits[q]) = make_uint4(0, 0, 0, 0);
   if (a.mode == 0) {
     a.rslt[i] = rslt; a.inst[i] = inst;
     if (a.low) a.low[i] = low;  // (the LocateBestMatches entry points have no low / nxt outputs)
@@ -608,7 +610,8 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
           if ((fl & K4_RF_INVALID) || (int)n_ns > max_ns) {
             k4_read_result r = {K4_HR_SEQERRS, 0, 0, 0, K4_NAR_NS, 0};
             a.rr[i] = r;
-            for (int q = 0; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&a.hits[i * a.max_hits + q]) = make_uint4(0, 0, 0, 0);
+            if (!a.sparse_hits)
+              for (int q = 0; q < a.max_hits; q++) *reinterpret_cast<uint4*>(&a.hits[i * a.max_hits + q]) = make_uint4(0, 0, 0, 0);
             skip = true;
           }
         }
@@ -1630,9 +1633,16 @@ static int resolve_kalign(k4_index* ix, const k4_kalign_params* p, k4_kalign_par
   return K4_OK;
 }
 
+// sparse_hits: the paired-end pass reads only the slots of reported instances, so the 10 slots per end need no zero fill
+int k4i_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len, const void* d_reads,
+                         const void* d_offs, const void* d_lens, void* d_out, void* d_hits, void* stream, int sparse_hits);
 extern "C" int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len,
                                    const void* d_reads, const void* d_offs, const void* d_lens, void* d_out,
                                    void* d_hits, void* stream) {
+  return k4i_kalign_batch_dev(ix, p, n, max_len, d_reads, d_offs, d_lens, d_out, d_hits, stream, 0);
+}
+int k4i_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len, const void* d_reads,
+                         const void* d_offs, const void* d_lens, void* d_out, void* d_hits, void* stream, int sparse_hits) {
   if (!ix) return K4_ERR_PARAMS;
   K4AlignArgs a;
   memset(&a, 0, sizeof(a));
@@ -1642,6 +1652,7 @@ extern "C" int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int6
   a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
   a.n_reads = n; a.mode = 1;
   a.rr = (k4_read_result*)d_out; a.hits = (k4_hit*)d_hits; a.max_hits = a.kp.max_ml;
+  a.sparse_hits = sparse_hits;
   return run_dev(ix, a, max_len, stream);
 }
 

@@ -120,6 +120,9 @@ int k4_check_hip(k4_index* ix, hipError_t e, const char* what);
 
 // k4_index.hip
 int k4i_build_device_structures(k4_index* ix, const void* d_seq_bytes, int kmer_k);
+// k4_align.hip
+int k4i_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len, const void* d_reads,
+                         const void* d_offs, const void* d_lens, void* d_out, void* d_hits, void* stream, int sparse_hits);
 // k4_sabuild.hip
 int k4i_build_sa(uint64_t n, uint32_t el, const uint8_t* d_seq, uint8_t* d_sa, int device, std::string* err);
 

@@ -339,7 +339,7 @@ extern "C" int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, c
   if (rc != K4_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   K4_HIP(ix, hipMemsetAsync(ix->pe_ctl, 0, 16, st));
-  rc = k4_kalign_batch_dev(ix, &kp, 2 * n_pairs, max_read_len, d_reads, d_offs, d_lens, ix->pe_rr, ix->pe_hits, stream);
+  rc = k4i_kalign_batch_dev(ix, &kp, 2 * n_pairs, max_read_len, d_reads, d_offs, d_lens, ix->pe_rr, ix->pe_hits, stream, 1);
   if (rc != K4_OK) return rc;
   hipLaunchKernelGGL(k4k_pe_pair, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, pe, n_pairs, mh, ix->pe_rr,
                      ix->pe_hits, (k4_pe_read*)d_out, ix->pe_list, ix->pe_ctl);
