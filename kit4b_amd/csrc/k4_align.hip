@@ -355,8 +355,8 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
             else memo_pending = lb1[0] == lb0[0] + 1;
           }
           // a bucket of one suffix whose next bases already disagree with the core cannot hold a match: drop it here
-          if (sizeof(KT) == 4 && tshift == 0 && lb1[j] == lb0[j] + 1 && cl > kk) {
-            const int nb = min(16, cl - kk);
+          if (tshift == 0 && lb1[j] == lb0[j] + 1 && cl > kk) {
+            const int nb = min(sizeof(KT) == 4 ? K4_SIG_BASES32 : K4_SIG_BASES64, cl - kk);
             const uint32_t cb = (uint32_t)(ln.chunk_at(s, oo[j] + kk) >> 32);
             const uint32_t df = (cb ^ sig[j]) & (0xFFFFFFFFu << (32 - 2 * nb));
             if (df) {

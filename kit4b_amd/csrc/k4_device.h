@@ -45,10 +45,13 @@ K4_DEV uint64_t k4d_sa_at(const K4DevIndex& ix, uint64_t i) {
   }
 }
 
-// k-mer table entry c = {lb, pos0[, sig]}: lb = number of suffixes sorting before k-mer c (its bucket is
-// [lb(c), lb(c+1))), pos0 = SA[lb] (offset of the bucket's first suffix, valid when the bucket is not empty) and, in
-// the 32-bit form, sig = the 16 bases that follow the k-mer in that first suffix (MSB-first), a filter that settles most
-// single-suffix buckets without touching the suffix array or the reference.
+// k-mer table entry c = {lb, pos0, sig}: lb = number of suffixes sorting before k-mer c (its bucket is
+// [lb(c), lb(c+1))), pos0 = SA[lb] (offset of the bucket's first suffix, valid when the bucket is not empty) and
+// sig = the bases that follow the k-mer in that first suffix (MSB-first; 16 of them in the 32-bit form, 12 in the 64-bit
+// form where they share a word with the 40-bit pos0), a filter that settles most single-suffix buckets without
+// touching the suffix array or the reference.
+#define K4_SIG_BASES32 16
+#define K4_SIG_BASES64 12
 #define K4_KTAB_STRIDE32 3
 #define K4_KTAB_STRIDE64 2
 K4_DEV uint64_t k4d_ktab_lb(const K4DevIndex& ix, uint64_t c) {
@@ -71,7 +74,8 @@ K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& l
   } else {
     const uint64_t* t = reinterpret_cast<const uint64_t*>(ix.ktab);
     const k4_u64x2_a8 v = *reinterpret_cast<const k4_u64x2_a8*>(t + K4_KTAB_STRIDE64 * c0);
-    lb0 = (KT)v.x; pos0 = (KT)v.y; sig = 0; lb1 = (KT)t[K4_KTAB_STRIDE64 * c1];
+    // 64-bit form: word 0 = lb, word 1 = pos0 (40 bits) | the 12 bases after the k-mer (24 bits, MSB first) << 40
+    lb0 = (KT)v.x; pos0 = (KT)(v.y & 0xFFFFFFFFFFull); sig = (uint32_t)(v.y >> 40) << 8; lb1 = (KT)t[K4_KTAB_STRIDE64 * c1];
   }
 }
 

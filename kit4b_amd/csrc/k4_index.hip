@@ -144,8 +144,11 @@ __global__ void __launch_bounds__(256) k4k_ktab_mark(K4DevIndex ix, T* __restric
       constexpr int ST = sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64;
       const uint64_t c = cc - 1;
       tab[ST * c] = (T)i;
-      tab[ST * c + 1] = (T)pos;
-      if (sizeof(T) == 4) tab[ST * c + 2] = (T)(k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 32);  // the next 16 bases
+      if (sizeof(T) == 4) {
+        tab[ST * c + 1] = (T)pos;
+        tab[ST * c + 2] = (T)(k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 32);  // the next 16 bases
+      } else  // 40-bit pos0 and the next 12 bases in one word
+        tab[ST * c + 1] = (T)((pos & 0xFFFFFFFFFFull) | ((k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 40) << 40));
     }
   }
 }
@@ -608,7 +611,8 @@ extern "C" int k4i_debug_ktab(const k4_index* ix, uint64_t c, uint64_t* out) {
   hipSetDevice(ix->device);
   if (ix->d.ktab64) {
     if (hipMemcpy(out, (const uint64_t*)ix->ktab + K4_KTAB_STRIDE64 * c, 16, hipMemcpyDeviceToHost) != hipSuccess) return K4_ERR_NO_DEVICE;
-    out[2] = 0;
+    out[2] = out[1] >> 40;
+    out[1] &= 0xFFFFFFFFFFull;
   } else {
     uint32_t v[3];
     if (hipMemcpy(v, (const uint32_t*)ix->ktab + K4_KTAB_STRIDE32 * c, 12, hipMemcpyDeviceToHost) != hipSuccess) return K4_ERR_NO_DEVICE;

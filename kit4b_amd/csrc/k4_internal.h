@@ -16,8 +16,8 @@
 // excblk    sorted list of the flagged block numbers; excnib holds, for flagged block r, its 256 symbols as
 //           nibbles (32 words, symbol j in bits 4*(j&7) of word r*32 + (j>>3)) -- the exact 4-bit reference.
 // sa        the .sfx suffix array unchanged: 4- or 5-byte little-endian elements.
-// ktab      direct-address table over the first k bases, 4^k + 1 entries {lb, pos0, sig} (12 bytes; {lb, pos0} of
-//           64-bit fields when concat_len >= 2^32): lb[c] = number of suffixes that sort before the k-mer with code c
+// ktab      direct-address table over the first k bases, 4^k + 1 entries {lb, pos0, sig} (12 bytes; 16 bytes when
+//           concat_len >= 2^32: 64-bit lb, then 40-bit pos0 and a 12-base sig sharing a word): lb[c] = number of suffixes that sort before the k-mer with code c
 //           (first base most significant), so the bucket of c is SA[lb[c] .. lb[c+1]); pos0[c] = SA[lb[c]], the
 //           offset of the bucket's first suffix, which saves the dependent SA fetch for the first probe of a lookup;
 //           sig[c] = the 16 bases after the k-mer in that suffix: a core that disagrees with it cannot match a
