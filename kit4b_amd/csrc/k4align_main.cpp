@@ -10,7 +10,7 @@
 //   statistics           CKAligner::ReportAlignStats :3600-3830 (NAR histogram, strand counts)
 //   SAM                  CKAligner::WriteBAMReadHits :5718-5914, ReportBAMread :5957-6320, SortHitMatch :10969,
 //                        CSAMfile::AddAlignment libkit4b/SAMfile.cpp:2194-2377 -> k4_format_sam_dev; header :1615,1667-1669,1799
-// Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R -X -N (plus -g <gpu>).
+// Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R -X -N (plus -g <gpu>, -S <i/N> read slice).
 #include <zlib.h>
 #include <algorithm>
 #include <chrono>
@@ -29,6 +29,7 @@ struct Opts {
   int min_len = 50, max_len = 500;  // cDfltMinAcceptReadLen / cDfltMaxAcceptReadLen, KAligner.h:112-113
   int ml_mode = 0, max_multi = 0;   // -r / -R (etMLMode, KAligner.h:250-258)
   bool clamp = false, best = false; // -X / -N (KAlignerCL.cpp:278-280)
+  int shard = 0, n_shards = 1;      // -S i/N: this process aligns the i-th of N contiguous slices of the reads (one process per GPU)
   int gpu = 0;
 };
 
@@ -109,7 +110,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-u mates] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0|1|5] [-R maxmulti=5] [-X] [-N] [-g gpu=0]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0|1|5] [-R maxmulti=5] [-X] [-N] [-S i/N] [-g gpu=0]\n");
 }
 
 }  // namespace
@@ -139,6 +140,7 @@ int main(int argc, char** argv) {
       case 'R': o.max_multi = atoi(val().c_str()); break;
       case 'X': o.clamp = true; break;
       case 'N': o.best = true; break;
+      case 'S': { std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2) { usage(); return 1; } break; }
       case 'g': o.gpu = atoi(val().c_str()); break;
       case 'b': (void)val(); break;  // (batch size of earlier versions: the whole input is one device batch now)
       case 'T': case 'F': (void)val(); break;  // accepted and ignored (threads, log file)
@@ -151,6 +153,7 @@ int main(int argc, char** argv) {
   // pick or cluster one locus (2 random, 3/4 AssignMultiMatches) are not part of this path
   if (o.ml_mode != 0 && o.ml_mode != 1 && o.ml_mode != 5) { fprintf(stderr, "k4align: -r%d is not supported (0, 1 and 5 are)\n", o.ml_mode); return 1; }
   if (o.ml_mode != 0 && pe) { fprintf(stderr, "k4align: multiloci processing '-r%d' not supported in paired end processing\n", o.ml_mode); return 1; }
+  if (o.n_shards < 1 || o.shard < 0 || o.shard >= o.n_shards) { fprintf(stderr, "k4align: -S i/N needs 0 <= i < N\n"); return 1; }
   if ((o.clamp || o.best) && o.ml_mode != 5) { fprintf(stderr, "k4align: -X / -N are supported together with -r5 only\n"); return 1; }
   int max_ml = 1;
   if (o.ml_mode != 0) {
@@ -184,10 +187,19 @@ int main(int argc, char** argv) {
   Parsed p1, p2;
   CK(load_reads(ix, t1, d_reads, 0, p1));
   if (pe) CK(load_reads(ix, t2, d_reads, p1.bases, p2));
+  const Parsed a1 = p1, a2 = p2;  // the allocations (p1 / p2 are narrowed to this process's slice below)
   std::vector<uint8_t>().swap(t1);
   std::vector<uint8_t>().swap(t2);
   if (pe && p2.n < p1.n) { fprintf(stderr, "k4align: fewer PE2 than PE1 reads\n"); return 3; }
-  const int64_t n = (int64_t)p1.n;
+  // -S i/N: reads (pairs) are independent units; every process parses the whole input -- that is cheap on
+  // the device -- and keeps its contiguous slice, so that the shards' SAM files merge back into load order (k4merge)
+  const int64_t r0 = (int64_t)p1.n * o.shard / o.n_shards, r1 = (int64_t)p1.n * (o.shard + 1) / o.n_shards;
+  for (Parsed* q : {&p1, &p2}) {
+    if (!q->d_offs) continue;
+    q->d_offs = (uint8_t*)q->d_offs + 8 * r0; q->d_lens = (uint8_t*)q->d_lens + 4 * r0;
+    q->d_noff = (uint8_t*)q->d_noff + 8 * r0; q->d_nlen = (uint8_t*)q->d_nlen + 4 * r0;
+  }
+  const int64_t n = r1 - r0;
   const int64_t n_reads = pe ? 2 * n : n;
   uint64_t n_under = 0, n_over = 0;
   uint32_t max_len = 0;
@@ -268,8 +280,8 @@ int main(int argc, char** argv) {
   fprintf(stderr, "k4align: %llu alignments written to %s; index %.2fs, read files %.2fs, upload+parse %.2fs, align+format %.2fs, write %.2fs\n",
           (unsigned long long)stt.n_lines, o.out.c_str(), secs(t0, t_open), secs(t_open, t_read), secs(t_read, t_parse),
           secs(t_parse, t1c), secs(t1c, t2c));
-  for (void* q : {d_reads, d_offs, d_lens, d_rr, d_hits, d_pe, d_sam, p1.d_text, p1.d_offs, p1.d_lens, p1.d_noff, p1.d_nlen,
-                  p2.d_text, p2.d_offs, p2.d_lens, p2.d_noff, p2.d_nlen})
+  for (void* q : {d_reads, d_offs, d_lens, d_rr, d_hits, d_pe, d_sam, a1.d_text, a1.d_offs, a1.d_lens, a1.d_noff, a1.d_nlen,
+                  a2.d_text, a2.d_offs, a2.d_lens, a2.d_noff, a2.d_nlen})
     k4_free_device(q);
   k4_close(ix);
   return 0;

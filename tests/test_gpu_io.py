@@ -259,3 +259,39 @@ def test_k4align_edge_inputs(golden_dir, tmp_path):
     assert len(recs) == 1 and recs[0].split("\t")[:4] == ["q1", "0", "chr2", "1001"]
     p, _ = run(b">a\n" + seq + b"\n", "-r2")
     assert p.returncode != 0 and "not supported" in p.stderr
+
+
+@pytest.mark.parametrize("case,n_shards", [("se_s2", 3), ("pe_u1", 2)])
+def test_k4align_shards_merge_to_the_single_run(golden_dir, tmp_path, case, n_shards):
+    """`k4align -S i/N` (one process per GPU, each its slice of the reads) + `k4merge` == one `k4align` run"""
+    import json
+    import lzma
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(golden_dir, "sam_cases.json")))
+
+    def unxz(name):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        return dst
+
+    files = ["-i", unxz("sam_%s.fa.xz" % case)] if case.startswith("se_") else \
+        ["-i", unxz("sam_%s_1.fa.xz" % case), "-u", unxz("sam_%s_2.fa.xz" % case)]
+    base = [os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx")] + cases[case]["args"] + files
+    shards = []
+    for k in range(n_shards):
+        o = str(tmp_path / ("s%d.sam" % k))
+        p = subprocess.run(base + ["-o", o, "-S", "%d/%d" % (k, n_shards)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        shards.append(o)
+    merged = str(tmp_path / "m.sam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4merge"), merged] + shards, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    got = [l for l in open(merged).read().splitlines() if not l.startswith("@PG")]
+    want = [l for l in lzma.open(os.path.join(golden_dir, "sam_%s.sam.xz" % case)).read().decode().splitlines() if not l.startswith("@PG")]
+    assert [l for l in got if l.startswith("@")] == [l for l in want if l.startswith("@")]
+    assert sorted(got) == sorted(want)
+    order = {l.split("\tSN:")[1].split("\t")[0]: i for i, l in enumerate(h for h in want if h.startswith("@SQ"))}
+    keys = [(order[l.split("\t")[2]], int(l.split("\t")[3])) for l in got if not l.startswith("@")]
+    assert keys == sorted(keys)
