@@ -257,12 +257,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
-                    help="c2 (default, the BASELINE metric's configuration): 50 M x 100 bp SE vs 3 Gbp, -s2; "
+    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c5"], default="c2",
+                    help="c1: 10 k x 100 bp SE vs 5 x 1 Mbp, -s0 (the reference's own CPU-runnable case; launch-bound here); "
+                         "c2 (default, the BASELINE metric's configuration): 50 M x 100 bp SE vs 3 Gbp, -s2; "
                          "c3: 50 M pairs 2x150 bp vs 3 Gbp, -s2 -U2 -d200 -D600; c5: 2x150 bp pairs vs 15 Gbp, -s3 -U2 "
                          "(40 M pairs per step: the 200 M of BASELINE config 5 do not fit one GPU next to the 162 GB index)")
     ap.add_argument("--chroms", type=int, default=None)
-    ap.add_argument("--chrom-mbp", type=float, default=125.0)
+    ap.add_argument("--chrom-mbp", type=float, default=None)
     ap.add_argument("--reads", type=int, default=None, help="reads (SE) or pairs (PE) per GPU per step")
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--max-subs", type=int, default=None)
@@ -273,13 +274,15 @@ def main():
     ap.add_argument("--ref-sample", type=int, default=8_000_000,
                     help="reads given to the real reference binary (oracle/_ref/ngskit4b) when it is present (0 = skip)")
     args = ap.parse_args()
-    wl = {"c2": (24, 50_000_000, 100, 2, False), "c3": (24, 50_000_000, 150, 2, True), "c5": (120, 40_000_000, 150, 3, True)}[args.workload]
+    wl = {"c1": (5, 10_000, 100, 0, False, 1.0), "c2": (24, 50_000_000, 100, 2, False, 125.0),
+          "c3": (24, 50_000_000, 150, 2, True, 125.0), "c5": (120, 40_000_000, 150, 3, True, 125.0)}[args.workload]
     args.chroms = wl[0] if args.chroms is None else args.chroms
     args.reads = wl[1] if args.reads is None else args.reads
     args.read_len = wl[2] if args.read_len is None else args.read_len
     args.max_subs = wl[3] if args.max_subs is None else args.max_subs
     pe = wl[4]
-    std_cfg = ((args.chroms, args.reads, args.read_len, args.max_subs) == wl[:4] and args.chrom_mbp == 125.0 and args.n_frac == 0
+    args.chrom_mbp = wl[5] if args.chrom_mbp is None else args.chrom_mbp
+    std_cfg = ((args.chroms, args.reads, args.read_len, args.max_subs) == wl[:4] and args.chrom_mbp == wl[5] and args.n_frac == 0
                and args.repeats == 0)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -482,7 +485,7 @@ def main():
         del seq_h, sa_h
         # the reference itself, when its binary travelled with the snapshot: that number becomes cpu_baseline, the
         # port's stays beside it (and is what the read-for-read comparison above ran against)
-        if args.ref_sample > 0:
+        if args.ref_sample > 0 and n_reads >= 1_000_000:  # (kit4b's fixed 5 s start-up sleep would swamp a small sample)
             Sr = min(args.ref_sample, n_reads) & ~1
             ref = time_reference(ix, reads, pe, L, args.max_subs, cores, Sr, dev, lambda *a: log(rank, *a))
             if ref is not None:
