@@ -158,6 +158,7 @@ int k4_get_ident(const k4_index* ix, const char* name);   /* <- CSfxArray::GetId
 int k4_set_max_iter(k4_index* ix, int max_iter);          /* <- CSfxArray::SetMaxIter, SfxArray.h:556 */
 int k4_get_seq(const k4_index* ix, uint32_t entry_id, uint32_t loci, uint8_t* out, uint32_t len); /* <- GetSeq, SfxArray.h:996 */
 int k4_write_sfx(const k4_index* ix, const char* sfx_path); /* <- CSfxArray::Finalise/Flush2Disk, SfxArray.cpp:892 */
+int k4_set_description(k4_index* ix, const char* description, const char* title); /* <- SetDescription / SetTitle, SfxArray.h:552-553 */
 int k4_get_sfx_header(const k4_index* ix, void* out_1224);  /* <- CSfxArray::GetSfxHeader: tsSfxHeaderV3, SfxArray.h:194-207 */
 
 /* ---- suffix-array construction on the GPU -----------------------------------
@@ -248,7 +249,8 @@ int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, const k4_pe_
 /* ---- read ingest and SAM emit on the device ----------------------------------------------
  * k4_parse_fastx_dev   <- CKAligner::LoadRawReads (KAligner.cpp:11648-12421) over CFasta: FASTA ('>', sequence over any
  *                         number of lines) or FASTQ ('@', four lines per record) text resident in HBM -> etSeqBase reads
- *                         (a/c/g/t/u either case -> 0..3, any other non-blank -> 4), offsets, lengths, and the span of
+ *                         (a/c/g/t/u either case -> 0..3, '-' -> 6, other letters -> 4, anything else sloughed:
+ *                         CFasta::ReadSequence / Ascii2Sense, Fasta.cpp:1172,1657), offsets, lengths, and the span of
  *                         each descriptor's first token (<= 127 bytes).  A chunk that is not the last one may end inside a
  *                         record: info->consumed tells how many bytes were used; resubmit the rest in front of the next
  *                         chunk.  The bases go to d_reads[reads_base ...) (room for text_bytes + 16 bytes), offs are

@@ -101,7 +101,7 @@ ABI_SYMBOLS = [
     "k4_get_kernel_times", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
     "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
-    "k4_get_sfx_header",
+    "k4_get_sfx_header", "k4_set_description",
 ]
 
 
@@ -186,6 +186,20 @@ def _flatten(reads):
     return cat, offs, lens
 
 
+def gen_hash16(name):
+    """CUtility::GenHash16 (libkit4b/Utility.cpp:402-420): the 16-bit hash of the lower-cased entry name"""
+    if not name:
+        return 0
+    h = 19937
+    for ch in name.lower():
+        h = ((h ^ ch) * 3119) & 0xFFFFFFFF
+        if h & 0x80000000:  # int arithmetic in the reference: the shift below is arithmetic
+            h -= 1 << 32
+        h ^= h >> 13
+        h &= 0xFFFF
+    return h or 19937
+
+
 def make_entries(names, lens):
     """tsSfxEntry table for sequences concatenated with one EOS after each (CSfxArray::AddEntry, SfxArray.cpp:1735-1750)."""
     arr = (Entry * len(names))()
@@ -194,6 +208,7 @@ def make_entries(names, lens):
         arr[i].entry_id = i + 1
         arr[i].fblock_id = 1
         arr[i].name = nm.encode() if isinstance(nm, str) else nm
+        arr[i].name_hash = gen_hash16(arr[i].name)
         arr[i].seq_len = int(ln)
         arr[i].start_ofs = ofs
         arr[i].end_ofs = ofs + int(ln) - 1

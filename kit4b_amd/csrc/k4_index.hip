@@ -664,8 +664,17 @@ static void make_header(const k4_index* ix, uint8_t* hdr) {
   memcpy(hdr + 20, &entries_ofs, 8); memcpy(hdr + 28, &entries_size, 4); memcpy(hdr + 32, &nblocks, 4);
   memcpy(hdr + 36, &block_size, 8); memcpy(hdr + 44, &block_ofs, 8);
   strncpy((char*)hdr + 52, ix->dataset.c_str(), 80);
-  strncpy((char*)hdr + 133, "k4sfx MI355X index", 1023);
-  strncpy((char*)hdr + 1157, "k4sfx", 63);
+  strncpy((char*)hdr + 133, ix->description.empty() ? "k4sfx MI355X index" : ix->description.c_str(), 1023);
+  strncpy((char*)hdr + 1157, ix->title.empty() ? "k4sfx" : ix->title.c_str(), 63);
+}
+
+// CSfxArray::SetDescription / SetTitle (SfxArray.h:552-553): the free-text header fields k4_write_sfx will write
+extern "C" int k4_set_description(k4_index* ix, const char* description, const char* title) {
+  if (!ix) return K4_ERR_PARAMS;
+  if (description) ix->description = description;
+  if (title) ix->title = title;
+  ix->raw_header.clear();
+  return K4_OK;
 }
 
 // CSfxArray::GetSfxHeader (SfxArray.h:551): the 1224-byte file header -- as read for an index opened from a file

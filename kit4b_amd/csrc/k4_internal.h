@@ -96,6 +96,7 @@ struct k4_index {
   uint64_t* counters = nullptr; // device k4_counters
   std::vector<k4_entry> entries;
   std::string dataset;
+  std::string description, title;  // header text for k4_write_sfx (k4_set_description)
   std::vector<uint8_t> raw_header;  // the file's tsSfxHeaderV3 when the index was opened from a .sfx
   uint64_t tot_seqs_len = 0;
   uint64_t device_bytes = 0;

@@ -2,7 +2,7 @@
 //
 //   k4_parse_fastx_dev   FASTA / FASTQ text in HBM -> etSeqBase reads, offsets, lengths, descriptor spans
 //                        <- CKAligner::LoadRawReads  ngskit4b/KAligner.cpp:11648-12421 (descriptor = first token of the
-//                           header line, bases a/c/g/t/u in either case -> 0..3, anything else that is not white space -> N)
+//                           header line, bases a/c/g/t/u in either case -> 0..3, '-' -> InDel, other letters -> N, anything else sloughed)
 //   k4_format_sam_dev    alignment records in HBM -> coordinate-sorted SAM text in HBM
 //                        <- CKAligner::WriteBAMReadHits :5718-5914, ReportBAMread :5957-6320, SortHitMatch :10969,
 //                           CSAMfile::AddAlignment libkit4b/SAMfile.cpp:2194-2377
@@ -22,7 +22,11 @@ struct IsNewline {
 };
 
 K4_DEV bool k4d_is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+// CFasta::ReadSequence (libkit4b/Fasta.cpp:1172-1173) keeps letters and '-' of a sequence line and sloughs everything else;
+// Ascii2Sense (:1657-1703) maps a/c/g/t/u in either case to 0..3, '-' to eBaseInDel (6) and any other letter to eBaseN
+K4_DEV bool k4d_seq_skip(uint8_t c) { return !(((c | 0x20) >= 'a' && (c | 0x20) <= 'z') || c == '-'); }
 K4_DEV uint8_t k4d_base_code(uint8_t c) {
+  if (c == '-') return 6;
   switch (c | 0x20) {  // lower-case the letters
     case 'a': return 0;
     case 'c': return 1;
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(64) k4k_fastx_count(const uint8_t* __restrict_
     const uint32_t span = seq_span[r];
     uint32_t n = 0;
     for (uint32_t q = 0; q < span; q += 64) {
-      const bool keep = q + lane < span && !k4d_is_space(src[q + lane]);
+      const bool keep = q + lane < span && !k4d_seq_skip(src[q + lane]);
       n += (uint32_t)__popcll(__ballot(keep));
     }
     if (lane == 0) lens[r] = n;
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(64) k4k_fastx_encode(const uint8_t* __restrict
     uint32_t done = 0;
     for (uint32_t q = 0; q < span; q += 64) {
       const uint8_t c = q + lane < span ? src[q + lane] : (uint8_t)' ';
-      const bool keep = !k4d_is_space(c);
+      const bool keep = !k4d_seq_skip(c);
       const unsigned long long m = __ballot(keep);
       if (keep) dst[done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k4d_base_code(c);
       done += (uint32_t)__popcll(m);

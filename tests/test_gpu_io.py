@@ -21,7 +21,8 @@ def host_parse(text):
         lines.pop()
     recs = []
     fastq = text[:1] == b"@"
-    enc = lambda s: [CODE.get(c, 4) for c in s if c not in b" \t\n\v\f\r"]  # noqa: E731
+    # CFasta: letters and '-' are kept ('-' -> eBaseInDel 6, letters other than acgtu -> N), everything else is sloughed
+    enc = lambda s: [6 if c == 45 else CODE.get(c, 4) for c in s if chr(c).isalpha() or c == 45]  # noqa: E731
     i = 0
     if fastq:
         while i + 3 < len(lines) or (i + 3 == len(lines) - 0 and False):
@@ -56,14 +57,14 @@ def _check(ix, text, chunk=None):
     return p
 
 
-PROBS = np.array([.2, .2, .2, .2, .03, .03, .03, .03, .01, .01, .01, .01, .01, .005, .01, .005])
+PROBS = np.array([.2, .2, .2, .2, .03, .03, .03, .03, .01, .01, .01, .01, .01, .005, .01, .005, .005, .005, .005, .005])
 PROBS = PROBS / PROBS.sum()
 
 
 def _fasta(rng, n, wrap, crlf, trailing_nl=True):
     eol = b"\r\n" if crlf else b"\n"
     out = []
-    alphabet = b"ACGTacgtNnRYKMU-"
+    alphabet = b"ACGTacgtNnRYKMU-*.4 "
     for i in range(n):
         L = int(rng.integers(0, 400))
         seq = bytes(rng.choice(list(alphabet), size=L, p=PROBS).tolist())
@@ -295,3 +296,57 @@ def test_k4align_shards_merge_to_the_single_run(golden_dir, tmp_path, case, n_sh
     order = {l.split("\tSN:")[1].split("\t")[0]: i for i, l in enumerate(h for h in want if h.startswith("@SQ"))}
     keys = [(order[l.split("\t")[2]], int(l.split("\t")[3])) for l in got if not l.startswith("@")]
     assert keys == sorted(keys)
+
+
+def test_k4index_writes_the_reference_index(tmp_path):
+    """`k4index` (FASTA -> .sfx with the suffix sort on the GPU) against `ngskit4b index` on the same FASTA: soft-masked
+    and wrapped sequences, IUPAC letters, a run of N long enough for kit4b's every-13th-N rule (rand(), same seed),
+    a sequence under the minimum length.  Everything behind the header text must be byte-identical: block header,
+    sequence, suffix array, entries."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ngs = os.path.join(root, "oracle", "_ref", "ngskit4b")
+    if not os.path.exists(ngs):
+        pytest.skip("oracle/_ref/ngskit4b not built")
+    rng = np.random.default_rng(314)
+    fa = tmp_path / "g.fa"
+    with open(fa, "w") as f:
+        for c, ln in enumerate([30000, 45000, 200, 20, 25000]):
+            s = np.array(list("ACGT"))[rng.integers(0, 4, ln)]
+            if ln > 1000:
+                s[5000:5400] = np.char.lower(s[5000:5400])           # soft masked
+                s[7000:7012] = "N"                                    # short N run: untouched
+                s[9000:9150] = "N"                                    # long N run: every 13th mutated
+                s[12000:12003] = ["R", "y", "-"]
+                s[15000:15600] = s[2000:2600]                          # a repeat
+            seq = "".join(s)
+            f.write(">chr%d some description\n" % (c + 1))
+            for i in range(0, len(seq), 70):
+                f.write(seq[i:i + 70] + ("\r\n" if c == 1 else "\n"))
+    ref_sfx, k4_sfx = str(tmp_path / "ref.sfx"), str(tmp_path / "k4.sfx")
+    p = subprocess.run([ngs, "index", "-i", str(fa), "-o", ref_sfx, "-r", "gtest", "-T", "4", "-F", str(tmp_path / "log")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    q = subprocess.run([os.path.join(root, "kit4b_amd", "k4index"), "-i", str(fa), "-o", k4_sfx, "-r", "gtest"],
+                       capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stderr
+    assert "1 sequences not accepted" in q.stderr
+    a, b = open(ref_sfx, "rb").read(), open(k4_sfx, "rb").read()
+    assert len(a) == len(b)
+    assert a[:52] == b[:52]                                   # magic, version, attributes, lengths, offsets
+    assert a[52:52 + 81].split(b"\0")[0] == b[52:52 + 81].split(b"\0")[0] == b"gtest"
+    # block header 20 B, then n sequence bytes, then n 4-byte suffix elements, then the entries
+    n = int.from_bytes(a[1224 + 8:1224 + 16], "little")
+    s0 = 1224 + 20
+    assert a[1224:s0 + n] == b[1224:s0 + n]                  # block header + sequence (incl. the mutated Ns: same rand())
+    assert a[s0 + 5 * n:] == b[s0 + 5 * n:]                  # entries block
+    seq = np.frombuffer(a[s0:s0 + n], dtype=np.uint8)
+    sa_a = np.frombuffer(a[s0 + n:s0 + 5 * n], dtype="<u4")
+    sa_b = np.frombuffer(b[s0 + n:s0 + 5 * n], dtype="<u4")
+    d = np.nonzero(sa_a != sa_b)[0]
+    # the two suffix arrays may differ only in the order of suffixes that compare equal: the comparison stops behind the
+    # first EOS (SfxArray.cpp:9779-9834), so the separator-only suffixes tie -- the reference's qsort leaves them in any order
+    assert (seq[sa_a[d]] == 7).all() and (seq[sa_b[d]] == 7).all()
+    assert sorted(sa_a[d].tolist()) == sorted(sa_b[d].tolist())
+    assert len(d) <= 5
