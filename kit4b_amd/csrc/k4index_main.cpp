@@ -97,44 +97,65 @@ bool add_file(const std::string& path, Builder& b) {
     else if (have) b.n_under++;  // (a descriptor with no sequence: under any minimum length)
     cur.clear();
   };
-  for (size_t i = 0; i < t.size(); i++) {
-    const uint8_t c = t[i];
-    if (in_descr) {
-      if (c == '\n' || c == '\r') {
-        in_descr = false;
-        size_t p = 0;
-        while (p < descr.size() && isspace((unsigned char)descr[p])) p++;
-        size_t e = p;
-        while (e < descr.size() && !isspace((unsigned char)descr[e])) e++;
-        seq_id++;
-        name = e > p ? descr.substr(p, e - p) : path + "." + std::to_string(++seq_id);  // kit4bax.cpp:540-541
-        have = true;
-      } else if (!(descr.empty() && (c == ' ' || c == '\t')))
-        descr.push_back((char)c);
+  // 256-entry translation of a sequence byte: 0..6 = code, 0xFF = sloughed
+  static uint8_t lut[256];
+  static bool lut_ready = false;
+  if (!lut_ready) {
+    for (int c = 0; c < 256; c++) lut[c] = (isalpha(c) || c == '-') ? 4 : 0xFF;
+    lut['a'] = lut['A'] = 0; lut['c'] = lut['C'] = 1; lut['g'] = lut['G'] = 2;
+    lut['t'] = lut['T'] = lut['u'] = lut['U'] = 3; lut['-'] = 6;
+    lut_ready = true;
+  }
+  auto end_descr = [&]() {
+    in_descr = false;
+    size_t p = 0;
+    while (p < descr.size() && isspace((unsigned char)descr[p])) p++;
+    size_t e = p;
+    while (e < descr.size() && !isspace((unsigned char)descr[e])) e++;
+    seq_id++;
+    name = e > p ? descr.substr(p, e - p) : path + "." + std::to_string(++seq_id);  // kit4bax.cpp:540-541
+    have = true;
+  };
+  const uint8_t* base = t.data();
+  const size_t T = t.size();
+  size_t i = 0;
+  while (i < T) {
+    if (in_descr) {  // to the end of the line
+      const uint8_t c = base[i++];
+      if (c == '\n' || c == '\r') end_descr();
+      else if (!(descr.empty() && (c == ' ' || c == '\t'))) descr.push_back((char)c);
       continue;
     }
-    if (c == '>') {
+    // a stretch of sequence text: up to the next '>' (wherever it stands, as CFasta takes it) or the end
+    const uint8_t* gt = (const uint8_t*)memchr(base + i, '>', T - i);
+    const size_t stop = gt ? (size_t)(gt - base) : T;
+    if (stop > i) {
+      const size_t old = cur.size();
+      cur.resize(old + (stop - i));
+      uint8_t* dst = cur.data() + old;
+      size_t k = 0;
+      for (size_t q = i; q < stop; q++) {
+        const uint8_t v = lut[base[q]];
+        dst[k] = v;
+        k += v != 0xFF;
+      }
+      cur.resize(old + k);
+      if (k && !have) {  // sequence without a descriptor, kit4bax.cpp:549-556
+        seq_id++;
+        name = path + "." + std::to_string(seq_id);
+        have = true;
+      }
+      i = stop;
+    }
+    if (gt) {
       flush();
       have = false;
       in_descr = true;
       descr.clear();
-      continue;
-    }
-    if (!(isalpha(c) || c == '-')) continue;
-    if (!have) {  // sequence without a descriptor, kit4bax.cpp:549-556
-      seq_id++;
-      name = path + "." + std::to_string(seq_id);
-      have = true;
-    }
-    switch (c) {
-      case 'a': case 'A': cur.push_back(0); break;
-      case 'c': case 'C': cur.push_back(1); break;
-      case 'g': case 'G': cur.push_back(2); break;
-      case 't': case 'T': case 'u': case 'U': cur.push_back(3); break;
-      case '-': cur.push_back(6); break;
-      default: cur.push_back(4);
+      i++;
     }
   }
+  if (in_descr) end_descr();
   flush();
   return true;
 }
