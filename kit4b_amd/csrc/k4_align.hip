@@ -1550,10 +1550,12 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
   const int slow_len = std::min(std::max(max_len, 1), K4_MAX_READ_LEN);
   const size_t slow_lds = (size_t)(a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES : 0) * 8 + (size_t)(slow_len / 32 + 2) * 8 +
                           (size_t)slow_len + 64;
-  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(K4_SLOW_WAVES), dim3(64), slow_lds, st, a, (uint32_t)K4_SLOW_WAVES, 0, small_base,
-                     (uint32_t)K4_SMALL_HASH, gen_small, slow_len);
-  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(K4_HUGE_WAVES), dim3(64), slow_lds, st, a, (uint32_t)K4_HUGE_WAVES, 1, big_base,
-                     w.slow_hash_cap, gen_big, slow_len);
+  // (no more waves than reads: a batch of one -- the facade's AlignReads -- should not pay for 8192 idle blocks)
+  const uint32_t sw = (uint32_t)std::min<int64_t>(K4_SLOW_WAVES, std::max<int64_t>(a.n_reads, 1));
+  const uint32_t hw = (uint32_t)std::min<int64_t>(K4_HUGE_WAVES, std::max<int64_t>(a.n_reads, 1));
+  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(sw), dim3(64), slow_lds, st, a, sw, 0, small_base, (uint32_t)K4_SMALL_HASH, gen_small,
+                     slow_len);
+  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(hw), dim3(64), slow_lds, st, a, hw, 1, big_base, w.slow_hash_cap, gen_big, slow_len);
   K4_HIP(ix, hipGetLastError());
   return K4_OK;
 }
@@ -1716,6 +1718,15 @@ extern "C" int k4_align_reads_batch(k4_index* ix, const k4_align_params* p, int6
   rc = k4_align_reads_batch_dev(ix, p, n, max_len, w.d_reads, w.d_offs, w.d_lens, o, o + n, o + 2 * n, o + 3 * n,
                                 w.d_hits, ix->stream);
   if (rc != K4_OK) return rc;
+  if (n <= 4096) {  // small batch: one copy for the four result arrays (they are contiguous on the device), scattered here
+    int32_t tmp[4 * 4096];
+    K4_HIP(ix, hipMemcpyAsync(tmp, o, (size_t)n * 16, hipMemcpyDeviceToHost, ix->stream));
+    K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
+    K4_HIP(ix, hipStreamSynchronize(ix->stream));
+    memcpy(rslt, tmp, (size_t)n * 4); memcpy(inst, tmp + n, (size_t)n * 4);
+    memcpy(low, tmp + 2 * n, (size_t)n * 4); memcpy(nxt, tmp + 3 * n, (size_t)n * 4);
+    return K4_OK;
+  }
   K4_HIP(ix, hipMemcpyAsync(rslt, o, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(inst, o + n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(low, o + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
