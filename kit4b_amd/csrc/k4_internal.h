@@ -109,6 +109,9 @@ struct k4_index {
   uint32_t* pe_ctl = nullptr;
   int64_t pe_cap_pairs = 0;
   int32_t pe_cap_hits = 0;
+  // staging of k4_mate_rescue_batch (grow-only)
+  void *rs_tasks = nullptr, *rs_reads = nullptr, *rs_res = nullptr, *rs_hits = nullptr;
+  size_t rs_cap_tasks = 0, rs_cap_reads = 0;
   hipStream_t stream = nullptr; // internal stream for the host-pointer entry points
   bool timing = false;          // bracket k4k_align_fast with events
   std::vector<hipEvent_t> ev0, ev1;

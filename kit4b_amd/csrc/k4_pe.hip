@@ -109,22 +109,28 @@ extern "C" int k4_mate_rescue_batch(k4_index* ix, int64_t n, const k4_rescue_tas
   for (int64_t i = 0; i < n; i++)
     if (tasks[i].read_off + tasks[i].read_len > reads_bytes) return k4_fail(ix, K4_ERR_PARAMS, "rescue task %lld outside the read buffer", (long long)i);
   K4_HIP(ix, hipSetDevice(ix->device));
-  k4_rescue_task* d_t = nullptr;
-  uint8_t* d_r = nullptr;
-  int32_t* d_res = nullptr;
-  k4_hit* d_h = nullptr;
-  auto cleanup = [&]() {
-    for (void* p : {(void*)d_t, (void*)d_r, (void*)d_res, (void*)d_h})
+  // staging buffers live with the index and only grow (the facade's AlignPairedRead comes here once per orphan read)
+  if ((size_t)n > ix->rs_cap_tasks) {
+    for (void* p : {(void*)ix->rs_tasks, (void*)ix->rs_res, (void*)ix->rs_hits})
       if (p) hipFree(p);
-  };
-  int rc;
-  if ((rc = k4_check_hip(ix, hipMalloc(&d_t, (size_t)n * sizeof(k4_rescue_task)), "rescue alloc")) != K4_OK ||
-      (rc = k4_check_hip(ix, hipMalloc(&d_r, reads_bytes + 16), "rescue alloc")) != K4_OK ||
-      (rc = k4_check_hip(ix, hipMalloc(&d_res, (size_t)n * 4), "rescue alloc")) != K4_OK ||
-      (rc = k4_check_hip(ix, hipMalloc(&d_h, (size_t)n * sizeof(k4_hit)), "rescue alloc")) != K4_OK) {
-    cleanup();
-    return rc;
+    ix->rs_tasks = nullptr; ix->rs_res = nullptr; ix->rs_hits = nullptr; ix->rs_cap_tasks = 0;
+    const size_t cap = std::max<size_t>((size_t)n, 256);
+    K4_HIP(ix, hipMalloc(&ix->rs_tasks, cap * sizeof(k4_rescue_task)));
+    K4_HIP(ix, hipMalloc(&ix->rs_res, cap * 4));
+    K4_HIP(ix, hipMalloc(&ix->rs_hits, cap * sizeof(k4_hit)));
+    ix->rs_cap_tasks = cap;
   }
+  if (reads_bytes + 16 > ix->rs_cap_reads) {
+    if (ix->rs_reads) hipFree(ix->rs_reads);
+    ix->rs_reads = nullptr; ix->rs_cap_reads = 0;
+    const size_t cap = std::max<size_t>(reads_bytes + 16, 1 << 16);
+    K4_HIP(ix, hipMalloc(&ix->rs_reads, cap));
+    ix->rs_cap_reads = cap;
+  }
+  k4_rescue_task* d_t = (k4_rescue_task*)ix->rs_tasks;
+  uint8_t* d_r = (uint8_t*)ix->rs_reads;
+  int32_t* d_res = (int32_t*)ix->rs_res;
+  k4_hit* d_h = (k4_hit*)ix->rs_hits;
   hipStream_t st = ix->stream;
   hipMemcpyAsync(d_t, tasks, (size_t)n * sizeof(k4_rescue_task), hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_r, reads, reads_bytes, hipMemcpyHostToDevice, st);
@@ -132,8 +138,7 @@ extern "C" int k4_mate_rescue_batch(k4_index* ix, int64_t n, const k4_rescue_tas
   hipLaunchKernelGGL(k4k_mate_rescue, dim3(grid), dim3(64), 0, st, ix->d, d_t, d_r, n, d_res, d_h);
   hipMemcpyAsync(rslt, d_res, (size_t)n * 4, hipMemcpyDeviceToHost, st);
   hipMemcpyAsync(hits, d_h, (size_t)n * sizeof(k4_hit), hipMemcpyDeviceToHost, st);
-  rc = k4_check_hip(ix, hipStreamSynchronize(st), "mate rescue");
-  cleanup();
+  int rc = k4_check_hip(ix, hipStreamSynchronize(st), "mate rescue");
   if (rc != K4_OK) return rc;
   for (int64_t i = 0; i < n; i++)
     if (rslt[i] == K4_ERR_UNSUPPORTED)
