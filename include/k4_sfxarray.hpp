@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -77,7 +78,77 @@ class CSfxArray {
   int m_MaxIter;
   std::deque<std::string> m_Errs;
   std::mutex m_Mtx;  // CKAligner calls AlignReads / AlignPairedRead from many threads on one object; an
-                     // index handle runs one batch at a time, so the single-read calls are serialised here
+                     // index handle runs one batch at a time: whoever talks to the device holds this
+  // AlignReads calls that arrive while a batch is on the device are collected and go out together as the next batch: the
+  // first caller to find no batch in flight becomes the leader, runs the pending requests (grouped by parameter set) and
+  // wakes their owners; with T caller threads the device sees batches of up to T reads instead of T batches of one.
+  struct Req {
+    k4_align_params p;
+    const etSeqBase* probe;
+    uint32_t len;
+    int32_t rslt, inst, low, nxt, rc;
+    std::vector<k4_hit> hits;
+    bool done;
+  };
+  std::mutex m_QMtx;
+  std::condition_variable m_QCv;
+  std::vector<Req*> m_Pending;
+  bool m_LeaderActive = false;
+
+  void RunGroup(std::vector<Req*>& g) {  // same parameters: one k4_align_reads_batch
+    const size_t n = g.size();
+    std::vector<uint8_t> cat;
+    std::vector<uint64_t> offs(n);
+    std::vector<uint32_t> lens(n);
+    for (size_t i = 0; i < n; i++) {
+      offs[i] = cat.size();
+      lens[i] = g[i]->len;
+      cat.insert(cat.end(), g[i]->probe, g[i]->probe + g[i]->len);
+    }
+    cat.resize(cat.size() + 16);
+    const int mh = g[0]->p.max_hits;
+    std::vector<int32_t> r(4 * n);
+    std::vector<k4_hit> h(n * (size_t)mh);
+    int rc;
+    {
+      std::lock_guard<std::mutex> dev(m_Mtx);
+      rc = k4_align_reads_batch(m_pIdx, &g[0]->p, (int64_t)n, cat.data(), offs.data(), lens.data(), r.data(), r.data() + n,
+                                r.data() + 2 * n, r.data() + 3 * n, h.data());
+      if (rc != K4_OK) Fail(rc);
+    }
+    for (size_t i = 0; i < n; i++) {
+      Req* q = g[i];
+      q->rc = rc; q->rslt = r[i]; q->inst = r[n + i]; q->low = r[2 * n + i]; q->nxt = r[3 * n + i];
+      q->hits.assign(h.begin() + (ptrdiff_t)(i * mh), h.begin() + (ptrdiff_t)((i + 1) * mh));
+    }
+  }
+  void Submit(Req& rq) {
+    std::unique_lock<std::mutex> lk(m_QMtx);
+    m_Pending.push_back(&rq);
+    while (!rq.done) {
+      if (m_LeaderActive) {  // a batch is on the device: this request goes with the next one
+        m_QCv.wait(lk);
+        continue;
+      }
+      m_LeaderActive = true;  // lead one batch: everything pending right now, this request included
+      std::vector<Req*> batch;
+      batch.swap(m_Pending);
+      lk.unlock();
+      std::vector<char> taken(batch.size(), 0);
+      for (size_t i = 0; i < batch.size(); i++) {
+        if (taken[i]) continue;
+        std::vector<Req*> g;
+        for (size_t j = i; j < batch.size(); j++)
+          if (!taken[j] && std::memcmp(&batch[j]->p, &batch[i]->p, sizeof(k4_align_params)) == 0) { g.push_back(batch[j]); taken[j] = 1; }
+        RunGroup(g);
+      }
+      lk.lock();
+      for (Req* q : batch) q->done = true;
+      m_LeaderActive = false;
+      m_QCv.notify_all();
+    }
+  }
+
   std::vector<uint16_t> m_IdentFlags;  // per entry, the flags half of tsSfxEntry.fBlockID (SfxArray.cpp:2048-2079)
 
   bool LoadIdentFlags() {
@@ -234,18 +305,17 @@ class CSfxArray {
       return K4_ERR_UNSUPPORTED;
     }
     if (Align2Strand == eALSnone) return eHRnone;
-    k4_align_params p = {TotMM, CoreLen, CoreDelta, MaxNumCoreSlides, MinCoreLen, MMDelta, (int32_t)Align2Strand, MaxHits};
-    uint64_t off = 0;
-    uint32_t len = (uint32_t)ProbeLen;
-    int32_t rslt = 0, inst = 0, low = 0, nxt = 0;
-    std::vector<k4_hit> hits((size_t)MaxHits);
-    std::lock_guard<std::mutex> lock(m_Mtx);
-    int rc = k4_align_reads_batch(m_pIdx, &p, 1, pProbeSeq, &off, &len, &rslt, &inst, &low, &nxt, hits.data());
-    if (rc != K4_OK) return Fail(rc);
-    *pLowHitInstances = inst; *pLowMMCnt = low; *pNxtLowMMCnt = nxt;
-    int nvalid = (rslt >= eHRhits && rslt <= eHRHitInsts) ? (inst < MaxHits ? inst : MaxHits) : 0;
-    for (int i = 0; i < nvalid; i++) Expand(hits[(size_t)i], &pHits[i]);
-    return rslt;
+    if (ProbeLen < 1 || MaxHits < 1) return K4_ERR_PARAMS;
+    Req rq;
+    rq.p = k4_align_params{TotMM, CoreLen, CoreDelta, MaxNumCoreSlides, MinCoreLen, MMDelta, (int32_t)Align2Strand, MaxHits};
+    rq.probe = pProbeSeq; rq.len = (uint32_t)ProbeLen;
+    rq.rslt = rq.inst = rq.low = rq.nxt = 0; rq.rc = K4_OK; rq.done = false;
+    Submit(rq);  // alone: a batch of one; with other threads calling at the same time: one batch for all of them
+    if (rq.rc != K4_OK) return rq.rc;
+    *pLowHitInstances = rq.inst; *pLowMMCnt = rq.low; *pNxtLowMMCnt = rq.nxt;
+    int nvalid = (rq.rslt >= eHRhits && rq.rslt <= eHRHitInsts) ? (rq.inst < MaxHits ? rq.inst : MaxHits) : 0;
+    for (int i = 0; i < nvalid; i++) Expand(rq.hits[(size_t)i], &pHits[i]);
+    return rq.rslt;
   }
 
   // CSfxArray::LocateBestMatches, SfxArray.h:793-806 -- identical parameter list (CKAligner's -N, KAligner.cpp:9779).

@@ -2,6 +2,7 @@
 // (ngskit4b/KAligner.cpp:342-388 open, :9353-9397 block + core k-mers, :9799 AlignReads, :5785-5821 names/lengths).
 // usage: k4_facade_test index.sfx  -> prints one line per probe; the -m gpu test compares with the golden vectors.
 #include <cstdio>
+#include <thread>
 #include <vector>
 #include "k4_sfxarray.hpp"
 
@@ -66,6 +67,33 @@ int main(int argc, char** argv) {
     Rslt = pSfx->AlignPairedRead(true, true, 2, 1000, 1099, 200, 600, 5, 1, 100, 0, 0, 0, 0, Rc.data(), &Pair);
     printf("pair rslt %d chrom %u loci %llu strand %c mm %u\n", Rslt, Pair.Seg[0].ChromID, (unsigned long long)Pair.Seg[0].MatchLoci,
            Pair.Seg[0].Strand, Pair.Seg[0].Mismatches);
+  }
+  // many threads on one object, as CKAligner's workers do: the same answers as one thread, whatever the interleaving
+  {
+    const int NT = 8, NP = 60;
+    std::vector<std::vector<etSeqBase>> Probes((size_t)NT * NP, std::vector<etSeqBase>(100));
+    std::vector<int> Want((size_t)NT * NP * 3), Got((size_t)NT * NP * 3);
+    for (int q = 0; q < NT * NP; q++) {
+      pSfx->GetSeq(1 + q % 5, 300 + 37 * q, Probes[q].data(), 100);
+      for (int k = 0; k < q % 4; k++) Probes[q][5 + 29 * k] = (Probes[q][5 + 29 * k] + 1 + q % 3) % 4;
+    }
+    auto Work = [&](int From, int To, std::vector<int>& Out) {
+      tsIdentNode N2[4];
+      for (int q = From; q < To; q++) {
+        int I = 0, L = 0, X = 0;
+        tsHitLoci H[2];
+        const int ML = q % 2 ? 2 : 1, CL = q % 3 ? 33 : 25;   // (several parameter sets in flight at once)
+        int R = pSfx->AlignReads(0, 1, 0, 2, CL, CL, 8, 8, 1, eALSboth, 0, 0, &I, &L, &X, Probes[q].data(), 100, ML, H, 4, N2);
+        Out[3 * q] = R; Out[3 * q + 1] = I * 1000 + L * 10 + X; Out[3 * q + 2] = R == eHRhits ? (int)H[0].Seg[0].MatchLoci : -1;
+      }
+    };
+    Work(0, NT * NP, Want);
+    std::vector<std::thread> Th;
+    for (int t = 0; t < NT; t++) Th.emplace_back(Work, t * NP, (t + 1) * NP, std::ref(Got));
+    for (auto& t : Th) t.join();
+    int Hits = 0;
+    for (int q = 0; q < NT * NP; q++) Hits += Want[3 * q] == eHRhits;
+    printf("threads %d probes %d hits %d identical %d\n", NT, NT * NP, Hits, Want == Got ? 1 : 0);
   }
   tsSfxHeaderV3 Hdr;
   pSfx->GetSfxHeader(&Hdr);

@@ -366,6 +366,8 @@ def test_csfxarray_facade_program(k4, golden_dir):
     assert "chimeric rslt -3 msgs 1" in lines
     assert "best rslt 1 inst 1 chrom 2 loci 1200 strand + mm 1" in lines      # LocateBestMatches, same signature
     assert "pair rslt 1 chrom 2 loci 1200 strand - mm 0" in lines              # AlignPairedRead, same signature
+    th = [l for l in lines if l.startswith("threads 8 probes 480 hits ")]
+    assert th and th[0].endswith("identical 1") and int(th[0].split()[5]) > 100  # 8 threads on one object == 1 thread
     assert any(l.startswith("header sfx version ") and l.endswith(" blocks 1 dataset g1") for l in lines)  # GetSfxHeader
     assert lines[-1] == "flags 0 prev 0 now 1 solid 0"
 

@@ -38,6 +38,8 @@ seq = bench.make_genome(dev, n_chrom, chrom_len)
 n = seq.numel()
 n_rep = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 extra = sys.argv[8].split() if len(sys.argv) > 8 else []
+dropin_threads = int(sys.argv[9]) if len(sys.argv) > 9 else 0  # > 0: also run oracle/_ref/ngskit4b_k4 (the reference's
+# own front end on libk4sfx.so through the facade) with this many threads
 if n_rep:
     bench.implant_repeats(seq, n_chrom, chrom_len, n_rep, dev)
     print("implanted %d repeat copies" % n_rep, flush=True)
@@ -91,6 +93,18 @@ def body(path):
     return [h for h in hdr if not h.startswith(b"@PG")], recs
 
 
+dropin = None
+if dropin_threads > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ngskit4b_k4")):
+    di_sam, di_log = os.path.join(tmp, "dropin.sam"), os.path.join(tmp, "dropin.log")
+    t0 = time.time()
+    d = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ngskit4b_k4"), "kalign", "-I", sfx, "-o", di_sam, "-T", str(dropin_threads),
+                        "-F", di_log, "-s2"] + extra + in_args, capture_output=True)
+    t_di = time.time() - t0
+    lg = open(di_log, errors="replace").read() if os.path.exists(di_log) else ""
+    al = [ln for ln in lg.splitlines() if "Now aligning" in ln or "Alignment of" in ln]
+    print("drop-in rc", d.returncode, "wall %.1fs" % t_di, "\n".join(al), flush=True)
+    dropin = (di_sam, t_di, al)
+
 hr, rr = body(ref_sam)
 hg, rg = body(gpu_sam)
 same_hdr = hr == hg
@@ -99,6 +113,12 @@ same_set = sorted(rr) == sorted(rg)
 out = {"extra_args": extra, "repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
        "reference_sam_records": len(rr), "k4align_sam_records": len(rg), "headers_equal": same_hdr,
        "records_equal_as_multiset": same_set, "records_equal_in_order": same_order}
+if dropin:
+    hd, rd = body(dropin[0])
+    out["dropin_threads"] = dropin_threads
+    out["dropin_wall_s"] = dropin[1]
+    out["dropin_records_equal_as_multiset"] = sorted(rd) == sorted(rr) and hd == hr
+    out["dropin_align_log"] = dropin[2]
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"summary": out, "reference_log_tail": keep[-40:], "k4align_stderr": g.stderr[-3000:]},
