@@ -16,7 +16,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
+#include <map>
+#include <queue>
 #include <string>
 #include <vector>
 #include "../../include/k4sfx.h"
@@ -29,29 +32,10 @@ struct Opts {
   int min_len = 50, max_len = 500;  // cDfltMinAcceptReadLen / cDfltMaxAcceptReadLen, KAligner.h:112-113
   int ml_mode = 0, max_multi = 0;   // -r / -R (etMLMode, KAligner.h:250-258)
   bool clamp = false, best = false; // -X / -N (KAlignerCL.cpp:278-280)
+  double batch_mb = 0;              // -b <MB>: stream the input, this much text per file per batch (0: the whole input at once)
   int shard = 0, n_shards = 1;      // -S i/N: this process aligns the i-th of N contiguous slices of the reads (one process per GPU)
   int gpu = 0;
 };
-
-// whole file into memory; zlib reads plain and gzip alike (CFasta opens both, libkit4b/Fasta.cpp)
-bool slurp(const std::string& path, std::vector<uint8_t>& buf) {
-  gzFile f = gzopen(path.c_str(), "rb");
-  if (!f) return false;
-  gzbuffer(f, 1 << 20);
-  size_t used = 0;
-  buf.resize(64 << 20);
-  for (;;) {
-    if (buf.size() - used < (16u << 20)) buf.resize(buf.size() * 2);
-    const int want = (int)std::min<size_t>(buf.size() - used, 1u << 30);
-    const int got = gzread(f, buf.data() + used, (unsigned)want);
-    if (got < 0) { gzclose(f); return false; }
-    if (got == 0) break;
-    used += (size_t)got;
-  }
-  gzclose(f);
-  buf.resize(used);
-  return true;
-}
 
 struct Parsed {  // one reads file after k4_parse_fastx_dev: everything lives in HBM
   void* d_text = nullptr;
@@ -72,15 +56,17 @@ struct Parsed {  // one reads file after k4_parse_fastx_dev: everything lives in
     }                                                                     \
   } while (0)
 
-// upload the text and parse it on the device, in pieces below the 4 GiB limit of one call
-int load_reads(k4_index* ix, const std::vector<uint8_t>& text, void* d_reads, uint64_t reads_base, Parsed& P) {
-  const uint64_t T = text.size();
+// upload the text and parse it on the device, in pieces below the 4 GiB limit of one call; at most max_records records;
+// *consumed = text bytes that belonged to them (the rest is resubmitted in front of the next batch)
+int load_reads(k4_index* ix, const uint8_t* text, uint64_t T, int final_text, int64_t max_records, void* d_reads, uint64_t reads_base,
+               Parsed& P, uint64_t* consumed) {
+  *consumed = 0;
   if (T == 0) return K4_OK;
   const bool fastq = text[0] == '@';
-  const uint64_t nl = (uint64_t)std::count(text.begin(), text.end(), (uint8_t)'\n');
-  const int64_t cap = (int64_t)((nl + 1) / (fastq ? 4 : 2) + 4);
+  const uint64_t nl = (uint64_t)std::count(text, text + T, (uint8_t)'\n');
+  const int64_t cap = std::min<int64_t>((int64_t)((nl + 1) / (fastq ? 4 : 2) + 4), max_records > 0 ? max_records : INT64_MAX);
   CK(k4_alloc_device(ix, T + 16, &P.d_text));
-  CK(k4_copy_to_device(ix, P.d_text, text.data(), T));
+  CK(k4_copy_to_device(ix, P.d_text, text, T));
   CK(k4_alloc_device(ix, (uint64_t)cap * 8, &P.d_offs));
   CK(k4_alloc_device(ix, (uint64_t)cap * 4, &P.d_lens));
   CK(k4_alloc_device(ix, (uint64_t)cap * 8, &P.d_noff));
@@ -88,9 +74,9 @@ int load_reads(k4_index* ix, const std::vector<uint8_t>& text, void* d_reads, ui
   uint64_t pos = 0;
   const uint64_t piece = 3ull << 30;
   int fmt = 0;
-  while (pos < T) {
+  while (pos < T && (int64_t)P.n < cap) {
     const uint64_t len = std::min(piece, T - pos);
-    const int final_chunk = pos + len == T;
+    const int final_chunk = final_text && pos + len == T;
     k4_parse_info info;
     CK(k4_parse_fastx_dev(ix, (const uint8_t*)P.d_text + pos, len, pos, final_chunk, fmt, cap - (int64_t)P.n, d_reads,
                           reads_base + P.bases, (uint8_t*)P.d_offs + 8 * P.n, (uint8_t*)P.d_lens + 4 * P.n,
@@ -102,15 +88,46 @@ int load_reads(k4_index* ix, const std::vector<uint8_t>& text, void* d_reads, ui
     P.max_len = std::max(P.max_len, info.max_len);
     pos += info.consumed;
   }
+  *consumed = pos;
   return K4_OK;
 }
+void free_parsed(Parsed& P) {
+  for (void* q : {P.d_text, P.d_offs, P.d_lens, P.d_noff, P.d_nlen}) k4_free_device(q);
+  P = Parsed();
+}
+
+// a reads file read in portions: buf holds the text not yet consumed
+struct Stream {
+  gzFile f = nullptr;
+  std::vector<uint8_t> buf;
+  bool eof = false;
+  bool open(const std::string& path) {
+    f = gzopen(path.c_str(), "rb");
+    if (f) gzbuffer(f, 1 << 20);
+    return f != nullptr;
+  }
+  bool fill(uint64_t want) {  // until buf holds `want` bytes or the file ends
+    while (!eof && buf.size() < want) {
+      const size_t old = buf.size();
+      const size_t step = (size_t)std::min<uint64_t>(std::max<uint64_t>(want - old, 1 << 20), 256u << 20);
+      buf.resize(old + step);
+      const int got = gzread(f, buf.data() + old, (unsigned)step);
+      if (got < 0) return false;
+      buf.resize(old + (size_t)got);
+      if (got == 0) eof = true;
+    }
+    return true;
+  }
+  void drop(uint64_t n) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)std::min<uint64_t>(n, buf.size())); }
+  void close() { if (f) gzclose(f); f = nullptr; }
+};
 
 const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"};
 
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-u mates] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0|1|5] [-R maxmulti=5] [-X] [-N] [-S i/N] [-g gpu=0]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0|1|5] [-R maxmulti=5] [-X] [-N] [-S i/N] [-b MB per batch] [-g gpu=0]\n");
 }
 
 }  // namespace
@@ -142,7 +159,7 @@ int main(int argc, char** argv) {
       case 'N': o.best = true; break;
       case 'S': { std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2) { usage(); return 1; } break; }
       case 'g': o.gpu = atoi(val().c_str()); break;
-      case 'b': (void)val(); break;  // (batch size of earlier versions: the whole input is one device batch now)
+      case 'b': o.batch_mb = atof(val().c_str()); break;
       case 'T': case 'F': (void)val(); break;  // accepted and ignored (threads, log file)
       default: usage(); return 1;
     }
@@ -178,111 +195,224 @@ int main(int argc, char** argv) {
           (unsigned long long)info.tot_seqs_len, mcl);
   auto t_open = std::chrono::steady_clock::now();
 
-  // ---- load: files -> host memory -> HBM -> records (k4_parse_fastx_dev) ------------------------------------------
-  std::vector<uint8_t> t1, t2;
-  if (!slurp(o.in1, t1) || (pe && !slurp(o.in2, t2))) { fprintf(stderr, "k4align: unable to open reads\n"); return 2; }
-  auto t_read = std::chrono::steady_clock::now();
-  void* d_reads = nullptr;
-  CK(k4_alloc_device(ix, t1.size() + t2.size() + 64, &d_reads));
-  Parsed p1, p2;
-  CK(load_reads(ix, t1, d_reads, 0, p1));
-  if (pe) CK(load_reads(ix, t2, d_reads, p1.bases, p2));
-  const Parsed a1 = p1, a2 = p2;  // the allocations (p1 / p2 are narrowed to this process's slice below)
-  std::vector<uint8_t>().swap(t1);
-  std::vector<uint8_t>().swap(t2);
-  if (pe && p2.n < p1.n) { fprintf(stderr, "k4align: fewer PE2 than PE1 reads\n"); return 3; }
-  // -S i/N: reads (pairs) are independent units; every process parses the whole input -- that is cheap on
-  // the device -- and keeps its contiguous slice, so that the shards' SAM files merge back into load order (k4merge)
-  const int64_t r0 = (int64_t)p1.n * o.shard / o.n_shards, r1 = (int64_t)p1.n * (o.shard + 1) / o.n_shards;
-  for (Parsed* q : {&p1, &p2}) {
-    if (!q->d_offs) continue;
-    q->d_offs = (uint8_t*)q->d_offs + 8 * r0; q->d_lens = (uint8_t*)q->d_lens + 4 * r0;
-    q->d_noff = (uint8_t*)q->d_noff + 8 * r0; q->d_nlen = (uint8_t*)q->d_nlen + 4 * r0;
-  }
-  const int64_t n = r1 - r0;
-  const int64_t n_reads = pe ? 2 * n : n;
-  uint64_t n_under = 0, n_over = 0;
-  uint32_t max_len = 0;
-  void *d_offs = nullptr, *d_lens = nullptr;
-  CK(k4_alloc_device(ix, (uint64_t)(n_reads + 1) * 8, &d_offs));
-  CK(k4_alloc_device(ix, (uint64_t)(n_reads + 1) * 4, &d_lens));
-  CK(k4_prepare_reads_dev(ix, pe ? 1 : 0, n, o.min_len, o.max_len, p1.d_offs, p1.d_lens, p2.d_offs, p2.d_lens, 0, d_offs, d_lens,
-                          &n_under, &n_over, &max_len, nullptr));
-  auto t_parse = std::chrono::steady_clock::now();
-
-  // ---- align (ProcCoredApprox / ProcessPairedEnds) -----------------------------------------------------------------
+  if (o.batch_mb > 0 && o.n_shards > 1) { fprintf(stderr, "k4align: -S slices the whole input; it cannot be combined with -b\n"); return 1; }
   k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, max_ml,
                          o.ml_mode == 5 ? (o.best ? 4 : o.clamp ? 3 : 2) : o.ml_mode == 1 ? 1 : 0,
                          mcl, slides};
   k4_pe_params pp = {o.pe_mode, o.pair_min, o.pair_max, o.pair_strand};
-  void *d_rr = nullptr, *d_hits = nullptr, *d_pe = nullptr;
-  if (n > 0 && max_len > 0) {
-    if (!pe) {
-      CK(k4_alloc_device(ix, (uint64_t)n * sizeof(k4_read_result), &d_rr));
-      CK(k4_alloc_device(ix, (uint64_t)n * max_ml * sizeof(k4_hit), &d_hits));
-      CK(k4_reserve(ix, n, (int32_t)max_len, max_ml));
-      CK(k4_kalign_batch_dev(ix, &kp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_rr, d_hits, nullptr));
-    } else {
-      CK(k4_alloc_device(ix, (uint64_t)2 * n * sizeof(k4_pe_read), &d_pe));
-      CK(k4_kalign_pe_batch_dev(ix, &kp, &pp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_pe, nullptr));
-    }
-  }
-  // ---- SAM body on the device (k4_format_sam_dev) -------------------------------------------------------------------
-  k4_sam_names nm;
-  memset(&nm, 0, sizeof(nm));
-  nm.d_text[0] = p1.d_text; nm.d_name_off[0] = p1.d_noff; nm.d_name_len[0] = p1.d_nlen;
-  nm.d_text[1] = p2.d_text; nm.d_name_off[1] = p2.d_noff; nm.d_name_len[1] = p2.d_nlen;
-  void* d_sam = nullptr;
-  uint64_t sam_bytes = 0;
-  k4_sam_stats stt;
-  memset(&stt, 0, sizeof(stt));
+  k4_sam_stats tot;
+  memset(&tot, 0, sizeof(tot));
   std::vector<uint8_t> hit_chrom(info.n_entries + 1, 0);
-  if (n > 0 && max_len > 0)
-    CK(k4_format_sam_dev(ix, pe ? 1 : 0, n, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, &nm, &d_sam, &sam_bytes, &stt,
-                         hit_chrom.data(), nullptr));
-  auto t1c = std::chrono::steady_clock::now();
+  uint64_t n_under = 0, n_over = 0, n_units = 0;
+  double s_read = 0, s_parse = 0, s_align = 0, s_write = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
+
+  // One batch: text holding whole records (the last one possibly cut when more text follows) -> records -> alignments ->
+  // SAM body.  The body goes to `body` (a part file) or, for the single batch of the whole-input mode, stays on the device.
+  void* keep_sam = nullptr;
+  uint64_t keep_bytes = 0;
+  auto run_batch = [&](const uint8_t* t1, uint64_t T1, int fin1, const uint8_t* t2, uint64_t T2, int fin2, FILE* body,
+                       uint64_t* used1, uint64_t* used2) -> int {
+    *used1 = *used2 = 0;
+    auto ta = now();
+    void* d_reads = nullptr;
+    CK(k4_alloc_device(ix, T1 + T2 + 64, &d_reads));
+    Parsed p1, p2;
+    CK(load_reads(ix, t1, T1, fin1, 0, d_reads, 0, p1, used1));
+    if (pe) {
+      CK(load_reads(ix, t2, T2, fin2, (int64_t)std::max<uint64_t>(p1.n, 1), d_reads, p1.bases, p2, used2));
+      if (p2.n < p1.n) {  // this portion of the mates' file holds fewer records: keep the pairs both files delivered
+        if (fin2 && fin1) { fprintf(stderr, "k4align: fewer PE2 than PE1 reads\n"); return 3; }
+        const int64_t n2 = (int64_t)p2.n;
+        free_parsed(p1);
+        free_parsed(p2);
+        if (n2 == 0) { k4_free_device(d_reads); *used1 = *used2 = 0; return K4_OK; }
+        CK(load_reads(ix, t1, T1, fin1, n2, d_reads, 0, p1, used1));
+        CK(load_reads(ix, t2, T2, fin2, n2, d_reads, p1.bases, p2, used2));
+      }
+    }
+    const Parsed a1 = p1, a2 = p2;  // the allocations (p1 / p2 are narrowed to this process's slice below)
+    // -S i/N: reads (pairs) are independent units; every process parses the whole input -- that is cheap
+    // on the device -- and keeps its contiguous slice, so that the shards' SAM files merge back into load order (k4merge)
+    const int64_t r0 = (int64_t)p1.n * o.shard / o.n_shards, r1 = (int64_t)p1.n * (o.shard + 1) / o.n_shards;
+    for (Parsed* q : {&p1, &p2}) {
+      if (!q->d_offs) continue;
+      q->d_offs = (uint8_t*)q->d_offs + 8 * r0; q->d_lens = (uint8_t*)q->d_lens + 4 * r0;
+      q->d_noff = (uint8_t*)q->d_noff + 8 * r0; q->d_nlen = (uint8_t*)q->d_nlen + 4 * r0;
+    }
+    const int64_t n = r1 - r0;
+    const int64_t n_reads = pe ? 2 * n : n;
+    uint64_t under = 0, over = 0;
+    uint32_t max_len = 0;
+    void *d_offs = nullptr, *d_lens = nullptr;
+    CK(k4_alloc_device(ix, (uint64_t)(n_reads + 1) * 8, &d_offs));
+    CK(k4_alloc_device(ix, (uint64_t)(n_reads + 1) * 4, &d_lens));
+    CK(k4_prepare_reads_dev(ix, pe ? 1 : 0, n, o.min_len, o.max_len, p1.d_offs, p1.d_lens, p2.d_offs, p2.d_lens, 0, d_offs, d_lens,
+                            &under, &over, &max_len, nullptr));
+    auto tb = now();
+    // ---- align (ProcCoredApprox / ProcessPairedEnds) ---------------------------------------------------------------
+    void *d_rr = nullptr, *d_hits = nullptr, *d_pe = nullptr;
+    if (n > 0 && max_len > 0) {
+      if (!pe) {
+        CK(k4_alloc_device(ix, (uint64_t)n * sizeof(k4_read_result), &d_rr));
+        CK(k4_alloc_device(ix, (uint64_t)n * max_ml * sizeof(k4_hit), &d_hits));
+        CK(k4_reserve(ix, n, (int32_t)max_len, max_ml));
+        CK(k4_kalign_batch_dev(ix, &kp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_rr, d_hits, nullptr));
+      } else {
+        CK(k4_alloc_device(ix, (uint64_t)2 * n * sizeof(k4_pe_read), &d_pe));
+        CK(k4_kalign_pe_batch_dev(ix, &kp, &pp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_pe, nullptr));
+      }
+    }
+    // ---- SAM body on the device (k4_format_sam_dev) ------------------------------------------------------------------
+    k4_sam_names nm;
+    memset(&nm, 0, sizeof(nm));
+    nm.d_text[0] = p1.d_text; nm.d_name_off[0] = p1.d_noff; nm.d_name_len[0] = p1.d_nlen;
+    nm.d_text[1] = p2.d_text; nm.d_name_off[1] = p2.d_noff; nm.d_name_len[1] = p2.d_nlen;
+    void* d_sam = nullptr;
+    uint64_t sam_bytes = 0;
+    k4_sam_stats stt;
+    memset(&stt, 0, sizeof(stt));
+    std::vector<uint8_t> hc(info.n_entries + 1, 0);
+    if (n > 0 && max_len > 0)
+      CK(k4_format_sam_dev(ix, pe ? 1 : 0, n, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, &nm, &d_sam, &sam_bytes, &stt,
+                           hc.data(), nullptr));
+    auto tc = now();
+    for (int k = 0; k < 20; k++) tot.nar[k] += stt.nar[k];
+    tot.plus += stt.plus; tot.minus += stt.minus; tot.n_lines += stt.n_lines;
+    for (size_t c = 0; c < hc.size(); c++) hit_chrom[c] |= hc[c];
+    n_under += under; n_over += over; n_units += (uint64_t)n;
+    if (body) {
+      std::vector<char> piece((size_t)std::min<uint64_t>(sam_bytes, 256ull << 20));
+      for (uint64_t off = 0; off < sam_bytes; off += piece.size()) {
+        const uint64_t len = std::min<uint64_t>(piece.size(), sam_bytes - off);
+        CK(k4_copy_to_host(ix, piece.data(), (const char*)d_sam + off, len));
+        if (fwrite(piece.data(), 1, len, body) != len) { fprintf(stderr, "k4align: write failed\n"); return 5; }
+      }
+      k4_free_device(d_sam);
+    } else {
+      keep_sam = d_sam;
+      keep_bytes = sam_bytes;
+    }
+    for (void* q : {d_reads, d_offs, d_lens, d_rr, d_hits, d_pe, a1.d_text, a1.d_offs, a1.d_lens, a1.d_noff, a1.d_nlen, a2.d_text,
+                    a2.d_offs, a2.d_lens, a2.d_noff, a2.d_nlen})
+      k4_free_device(q);
+    auto td = now();
+    s_parse += secs(ta, tb); s_align += secs(tb, tc); s_write += secs(tc, td);
+    return K4_OK;
+  };
+
+  // ---- the input: all at once (one batch, its SAM body stays on the device until the header is out) or streamed ----------
+  Stream f1, f2;
+  if (!f1.open(o.in1) || (pe && !f2.open(o.in2))) { fprintf(stderr, "k4align: unable to open reads\n"); return 2; }
+  std::vector<std::string> parts;
+  const uint64_t want0 = o.batch_mb > 0 ? std::max<uint64_t>((uint64_t)(o.batch_mb * 1048576.0), 4096) : UINT64_MAX;
+  uint64_t want = want0;
+  for (;;) {
+    auto tr = now();
+    if (!f1.fill(want) || (pe && !f2.fill(want))) { fprintf(stderr, "k4align: error reading the input\n"); return 2; }
+    s_read += secs(tr, now());
+    if (f1.buf.empty()) break;
+    const bool whole = o.batch_mb <= 0;
+    FILE* body = nullptr;
+    if (!whole) {
+      parts.push_back(o.out + ".part" + std::to_string(parts.size()));
+      body = fopen(parts.back().c_str(), "wb");
+      if (!body) { fprintf(stderr, "k4align: unable to create %s\n", parts.back().c_str()); return 5; }
+    }
+    uint64_t u1 = 0, u2 = 0;
+    rc = run_batch(f1.buf.data(), f1.buf.size(), f1.eof, f2.buf.data(), f2.buf.size(), f2.eof, body, &u1, &u2);
+    if (body) fclose(body);
+    if (rc != K4_OK) return rc;
+    if (u1 == 0) {  // not one whole record (pair) in this much text
+      if (!whole) { remove(parts.back().c_str()); parts.pop_back(); }
+      if (f1.eof && (!pe || f2.eof)) break;
+      want *= 2;
+      continue;
+    }
+    want = want0;
+    f1.drop(u1);
+    f2.drop(u2);
+    if (whole) break;
+  }
+  f1.close();
+  f2.close();
 
   // ---- statistics (ReportAlignStats) ------------------------------------------------------------------------------
-  const uint64_t n_loaded = (uint64_t)(pe ? 2 : 1) * ((uint64_t)n - n_under - n_over);
+  const uint64_t n_loaded = (uint64_t)(pe ? 2 : 1) * (n_units - n_under - n_over);
   fprintf(stderr, "k4align: From %llu source reads there are %llu accepted alignments, %llu on '+' strand, %llu on '-' strand\n",
-          (unsigned long long)n_loaded, (unsigned long long)stt.nar[1], (unsigned long long)stt.plus, (unsigned long long)stt.minus);
+          (unsigned long long)n_loaded, (unsigned long long)tot.nar[1], (unsigned long long)tot.plus, (unsigned long long)tot.minus);
   if (n_under || n_over)
     fprintf(stderr, "k4align: %llu under length and %llu over length reads were sloughed\n", (unsigned long long)n_under,
             (unsigned long long)n_over);
-  for (int k = 0; k < 20; k++) fprintf(stderr, "k4align:    %llu (%s)\n", (unsigned long long)stt.nar[k], kNarAbbr[k]);
+  for (int k = 0; k < 20; k++) fprintf(stderr, "k4align:    %llu (%s)\n", (unsigned long long)tot.nar[k], kNarAbbr[k]);
 
   // ---- SAM file: header here, body as formatted on the device ----------------------------------------------------------
+  auto tw = now();
   FILE* fp = fopen(o.out.c_str(), "wb");
   if (!fp) { fprintf(stderr, "k4align: unable to create %s\n", o.out.c_str()); return 5; }
   static char iobuf[1 << 22];
   setvbuf(fp, iobuf, _IOFBF, sizeof(iobuf));
   fprintf(fp, "@HD\tVN:1.4\tSO:coordinate\n");
   const bool all_chroms = info.n_entries <= 10000;  // m_MaxRptSAMSeqsThres, KAligner.cpp:5785-5821
+  std::map<std::string, long> order;
   for (uint32_t c = 1; c <= info.n_entries; c++) {
     k4_entry e;
     k4_get_entry(ix, c, &e);
+    order.emplace(e.name, (long)c);
     if (all_chroms || hit_chrom[c]) fprintf(fp, "@SQ\tAS:%s\tSN:%s\tLN:%u\n", info.dataset, e.name, e.seq_len);
   }
   fprintf(fp, "@PG\tID:k4align\tVN:1.0\n");
-  {
-    std::vector<char> piece((size_t)std::min<uint64_t>(sam_bytes, 256ull << 20));
-    for (uint64_t off = 0; off < sam_bytes; off += piece.size()) {
-      const uint64_t len = std::min<uint64_t>(piece.size(), sam_bytes - off);
-      CK(k4_copy_to_host(ix, piece.data(), (const char*)d_sam + off, len));
+  if (keep_sam) {
+    std::vector<char> piece((size_t)std::min<uint64_t>(keep_bytes, 256ull << 20));
+    for (uint64_t off = 0; off < keep_bytes; off += piece.size()) {
+      const uint64_t len = std::min<uint64_t>(piece.size(), keep_bytes - off);
+      CK(k4_copy_to_host(ix, piece.data(), (const char*)keep_sam + off, len));
       if (fwrite(piece.data(), 1, len, fp) != len) { fprintf(stderr, "k4align: write to %s failed\n", o.out.c_str()); return 5; }
     }
+    k4_free_device(keep_sam);
+  } else if (!parts.empty()) {
+    // every part is coordinate sorted; merge by (chromosome, position), equal keys in batch order = load order
+    struct Src { FILE* f; std::string line; long chrom, pos; };
+    std::vector<Src> src(parts.size());
+    auto next = [&](Src& x) -> bool {
+      x.line.clear();
+      char buf[1 << 16];
+      while (fgets(buf, sizeof(buf), x.f)) {
+        x.line += buf;
+        if (!x.line.empty() && x.line.back() == '\n') break;
+      }
+      if (x.line.empty()) return false;
+      size_t a = x.line.find('\t'), b = a == std::string::npos ? a : x.line.find('\t', a + 1);
+      size_t c = b == std::string::npos ? b : x.line.find('\t', b + 1);
+      if (c == std::string::npos) return false;
+      auto it = order.find(x.line.substr(b + 1, c - b - 1));
+      x.chrom = it == order.end() ? LONG_MAX : it->second;
+      x.pos = atol(x.line.c_str() + c + 1);
+      return true;
+    };
+    typedef std::pair<std::pair<long, long>, int> Item;
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
+    for (size_t i = 0; i < parts.size(); i++) {
+      src[i].f = fopen(parts[i].c_str(), "rb");
+      if (!src[i].f) { fprintf(stderr, "k4align: unable to reopen %s\n", parts[i].c_str()); return 5; }
+      if (next(src[i])) pq.push({{src[i].chrom, src[i].pos}, (int)i});
+    }
+    while (!pq.empty()) {
+      const int i = pq.top().second;
+      pq.pop();
+      fputs(src[i].line.c_str(), fp);
+      if (next(src[i])) pq.push({{src[i].chrom, src[i].pos}, i});
+    }
+    for (size_t i = 0; i < parts.size(); i++) { fclose(src[i].f); remove(parts[i].c_str()); }
   }
   fclose(fp);
-  auto t2c = std::chrono::steady_clock::now();
-  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-    return std::chrono::duration<double>(b - a).count();
-  };
-  fprintf(stderr, "k4align: %llu alignments written to %s; index %.2fs, read files %.2fs, upload+parse %.2fs, align+format %.2fs, write %.2fs\n",
-          (unsigned long long)stt.n_lines, o.out.c_str(), secs(t0, t_open), secs(t_open, t_read), secs(t_read, t_parse),
-          secs(t_parse, t1c), secs(t1c, t2c));
-  for (void* q : {d_reads, d_offs, d_lens, d_rr, d_hits, d_pe, d_sam, a1.d_text, a1.d_offs, a1.d_lens, a1.d_noff, a1.d_nlen,
-                  a2.d_text, a2.d_offs, a2.d_lens, a2.d_noff, a2.d_nlen})
-    k4_free_device(q);
+  s_write += secs(tw, now());
+  fprintf(stderr, "k4align: %llu alignments written to %s (%zu batch%s); index %.2fs, read files %.2fs, upload+parse %.2fs, align+format %.2fs, write %.2fs\n",
+          (unsigned long long)tot.n_lines, o.out.c_str(), parts.empty() ? (size_t)1 : parts.size(), parts.size() > 1 ? "es" : "",
+          secs(t0, t_open), s_read, s_parse, s_align, s_write);
   k4_close(ix);
   return 0;
 }

@@ -350,3 +350,39 @@ def test_k4index_writes_the_reference_index(tmp_path):
     assert (seq[sa_a[d]] == 7).all() and (seq[sa_b[d]] == 7).all()
     assert sorted(sa_a[d].tolist()) == sorted(sa_b[d].tolist())
     assert len(d) <= 5
+
+
+@pytest.mark.parametrize("case,mb", [("se_s2", "0.03"), ("pe_u1", "0.05"), ("se_r5_R12", "0.1"), ("pe_u2", "2")])
+def test_k4align_streamed_batches_equal_the_single_run(golden_dir, tmp_path, case, mb):
+    """`k4align -b <MB>`: the input is read and aligned in portions (inputs larger than memory), the sorted parts are merged"""
+    import json
+    import lzma
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(golden_dir, "sam_cases.json")))
+
+    def unxz(name):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        return dst
+
+    files = ["-i", unxz("sam_%s.fa.xz" % case)] if case.startswith("se_") else \
+        ["-i", unxz("sam_%s_1.fa.xz" % case), "-u", unxz("sam_%s_2.fa.xz" % case)]
+    out = str(tmp_path / "o.sam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-b", mb]
+                       + cases[case]["args"] + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    if float(mb) < 1:
+        assert "batches)" in p.stderr
+    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    want = [l for l in lzma.open(os.path.join(golden_dir, "sam_%s.sam.xz" % case)).read().decode().splitlines() if not l.startswith("@PG")]
+    assert [l for l in got if l.startswith("@")] == [l for l in want if l.startswith("@")]
+    assert sorted(got) == sorted(want)
+    order = {l.split("\tSN:")[1].split("\t")[0]: i for i, l in enumerate(h for h in want if h.startswith("@SQ"))}
+    keys = [(order[l.split("\t")[2]], int(l.split("\t")[3])) for l in got if not l.startswith("@")]
+    assert keys == sorted(keys)
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+    if "-r5" not in cases[case]["args"]:
+        for name, n in cases[case]["nar"].items():
+            assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
