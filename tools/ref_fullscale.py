@@ -38,6 +38,7 @@ seq = bench.make_genome(dev, n_chrom, chrom_len)
 n = seq.numel()
 n_rep = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 extra = sys.argv[8].split() if len(sys.argv) > 8 else []
+k4_extra = sys.argv[10].split() if len(sys.argv) > 10 else []  # options for k4align only (e.g. "-b 100")
 dropin_threads = int(sys.argv[9]) if len(sys.argv) > 9 else 0  # > 0: also run oracle/_ref/ngskit4b_k4 (the reference's
 # own front end on libk4sfx.so through the facade) with this many threads
 if n_rep:
@@ -79,7 +80,7 @@ print("\n".join(keep[-40:]), flush=True)
 
 gpu_sam = os.path.join(tmp, "gpu.sam")
 t0 = time.time()
-g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam, "-s2"] + extra + in_args, capture_output=True, text=True)
+g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam, "-s2"] + extra + k4_extra + in_args, capture_output=True, text=True)
 t_gpu = time.time() - t0
 print("k4align rc", g.returncode, "wall %.1fs" % t_gpu)
 print(g.stderr[-1500:], flush=True)
@@ -110,7 +111,7 @@ hg, rg = body(gpu_sam)
 same_hdr = hr == hg
 same_order = rr == rg
 same_set = sorted(rr) == sorted(rg)
-out = {"extra_args": extra, "repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
+out = {"extra_args": extra, "k4align_extra_args": k4_extra, "repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
        "reference_sam_records": len(rr), "k4align_sam_records": len(rg), "headers_equal": same_hdr,
        "records_equal_as_multiset": same_set, "records_equal_in_order": same_order}
 if dropin:
