@@ -38,6 +38,7 @@ seq = bench.make_genome(dev, n_chrom, chrom_len)
 n = seq.numel()
 n_rep = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 extra = sys.argv[8].split() if len(sys.argv) > 8 else []
+subs = [] if any(a.startswith("-s") for a in (sys.argv[8].split() if len(sys.argv) > 8 else [])) else ["-s2"]
 k4_extra = sys.argv[10].split() if len(sys.argv) > 10 else []  # options for k4align only (e.g. "-b 100")
 dropin_threads = int(sys.argv[9]) if len(sys.argv) > 9 else 0  # > 0: also run oracle/_ref/ngskit4b_k4 (the reference's
 # own front end on libk4sfx.so through the facade) with this many threads
@@ -71,7 +72,7 @@ torch.cuda.empty_cache()
 
 ref_sam, ref_log = os.path.join(tmp, "ref.sam"), os.path.join(tmp, "ref.log")
 t0 = time.time()
-r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log, "-s2"] + extra + in_args, capture_output=True)
+r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log] + subs + extra + in_args, capture_output=True)
 t_ref = time.time() - t0
 print("reference rc", r.returncode, "wall %.1fs" % t_ref, flush=True)
 log = open(ref_log, errors="replace").read() if os.path.exists(ref_log) else ""
@@ -80,7 +81,7 @@ print("\n".join(keep[-40:]), flush=True)
 
 gpu_sam = os.path.join(tmp, "gpu.sam")
 t0 = time.time()
-g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam, "-s2"] + extra + k4_extra + in_args, capture_output=True, text=True)
+g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam] + subs + extra + k4_extra + in_args, capture_output=True, text=True)
 t_gpu = time.time() - t0
 print("k4align rc", g.returncode, "wall %.1fs" % t_gpu)
 print(g.stderr[-1500:], flush=True)
@@ -99,7 +100,7 @@ if dropin_threads > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "n
     di_sam, di_log = os.path.join(tmp, "dropin.sam"), os.path.join(tmp, "dropin.log")
     t0 = time.time()
     d = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ngskit4b_k4"), "kalign", "-I", sfx, "-o", di_sam, "-T", str(dropin_threads),
-                        "-F", di_log, "-s2"] + extra + in_args, capture_output=True)
+                        "-F", di_log] + subs + extra + in_args, capture_output=True)
     t_di = time.time() - t0
     lg = open(di_log, errors="replace").read() if os.path.exists(di_log) else ""
     al = [ln for ln in lg.splitlines() if "Now aligning" in ln or "Alignment of" in ln]
