@@ -86,6 +86,33 @@ def implant_repeats(seq, n_chrom, chrom_len, n_rep, dev, seed=4242):
     assert int(((seq > 4) & (seq != 7)).sum()) == 0
 
 
+def implant_stress(seq, n_chrom, chrom_len, n_copies, dev, seed=777):
+    """MaxIter / node-limit stress (not a BASELINE workload): ONE 300 bp element copied n_copies times (0..2 % diverged),
+    plus low-complexity stretches (poly-A, (AC)n, (AAT)n) of 5 kbp each."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    span = chrom_len - 6000
+    elem = torch.randint(0, 4, (300,), device=dev, generator=g, dtype=torch.uint8)
+    pos = torch.randint(0, n_chrom * span, (n_copies,), device=dev, generator=g).tolist()
+    for r, u in enumerate(pos):
+        c, o = divmod(int(u), span)
+        dst = c * (chrom_len + 1) + o
+        seg = elem.clone()
+        rate = (r % 3) * 0.01
+        if rate:
+            mut = torch.rand(300, device=dev, generator=g) < rate
+            seg = torch.where(mut, (seg + torch.randint(1, 4, (300,), device=dev, generator=g, dtype=torch.uint8)) % 4, seg)
+        if r % 2:
+            seg = (3 - seg).flip(0)
+        seq[dst:dst + 300] = seg
+    for k, unit in enumerate(([0], [0, 1], [0, 0, 3])):
+        for rep in range(3):
+            u = int(torch.randint(0, n_chrom * span, (1,), device=dev, generator=g))
+            c, o = divmod(u, span)
+            dst = c * (chrom_len + 1) + o
+            seq[dst:dst + 5000] = torch.tensor(unit * (5000 // len(unit) + 1), dtype=torch.uint8, device=dev)[:5000]
+
+
 def mutate(r, g, dev):
     """In place: Poisson(1) substitutions truncated at 8, distinct uniform positions, new base != old.  Returns the counts."""
     m, read_len = r.shape

@@ -42,8 +42,10 @@ subs = [] if any(a.startswith("-s") for a in (sys.argv[8].split() if len(sys.arg
 k4_extra = sys.argv[10].split() if len(sys.argv) > 10 else []  # options for k4align only (e.g. "-b 100")
 dropin_threads = int(sys.argv[9]) if len(sys.argv) > 9 else 0  # > 0: also run oracle/_ref/ngskit4b_k4 (the reference's
 # own front end on libk4sfx.so through the facade) with this many threads
-if n_rep:
+if n_rep > 0:
     bench.implant_repeats(seq, n_chrom, chrom_len, n_rep, dev)
+elif n_rep < 0:  # one element copied -n_rep times + low-complexity stretches: MaxIter and the node limit are reached
+    bench.implant_stress(seq, n_chrom, chrom_len, -n_rep, dev)
     print("implanted %d repeat copies" % n_rep, flush=True)
 el = 4 if n < 4_000_000_000 else 5
 sa = torch.empty(n * el + 16, dtype=torch.uint8, device=dev)
@@ -124,5 +126,5 @@ if dropin:
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"summary": out, "reference_log_tail": keep[-40:], "k4align_stderr": g.stderr[-3000:]},
-          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep else "") + ("_" + "".join(extra).replace("-", "") if extra else ""))), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep > 0 else "_stress" if n_rep < 0 else "") + ("_" + "".join(extra).replace("-", "") if extra else ""))), "w"), indent=1)
 shutil.rmtree(tmp, ignore_errors=True)
