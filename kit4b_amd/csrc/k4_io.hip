@@ -282,7 +282,7 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
   a.seq_off = so.as<uint32_t>(); a.seq_span = ss.as<uint32_t>(); a.lens = (uint32_t*)d_lens;
   a.name_off = (uint64_t*)d_name_off; a.name_len = (uint32_t*)d_name_len; a.tot = tot.as<unsigned long long>();
   hipLaunchKernelGGL(k4k_fastx_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k4k_fastx_count, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 18)), dim3(64), 0, st, text, so.as<uint32_t>(),
+  hipLaunchKernelGGL(k4k_fastx_count, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 14)), dim3(64), 0, st, text, so.as<uint32_t>(),
                      ss.as<uint32_t>(), n_rec, (uint32_t*)d_lens, tot.as<unsigned long long>());
   {
     size_t tb = 0;
@@ -292,7 +292,7 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
     K4_HIP(ix, tmp3.alloc(tb));
     K4_HIP(ix, rocprim::exclusive_scan(tmp3.p, tb, (const uint32_t*)d_lens, (uint64_t*)d_offs, reads_base, (size_t)n_rec,
                                        rocprim::plus<uint64_t>(), st));
-    hipLaunchKernelGGL(k4k_fastx_encode, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 20)), dim3(64), 0, st, text, so.as<uint32_t>(),
+    hipLaunchKernelGGL(k4k_fastx_encode, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 16)), dim3(64), 0, st, text, so.as<uint32_t>(),
                        ss.as<uint32_t>(), (const uint64_t*)d_offs, n_rec, (uint8_t*)d_reads);
     K4_HIP(ix, hipGetLastError());
     K4_HIP(ix, hipStreamSynchronize(st));  // tmp3 is released here
@@ -315,27 +315,32 @@ __global__ void __launch_bounds__(256) k4k_prepare_reads(int pe, int64_t n, uint
                                                          const uint64_t* __restrict__ o2, const uint32_t* __restrict__ l2,
                                                          uint64_t base2, uint64_t* __restrict__ oo, uint32_t* __restrict__ lo,
                                                          unsigned long long* __restrict__ tot) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool valid = i < n;  // (no early return: the wave reductions below need every lane)
-  const uint32_t a = valid ? l1[i] : 0u, b = valid ? (pe ? l2[i] : a) : 0u;
-  const bool under = valid && (a < min_len || b < min_len);  // sloughed, KAligner.cpp:12024-12060
-  const bool over = valid && !under && (a > max_len || b > max_len);
-  const bool keep = valid && !under && !over;
-  if (valid) {
+  // grid-stride, tallies kept per thread and folded once per wave at the end: a same-address atomic per wave of a
+  // one-thread-per-read launch (312 k of them for 20 M reads) costs more than the whole copy
+  uint32_t n_u = 0, n_o = 0, mx = 0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const uint32_t a = l1[i], b = pe ? l2[i] : a;
+    const bool under = a < min_len || b < min_len;  // sloughed, KAligner.cpp:12024-12060
+    const bool over = !under && (a > max_len || b > max_len);
+    const bool keep = !under && !over;
     if (pe) {
       oo[2 * i] = o1[i]; lo[2 * i] = keep ? a : 0;
       oo[2 * i + 1] = o2[i] + base2; lo[2 * i + 1] = keep ? b : 0;
     } else {
       oo[i] = o1[i]; lo[i] = keep ? a : 0;
     }
+    n_u += under; n_o += over;
+    if (keep) mx = max(mx, max(a, b));
   }
-  // one atomic per wave and tally
-  const unsigned long long mu = __ballot(under), mo = __ballot(over);
-  uint32_t mx = keep ? max(a, b) : 0u;
-  for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+  for (int d = 32; d > 0; d >>= 1) {
+    n_u += __shfl_xor(n_u, d, 64);
+    n_o += __shfl_xor(n_o, d, 64);
+    mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+  }
   if ((threadIdx.x & 63) == 0) {
-    if (mu) atomicAdd(&tot[0], (unsigned long long)__popcll(mu));
-    if (mo) atomicAdd(&tot[1], (unsigned long long)__popcll(mo));
+    if (n_u) atomicAdd(&tot[0], (unsigned long long)n_u);
+    if (n_o) atomicAdd(&tot[1], (unsigned long long)n_o);
     if (mx) atomicMax(&tot[2], (unsigned long long)mx);
   }
 }
@@ -356,7 +361,7 @@ extern "C" int k4_prepare_reads_dev(k4_index* ix, int pe, int64_t n, int32_t min
   Buf tot;
   K4_HIP(ix, tot.alloc(24));
   K4_HIP(ix, hipMemsetAsync(tot.p, 0, 24, st));
-  hipLaunchKernelGGL(k4k_prepare_reads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pe ? 1 : 0, n,
+  hipLaunchKernelGGL(k4k_prepare_reads, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, st, pe ? 1 : 0, n,
                      (uint32_t)std::max(min_len, 0), (uint32_t)std::max(max_len, 0), (const uint64_t*)d_offs1, (const uint32_t*)d_lens1,
                      (const uint64_t*)d_offs2, (const uint32_t*)d_lens2, reads2_base, (uint64_t*)d_offs_out, (uint32_t*)d_lens_out,
                      tot.as<unsigned long long>());
@@ -721,7 +726,7 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
   K4_HIP(ix, hipMemcpy(&total, lo.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost));
   char* out = nullptr;
   K4_HIP(ix, hipMalloc(&out, total + 16));
-  hipLaunchKernelGGL(k4k_sam_write, dim3((unsigned)std::min<uint64_t>((m + 3) / 4, 1u << 20)), dim3(64), 0, st, a, order, lo.as<uint64_t>(), m, out);
+  hipLaunchKernelGGL(k4k_sam_write, dim3((unsigned)std::min<uint64_t>((m + 3) / 4, 1u << 16)), dim3(64), 0, st, a, order, lo.as<uint64_t>(), m, out);
   int rc = k4_check_hip(ix, hipGetLastError(), "SAM write");
   if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(st), "SAM write");
   if (rc != K4_OK) {
