@@ -293,6 +293,11 @@ int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, c
                       const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens,
                       const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
                       uint8_t* chrom_hit /* host, n_entries + 1 bytes, or NULL */, void* stream);
+/* k4_select_hits_dev <- MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962) after k4_kalign_batch_dev with pe_mode 2: every accepted
+ * read keeps ONE instance, hits[choice[i] % NumHits] moved to slot 0, NumHits = 1.  d_choice: uint32 per read, the caller's
+ * draws (the reference: rand() once per read within the limit, in load order when it runs one thread). */
+int k4_select_hits_dev(k4_index* ix, int64_t n_reads, int32_t max_ml, void* d_rr, void* d_hits, const void* d_choice,
+                       void* stream);
 void k4_free_device(void* p);
 /* device memory for host programs that use the *_dev entry points without a HIP runtime of their own */
 int k4_alloc_device(k4_index* ix, uint64_t bytes, void** d_ptr);

@@ -101,7 +101,7 @@ ABI_SYMBOLS = [
     "k4_get_kernel_times", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
     "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
-    "k4_get_sfx_header", "k4_set_description",
+    "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",
 ]
 
 
@@ -160,6 +160,7 @@ def lib():
     L.k4_parse_fastx_dev.argtypes = [vp, vp, u64, u64, i32, i32, i64, vp, u64, vp, vp, vp, vp, C.POINTER(ParseInfo), vp]
     L.k4_prepare_reads_dev.argtypes = [vp, i32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, u64, vp, vp,
                                        C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), vp]
+    L.k4_select_hits_dev.argtypes = [vp, i64, C.c_int32, vp, vp, vp, vp]
     L.k4_format_sam_dev.argtypes = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, C.POINTER(SamNames), C.POINTER(vp),
                                     C.POINTER(u64), C.POINTER(SamStats), vp, vp]
     L.k4_free_device.argtypes = [vp]
@@ -466,6 +467,23 @@ class SfxIndex:
     def kalign_pe_batch_dev(self, params, pe_params, n_pairs, max_read_len, d_reads, d_offs, d_lens, d_out, stream=0):
         self._ck(lib().k4_kalign_pe_batch_dev(self.h, C.byref(params), C.byref(pe_params), n_pairs, max_read_len,
                                               d_reads, d_offs, d_lens, d_out, stream))
+
+    def select_hits_dev(self, n, max_ml, d_rr, d_hits, d_choice, stream=0):
+        """MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962): keep hits[choice % NumHits] of every accepted read."""
+        self._ck(lib().k4_select_hits_dev(self.h, n, max_ml, d_rr, d_hits, d_choice, stream))
+
+    def select_hits(self, out, hits, choice):
+        """select_hits_dev over host arrays (kalign_batch's out / hits, uint32 draws); returns the new (out, hits)."""
+        import torch
+
+        dev = torch.device("cuda", self.info()["device"])
+        n, max_ml = hits.shape
+        d_rr = torch.from_numpy(out.view(np.uint8).copy()).to(dev)
+        d_hits = torch.from_numpy(hits.reshape(-1).view(np.uint8).copy()).to(dev)
+        d_ch = torch.from_numpy(np.ascontiguousarray(choice, dtype=np.uint32).view(np.int32)).to(dev)
+        self.select_hits_dev(n, max_ml, d_rr.data_ptr(), d_hits.data_ptr(), d_ch.data_ptr())
+        torch.cuda.synchronize()
+        return (d_rr.cpu().numpy().view(RESULT_DTYPE), d_hits.cpu().numpy().view(HIT_DTYPE).reshape(n, max_ml))
 
     def kalign_batch_dev(self, params, n, max_read_len, d_reads, d_offs, d_lens, d_out, d_hits, stream=0):
         self._ck(lib().k4_kalign_batch_dev(self.h, C.byref(params), n, max_read_len, d_reads, d_offs, d_lens, d_out,

@@ -604,6 +604,32 @@ extern "C" int k4_copy_to_host(k4_index* ix, void* dst, const void* d_src, uint6
   return K4_OK;
 }
 
+// MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962): a read within the instance limit reports ONE of its instances, the one the
+// caller's random stream names; the caller draws in load order (one draw per such read, unique ones included, as the
+// reference does with one thread) and passes the draws, this moves the chosen instance into slot 0.
+__global__ void k4k_select_hits(int64_t n, int32_t max_ml, k4_read_result* __restrict__ rr, k4_hit* __restrict__ hits,
+                                const uint32_t* __restrict__ choice) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    k4_read_result r = rr[i];
+    if (r.nar != K4_NAR_ACCEPTED || r.num_hits < 1) continue;
+    const uint32_t c = choice[i] % (uint32_t)r.num_hits;
+    if (c) hits[i * max_ml] = hits[i * max_ml + c];
+    rr[i].num_hits = 1;
+  }
+}
+
+extern "C" int k4_select_hits_dev(k4_index* ix, int64_t n_reads, int32_t max_ml, void* d_rr, void* d_hits, const void* d_choice,
+                                  void* stream) {
+  if (!ix || n_reads < 0 || max_ml < 1 || (n_reads && (!d_rr || !d_hits || !d_choice))) return K4_ERR_PARAMS;
+  if (!n_reads) return K4_OK;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  const int64_t blocks = std::min<int64_t>((n_reads + 255) / 256, 65536);
+  k4k_select_hits<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(n_reads, max_ml, (k4_read_result*)d_rr,
+                                                                                  (k4_hit*)d_hits, (const uint32_t*)d_choice);
+  K4_HIP(ix, hipGetLastError());
+  return K4_OK;
+}
+
 extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                                  const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens,
                                  const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,

@@ -132,6 +132,31 @@ void usage() {
 
 }  // namespace
 
+// The C library's rand() as the reference binary sees it on Linux -- glibc's default TYPE_3 additive feedback generator,
+// never seeded by kalign (seed 1): r[i] = r[i-3] + r[i-31] over 32-bit words, 310 values discarded, output = r[i] >> 1.
+struct GlibcRand {
+  uint32_t r[34];
+  int k = 0;
+  GlibcRand() {
+    r[0] = 1;
+    for (int i = 1; i < 31; i++) {
+      int64_t v = (16807ll * (int32_t)r[i - 1]) % 2147483647ll;
+      if (v < 0) v += 2147483647ll;
+      r[i] = (uint32_t)v;
+    }
+    for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+    for (int i = 0; i < 310; i++) step();
+  }
+  uint32_t step() {  // ring of 34: r[k] holds x[i-34]; x[i] = x[i-3] + x[i-31]
+    const uint32_t v = r[(k + 31) % 34] + r[(k + 3) % 34];
+    r[k] = v;
+    k = (k + 1) % 34;
+    return v;
+  }
+  int next() { return (int)(step() >> 1); }
+};
+static GlibcRand draws;
+
 int main(int argc, char** argv) {
   Opts o;
   for (int i = 1; i < argc; i++) {
@@ -168,7 +193,7 @@ int main(int argc, char** argv) {
   const bool pe = !o.in2.empty();
   // multi-loci modes (KAlignerCL.cpp:686-707): 0 slough, 1 statistics only, 5 report every locus up to -R; the modes that
   // pick or cluster one locus (2 random, 3/4 AssignMultiMatches) are not part of this path
-  if (o.ml_mode != 0 && o.ml_mode != 1 && o.ml_mode != 5) { fprintf(stderr, "k4align: -r%d is not supported (0, 1 and 5 are)\n", o.ml_mode); return 1; }
+  if (o.ml_mode != 0 && o.ml_mode != 1 && o.ml_mode != 2 && o.ml_mode != 5) { fprintf(stderr, "k4align: -r%d is not supported (0, 1, 2 and 5 are)\n", o.ml_mode); return 1; }
   if (o.ml_mode != 0 && pe) { fprintf(stderr, "k4align: multiloci processing '-r%d' not supported in paired end processing\n", o.ml_mode); return 1; }
   if (o.n_shards < 1 || o.shard < 0 || o.shard >= o.n_shards) { fprintf(stderr, "k4align: -S i/N needs 0 <= i < N\n"); return 1; }
   if ((o.clamp || o.best) && o.ml_mode != 5) { fprintf(stderr, "k4align: -X / -N are supported together with -r5 only\n"); return 1; }
@@ -197,7 +222,7 @@ int main(int argc, char** argv) {
 
   if (o.batch_mb > 0 && o.n_shards > 1) { fprintf(stderr, "k4align: -S slices the whole input; it cannot be combined with -b\n"); return 1; }
   k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, max_ml,
-                         o.ml_mode == 5 ? (o.best ? 4 : o.clamp ? 3 : 2) : o.ml_mode == 1 ? 1 : 0,
+                         o.ml_mode == 5 ? (o.best ? 4 : o.clamp ? 3 : 2) : o.ml_mode == 2 ? 2 : o.ml_mode == 1 ? 1 : 0,
                          mcl, slides};
   k4_pe_params pp = {o.pe_mode, o.pair_min, o.pair_max, o.pair_strand};
   k4_sam_stats tot;
@@ -261,6 +286,21 @@ int main(int argc, char** argv) {
         CK(k4_alloc_device(ix, (uint64_t)n * max_ml * sizeof(k4_hit), &d_hits));
         CK(k4_reserve(ix, n, (int32_t)max_len, max_ml));
         CK(k4_kalign_batch_dev(ix, &kp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_rr, d_hits, nullptr));
+        if (o.ml_mode == 2) {
+          // eMLrand (KAligner.cpp:9945-9962): rand() once per read within the instance limit, in load order -- what the
+          // reference does when it runs one thread (with more its draws depend on thread timing).  The draws are a private
+          // restatement of the C library's generator: other code in this process (the HIP runtime) may call rand() too
+          std::vector<k4_read_result> rr((size_t)n);
+          std::vector<uint32_t> choice((size_t)n, 0);
+          CK(k4_copy_to_host(ix, rr.data(), d_rr, (uint64_t)n * sizeof(k4_read_result)));
+          for (int64_t i = 0; i < n; i++)
+            if (rr[i].nar == K4_NAR_ACCEPTED && rr[i].num_hits >= 1) choice[i] = (uint32_t)(draws.next() % rr[i].num_hits);
+          void* d_choice = nullptr;
+          CK(k4_alloc_device(ix, (uint64_t)n * 4, &d_choice));
+          CK(k4_copy_to_device(ix, d_choice, choice.data(), (uint64_t)n * 4));
+          CK(k4_select_hits_dev(ix, n, max_ml, d_rr, d_hits, d_choice, nullptr));
+          k4_free_device(d_choice);
+        }
       } else {
         CK(k4_alloc_device(ix, (uint64_t)2 * n * sizeof(k4_pe_read), &d_pe));
         CK(k4_kalign_pe_batch_dev(ix, &kp, &pp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_pe, nullptr));

@@ -29,6 +29,9 @@ CASES = {
     "se_r5_R12": (["-s2", "-r5", "-R12"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4324, n_prob=0.02, edge_frac=0.05)[0]),
     # the same with reads over the limit clamped to -R (-X), and with LocateBestMatches instead of AlignReads (-N)
     "se_r5_R6_X": (["-s2", "-r5", "-R6", "-X"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4325, n_prob=0.02, edge_frac=0.05)[0]),
+    # MLMode eMLrand: one instance, picked by rand() in load order; the reference is run with ONE thread for this case (with
+    # more its draws depend on thread timing)
+    "se_r2_R8": (["-s2", "-r2", "-R8"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4327, n_prob=0.02, edge_frac=0.05)[0]),
     "se_r5_R8_N": (["-s3", "-r5", "-R8", "-N"], lambda ch: synth.make_reads(ch, 3000, 110, seed=4326, sub_lambda=1.5, n_prob=0.02, edge_frac=0.05)[0]),
 }
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # case names: regenerate just these (others keep their files)
@@ -41,7 +44,7 @@ PE_CASES = {
 def run(tmp, name, args, files):
     sam = os.path.join(tmp, name + ".sam")
     log = os.path.join(tmp, name + ".log")
-    cmd = [NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", sam, "-T", "4", "-F", log] + args + files
+    cmd = [NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", sam, "-T", "1" if "-r2" in args else "4", "-F", log] + args + files
     subprocess.run(cmd, check=True, capture_output=True)
     hist = {}
     for line in open(log):

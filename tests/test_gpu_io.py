@@ -258,7 +258,7 @@ def test_k4align_edge_inputs(golden_dir, tmp_path):
     assert p.returncode == 0, p.stderr
     recs = [l for l in lines if not l.startswith("@")]
     assert len(recs) == 1 and recs[0].split("\t")[:4] == ["q1", "0", "chr2", "1001"]
-    p, _ = run(b">a\n" + seq + b"\n", "-r2")
+    p, _ = run(b">a\n" + seq + b"\n", "-r3")
     assert p.returncode != 0 and "not supported" in p.stderr
 
 
@@ -352,7 +352,7 @@ def test_k4index_writes_the_reference_index(tmp_path):
     assert len(d) <= 5
 
 
-@pytest.mark.parametrize("case,mb", [("se_s2", "0.03"), ("pe_u1", "0.05"), ("se_r5_R12", "0.1"), ("pe_u2", "2")])
+@pytest.mark.parametrize("case,mb", [("se_s2", "0.03"), ("pe_u1", "0.05"), ("se_r5_R12", "0.1"), ("pe_u2", "2"), ("se_r2_R8", "0.08")])
 def test_k4align_streamed_batches_equal_the_single_run(golden_dir, tmp_path, case, mb):
     """`k4align -b <MB>`: the input is read and aligned in portions (inputs larger than memory), the sorted parts are merged"""
     import json

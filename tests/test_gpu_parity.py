@@ -218,9 +218,27 @@ def _kalign_args(args):
         elif a.startswith("-D"): pe["pair_max_len"] = int(a[2:])
         elif a.startswith("-R"): kw["max_ml"] = int(a[2:])
         elif a == "-r5": kw["pe_mode"] = max(kw.get("pe_mode", 0), 2)  # MLMode eMLall: every instance reported
+        elif a == "-r2": kw["pe_mode"] = 2                              # MLMode eMLrand: ... then one of them picked
         elif a == "-X": kw["pe_mode"] = max(kw.get("pe_mode", 0), 3)   # ... reads over the -R limit clamped to it
         elif a == "-N": kw["pe_mode"] = 4                               # ... through LocateBestMatches
     return kw, pe
+
+
+def _pick_rand_on_device(ix, out, hits):
+    """`-r2`: the draws the reference makes with one thread (C library rand(), never seeded, once per read within the
+    instance limit, load order), applied by k4_select_hits_dev."""
+    import ctypes
+
+    libc = ctypes.CDLL(None)
+    libc.srand(1)
+    within = (out["nar"] == 1) & (out["num_hits"] >= 1)
+    assert (out["num_hits"][within] > 1).sum() > 5
+    choice = np.zeros(len(out), np.uint32)
+    for i in np.nonzero(within)[0]:
+        choice[i] = libc.rand()  # the entry point reduces it modulo NumHits
+    out2, hits2 = ix.select_hits(out, hits, choice)
+    assert (out2["num_hits"][within] == 1).all() and (out2["nar"] == out["nar"]).all()
+    return out2, hits2
 
 
 @pytest.mark.parametrize("case", sorted(SAM_CASES))
@@ -235,6 +253,8 @@ def test_reference_sam_end_to_end(k4, golden_dir, case):
         r = ix.kalign_batch(reads, **kw)
         from test_oracle_sam_golden import expand_all_hits
 
+        if "-r2" in SAM_CASES[case]["args"]:
+            r["out"], r["hits"] = _pick_rand_on_device(ix, r["out"], r["hits"])
         names, reads, res = expand_all_hits(names, reads, r["out"], r["hits"])
         got = samutil.sam_records(names, reads, res, CHROMS)
         nars = r["out"]["nar"]
