@@ -298,6 +298,13 @@ int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, c
  * draws (the reference: rand() once per read within the limit, in load order when it runs one thread). */
 int k4_select_hits_dev(k4_index* ix, int64_t n_reads, int32_t max_ml, void* d_rr, void* d_hits, const void* d_choice,
                        void* stream);
+/* k4_assign_multi_dev <- CKAligner::AssignMultiMatches (KAligner.cpp:5092-5258; scoring: ProcAssignMultiMatches :4944-5085),
+ * MLMode eMLuniq (ml_mode 3, `-r3`) / eMLmulti (4, `-r4`), after k4_kalign_batch_dev with pe_mode 1 over ALL reads of the
+ * run (the clustering is global): a multi-aligned read whose best locus clusters well enough with other reads (score >= 50
+ * and twice the next locus') becomes accepted with that locus in slot 0 (NumHits 1, LowHitInstances 1).
+ * max_reads_len: the longest read loaded (m_MaxReadsLen).  Waits for `stream`. */
+int k4_assign_multi_dev(k4_index* ix, int ml_mode, int32_t max_reads_len, int64_t n_reads, int32_t max_ml, void* d_rr,
+                        void* d_hits, int64_t* n_assigned, void* stream);
 void k4_free_device(void* p);
 /* device memory for host programs that use the *_dev entry points without a HIP runtime of their own */
 int k4_alloc_device(k4_index* ix, uint64_t bytes, void** d_ptr);

@@ -102,6 +102,7 @@ ABI_SYMBOLS = [
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
     "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
     "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",
+    "k4_assign_multi_dev",
 ]
 
 
@@ -160,6 +161,7 @@ def lib():
     L.k4_parse_fastx_dev.argtypes = [vp, vp, u64, u64, i32, i32, i64, vp, u64, vp, vp, vp, vp, C.POINTER(ParseInfo), vp]
     L.k4_prepare_reads_dev.argtypes = [vp, i32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, u64, vp, vp,
                                        C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), vp]
+    L.k4_assign_multi_dev.argtypes = [vp, i32, C.c_int32, i64, C.c_int32, vp, vp, C.POINTER(C.c_int64), vp]
     L.k4_select_hits_dev.argtypes = [vp, i64, C.c_int32, vp, vp, vp, vp]
     L.k4_format_sam_dev.argtypes = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, C.POINTER(SamNames), C.POINTER(vp),
                                     C.POINTER(u64), C.POINTER(SamStats), vp, vp]
@@ -471,6 +473,20 @@ class SfxIndex:
     def select_hits_dev(self, n, max_ml, d_rr, d_hits, d_choice, stream=0):
         """MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962): keep hits[choice % NumHits] of every accepted read."""
         self._ck(lib().k4_select_hits_dev(self.h, n, max_ml, d_rr, d_hits, d_choice, stream))
+
+    def assign_multi(self, out, hits, ml_mode, max_reads_len):
+        """CKAligner::AssignMultiMatches (`-r3` / `-r4`, KAligner.cpp:5092) over kalign_batch(pe_mode=1) results held in
+        host arrays; returns (out, hits, reads assigned)."""
+        import torch
+
+        dev = torch.device("cuda", self.info()["device"])
+        n, max_ml = hits.shape
+        d_rr = torch.from_numpy(out.view(np.uint8).copy()).to(dev)
+        d_hits = torch.from_numpy(hits.reshape(-1).view(np.uint8).copy()).to(dev)
+        na = C.c_int64(0)
+        self._ck(lib().k4_assign_multi_dev(self.h, ml_mode, max_reads_len, n, max_ml, d_rr.data_ptr(), d_hits.data_ptr(),
+                                           C.byref(na), 0))
+        return (d_rr.cpu().numpy().view(RESULT_DTYPE), d_hits.cpu().numpy().view(HIT_DTYPE).reshape(n, max_ml), na.value)
 
     def select_hits(self, out, hits, choice):
         """select_hits_dev over host arrays (kalign_batch's out / hits, uint32 draws); returns the new (out, hits)."""

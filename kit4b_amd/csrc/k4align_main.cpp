@@ -193,7 +193,7 @@ int main(int argc, char** argv) {
   const bool pe = !o.in2.empty();
   // multi-loci modes (KAlignerCL.cpp:686-707): 0 slough, 1 statistics only, 5 report every locus up to -R; the modes that
   // pick or cluster one locus (2 random, 3/4 AssignMultiMatches) are not part of this path
-  if (o.ml_mode != 0 && o.ml_mode != 1 && o.ml_mode != 2 && o.ml_mode != 5) { fprintf(stderr, "k4align: -r%d is not supported (0, 1, 2 and 5 are)\n", o.ml_mode); return 1; }
+  if (o.ml_mode < 0 || o.ml_mode > 5) { fprintf(stderr, "k4align: -r%d is not supported (0..5 are)\n", o.ml_mode); return 1; }
   if (o.ml_mode != 0 && pe) { fprintf(stderr, "k4align: multiloci processing '-r%d' not supported in paired end processing\n", o.ml_mode); return 1; }
   if (o.n_shards < 1 || o.shard < 0 || o.shard >= o.n_shards) { fprintf(stderr, "k4align: -S i/N needs 0 <= i < N\n"); return 1; }
   if ((o.clamp || o.best) && o.ml_mode != 5) { fprintf(stderr, "k4align: -X / -N are supported together with -r5 only\n"); return 1; }
@@ -220,9 +220,13 @@ int main(int argc, char** argv) {
           (unsigned long long)info.tot_seqs_len, mcl);
   auto t_open = std::chrono::steady_clock::now();
 
+  if ((o.ml_mode == 3 || o.ml_mode == 4) && (o.batch_mb > 0 || o.n_shards > 1)) {
+    fprintf(stderr, "k4align: -r3 / -r4 cluster over all reads of the run; they cannot be combined with -b or -S\n");
+    return 1;
+  }
   if (o.batch_mb > 0 && o.n_shards > 1) { fprintf(stderr, "k4align: -S slices the whole input; it cannot be combined with -b\n"); return 1; }
   k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, max_ml,
-                         o.ml_mode == 5 ? (o.best ? 4 : o.clamp ? 3 : 2) : o.ml_mode == 2 ? 2 : o.ml_mode == 1 ? 1 : 0,
+                         o.ml_mode == 5 ? (o.best ? 4 : o.clamp ? 3 : 2) : o.ml_mode == 2 ? 2 : o.ml_mode != 0 ? 1 : 0,
                          mcl, slides};
   k4_pe_params pp = {o.pe_mode, o.pair_min, o.pair_max, o.pair_strand};
   k4_sam_stats tot;
@@ -286,6 +290,11 @@ int main(int argc, char** argv) {
         CK(k4_alloc_device(ix, (uint64_t)n * max_ml * sizeof(k4_hit), &d_hits));
         CK(k4_reserve(ix, n, (int32_t)max_len, max_ml));
         CK(k4_kalign_batch_dev(ix, &kp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_rr, d_hits, nullptr));
+        if (o.ml_mode == 3 || o.ml_mode == 4) {  // AssignMultiMatches (KAligner.cpp:5092): clusters over all reads of the run
+          int64_t n_assigned = 0;
+          CK(k4_assign_multi_dev(ix, o.ml_mode, (int32_t)max_len, n, max_ml, d_rr, d_hits, &n_assigned, nullptr));
+          fprintf(stderr, "k4align: %lld multi-aligned reads assigned to one locus by clustering\n", (long long)n_assigned);
+        }
         if (o.ml_mode == 2) {
           // eMLrand (KAligner.cpp:9945-9962): rand() once per read within the instance limit, in load order -- what the
           // reference does when it runs one thread (with more its draws depend on thread timing).  The draws are a private

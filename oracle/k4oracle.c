@@ -1141,3 +1141,180 @@ int k4o_kalign_pe_batch(const k4o_index* ix, const k4o_kalign_params* kp, const 
   pthread_mutex_destroy(&j.mtx);
   return j.bad ? -3 : 0;
 }
+
+/* ---- AssignMultiMatches: KAligner.cpp:4913-5258 ------------------------------------------------------------------ */
+typedef struct {
+  uint32_t read_id; /* load order + 1 */
+  uint32_t slot;
+  k4o_hit h;
+  uint16_t score;
+  uint8_t mh, mha, hl; /* FlagMH, FlagMHA, FlagHL (4 clustunique, 5 clustany) */
+} mm_ent;
+
+#define MM_UNIQ 0x8000u /* cUniqueClustFlg, KAligner.h:96-101 */
+enum { MM_OVERLAP = 10, MM_USCORE = 5, MM_MSCORE = 1, MM_SCALE = 10, MM_MINSCORE = 50 };
+
+static int mm_cmp_loci(const void* a, const void* b) { /* SortMultiHits, KAligner.cpp:11019-11053 */
+  const mm_ent *x = (const mm_ent*)a, *y = (const mm_ent*)b;
+  if (x->h.chrom_id != y->h.chrom_id) return x->h.chrom_id < y->h.chrom_id ? -1 : 1;
+  if (x->h.match_loci != y->h.match_loci) return x->h.match_loci < y->h.match_loci ? -1 : 1;
+  if (x->h.match_len != y->h.match_len) return x->h.match_len < y->h.match_len ? -1 : 1;
+  if (x->h.mismatches != y->h.mismatches) return x->h.mismatches < y->h.mismatches ? -1 : 1;
+  if (x->h.strand != y->h.strand) return x->h.strand < y->h.strand ? -1 : 1;
+  if (x->read_id != y->read_id) return x->read_id < y->read_id ? -1 : 1;
+  return 0;
+}
+
+static int mm_cmp_read(const void* a, const void* b) { /* SortMultiHitReadIDs, KAligner.cpp:11058-11098 */
+  const mm_ent *x = (const mm_ent*)a, *y = (const mm_ent*)b;
+  if (x->read_id != y->read_id) return x->read_id < y->read_id ? -1 : 1;
+  if (x->score != y->score) return x->score > y->score ? -1 : 1;
+  if (x->h.chrom_id != y->h.chrom_id) return x->h.chrom_id < y->h.chrom_id ? -1 : 1;
+  if (x->h.match_len != y->h.match_len) return x->h.match_len < y->h.match_len ? -1 : 1;
+  if (x->h.mismatches != y->h.mismatches) return x->h.mismatches < y->h.mismatches ? -1 : 1;
+  if (x->h.match_loci != y->h.match_loci) return x->h.match_loci < y->h.match_loci ? -1 : 1;
+  if (x->h.strand != y->h.strand) return x->h.strand < y->h.strand ? -1 : 1;
+  return 0;
+}
+
+static void mm_score_one(mm_ent* e, int64_t n, int64_t i, int ml_mode, uint32_t max_reads_len) { /* :4975-5081 */
+  mm_ent* cur = &e[i];
+  const uint32_t cs = cur->h.match_loci, clen = cur->h.match_len, cend = cs + clen - 1;
+  uint32_t score;
+  cur->score = 0;
+  for (int64_t j = i - 1; j >= 0; j--) { /* upstream */
+    const mm_ent* c = &e[j];
+    if (c->h.chrom_id != cur->h.chrom_id) break;
+    if (cs - c->h.match_loci >= max_reads_len) break;
+    const uint32_t ce = c->h.match_loci + c->h.match_len - 1;
+    if (ce < cs + MM_OVERLAP) continue;
+    uint32_t ov = ce - cs;
+    if (clen < ov) ov = clen;
+    if ((ml_mode == 3 && c->mh) || ((cur->score & MM_UNIQ) && (cur->score & ~MM_UNIQ) >= 0x1fff)) continue;
+    if (c->h.strand != cur->h.strand || c->read_id == cur->read_id) continue;
+    if (!c->mh) {
+      score = 1 + (ov * MM_USCORE) / MM_SCALE;
+      if (cur->score & MM_UNIQ) score += cur->score & ~MM_UNIQ;
+      if (score > 0x1fff) score = 0x1fff;
+      cur->score = (uint16_t)(score | MM_UNIQ);
+      if (score == 0x1fff) break;
+    } else if (!(cur->score & MM_UNIQ)) {
+      score = 1 + (ov * MM_MSCORE) / MM_SCALE;
+      score += cur->score & ~MM_UNIQ;
+      if (score > 0x1fff) score = 0x1fff;
+      cur->score = (uint16_t)score;
+    }
+  }
+  for (int64_t j = i + 1; j < n; j++) { /* downstream */
+    const mm_ent* c = &e[j];
+    if (c->h.chrom_id != cur->h.chrom_id) break;
+    if (c->h.match_loci > cend - (uint32_t)MM_OVERLAP) break;
+    uint32_t ov = cend - c->h.match_loci;
+    if (c->h.match_len < ov) ov = c->h.match_len;
+    if ((ml_mode == 3 && c->mh) || ((cur->score & MM_UNIQ) && (cur->score & ~MM_UNIQ) >= 0x3fff)) continue;
+    if (c->h.strand != cur->h.strand || c->read_id == cur->read_id) continue;
+    if (!c->mh) {
+      score = 1 + (ov * MM_USCORE) / MM_SCALE;
+      if (cur->score & MM_UNIQ) score += cur->score & ~MM_UNIQ;
+      if (score > 0x3fff) score = 0x3fff;
+      cur->score = (uint16_t)(score | MM_UNIQ);
+      if (score == 0x3fff) break;
+    } else if (!(cur->score & MM_UNIQ)) {
+      score = 1 + (ov * MM_MSCORE) / MM_SCALE;
+      score += cur->score & ~MM_UNIQ;
+      if (score > 0x3fff) score = 0x3fff;
+      cur->score = (uint16_t)score;
+    }
+  }
+}
+
+int64_t k4o_assign_multi_matches(int ml_mode, int max_reads_len, int64_t n_reads, int max_ml, k4o_read_result* rr,
+                                 k4o_hit* hits, int nthreads) {
+  if (ml_mode != 3 && ml_mode != 4) return -1;
+  if (nthreads < 1) nthreads = 1;
+  int64_t n = 0;
+  for (int64_t r = 0; r < n_reads; r++)
+    if (rr[r].hit_rslt == K4O_HR_HITS) n += rr[r].inst; /* AddMHitReads, KAligner.cpp:10002-10022 */
+  mm_ent* e = (mm_ent*)calloc((size_t)n + 2, sizeof(mm_ent));
+  int64_t k = 0;
+  for (int64_t r = 0; r < n_reads; r++) {
+    if (rr[r].hit_rslt != K4O_HR_HITS) continue;
+    for (int q = 0; q < rr[r].inst; q++) {
+      e[k].read_id = (uint32_t)(r + 1);
+      e[k].slot = (uint32_t)q;
+      e[k].h = hits[r * max_ml + q];
+      e[k].mh = rr[r].inst > 1;
+      k++;
+    }
+  }
+  qsort(e, (size_t)n, sizeof(mm_ent), mm_cmp_loci);
+  /* ProcAssignMultiMatches over the blocks GetClusterStartEnd hands out (:4913-4940) */
+  int64_t from = 0;
+  while (from < n) {
+    const uint32_t left = (uint32_t)(n - from);
+    uint32_t take = left;
+    if (left >= 100) {
+      take = (uint32_t)nthreads + left / (uint32_t)nthreads;
+      if (take > 2000u) take = 2000u;
+      if (take > left) take = left;
+    }
+    const mm_ent* prev = NULL;
+    for (int64_t i = from; i < from + take; i++) {
+      if (!e[i].mh) continue;
+      if (prev && prev->h.match_loci == e[i].h.match_loci && prev->h.match_len == e[i].h.match_len &&
+          prev->h.strand == e[i].h.strand && prev->h.chrom_id == e[i].h.chrom_id) {
+        e[i].score = prev->score;
+        continue;
+      }
+      mm_score_one(e, n, i, ml_mode, (uint32_t)max_reads_len);
+      prev = &e[i];
+    }
+    from += take;
+  }
+  /* the best-scoring locus of each multi-aligned read (:5119-5163) */
+  qsort(e, (size_t)n, sizeof(mm_ent), mm_cmp_read);
+  uint32_t cur_id = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (!e[i].mh || cur_id == e[i].read_id) continue;
+    cur_id = e[i].read_id;
+    const uint32_t best = e[i].score & ~MM_UNIQ;
+    if (best < MM_MINSCORE) continue;
+    if ((e[i].score & MM_UNIQ) == (e[i + 1].score & MM_UNIQ) && best < 2u * (e[i + 1].score & ~MM_UNIQ)) continue;
+    e[i].mha = 1;
+    e[i].hl = (e[i].score & MM_UNIQ) ? 4 : 5;
+  }
+  /* orphans: a locus won by clustering with other multi-aligned reads needs a neighbour that is still in play (:5168-5251) */
+  qsort(e, (size_t)n, sizeof(mm_ent), mm_cmp_loci);
+  int64_t assigned = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (!e[i].mha) continue;
+    int accept = 1;
+    if (e[i].hl == 5) {
+      accept = 0;
+      for (int64_t j = i - 1; j >= 0; j--) {
+        const uint32_t dist = e[i].h.match_loci - e[j].h.match_loci;
+        if (dist > (uint32_t)(MM_OVERLAP + (int)e[j].h.match_len)) break;
+        if (e[j].h.chrom_id != e[i].h.chrom_id) break;
+        if (!e[j].mh || e[j].mha == 1) { accept = 1; break; }
+      }
+      if (!accept)
+        for (int64_t j = i + 1; j < n; j++) {
+          const uint32_t dist = e[j].h.match_loci - e[i].h.match_loci;
+          if (dist > (uint32_t)(MM_OVERLAP + (int)e[i].h.match_len)) break;
+          if (e[j].h.chrom_id != e[i].h.chrom_id) break;
+          if (!e[j].mh || e[j].mha == 1) { accept = 1; break; }
+        }
+      if (!accept) e[i].mha = 0;
+    }
+    if (accept) {
+      const int64_t r = (int64_t)e[i].read_id - 1;
+      hits[r * max_ml] = e[i].h;
+      rr[r].num_hits = 1;
+      rr[r].nar = K4O_NAR_ACCEPTED;
+      rr[r].inst = 1;
+      assigned++;
+    }
+  }
+  free(e);
+  return assigned;
+}

@@ -168,6 +168,15 @@ int k4o_kalign_pe_batch(const k4o_index* ix, const k4o_kalign_params* kp, const 
                         const uint8_t* reads1, const uint64_t* offs1, const uint32_t* lens1, const uint8_t* reads2,
                         const uint64_t* offs2, const uint32_t* lens2, k4o_pe_read* out, int nthreads);
 
+/* CKAligner::AssignMultiMatches (KAligner.cpp:5092-5258) with ProcAssignMultiMatches (:4944-5085) over the results of
+ * k4o_align_batch run with pe_mode 1 (a read within the instance limit keeps its inst loci; unique ones are accepted):
+ * ml_mode 3 = eMLuniq (`-r3`, cluster with uniquely aligned reads only), 4 = eMLmulti (`-r4`).  A multi-aligned read that
+ * wins a locus becomes accepted with that locus in slot 0 (NumHits 1, LowHitInstances 1).  nthreads only shapes the
+ * blocks GetClusterStartEnd (:4913-4940) hands out, which bound the reference's copy-the-previous-score shortcut.
+ * Returns the number of reads assigned. */
+int64_t k4o_assign_multi_matches(int ml_mode, int max_reads_len, int64_t n_reads, int max_ml, k4o_read_result* rr,
+                                 k4o_hit* hits, int nthreads);
+
 void k4o_revcomp(uint8_t* seq, int len);                                      /* SeqTrans.cpp:497-545 */
 
 #ifdef __cplusplus

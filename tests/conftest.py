@@ -24,6 +24,17 @@ def golden_dir():
 
 
 @pytest.fixture(scope="session")
+def g2_path(golden_dir, tmp_path_factory):
+    """tests/golden/g2.sfx.xz (the repeat-family genome of the `-r3/-r4` cases) unpacked to a temp file"""
+    import lzma
+
+    p = tmp_path_factory.mktemp("golden") / "g2.sfx"
+    with lzma.open(os.path.join(golden_dir, "g2.sfx.xz"), "rb") as f, open(p, "wb") as g:
+        g.write(f.read())
+    return str(p)
+
+
+@pytest.fixture(scope="session")
 def g1_el5_path(golden_dir, tmp_path_factory):
     """tests/golden/g1_el5.sfx.xz unpacked to a temp file"""
     import lzma

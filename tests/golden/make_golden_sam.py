@@ -34,6 +34,12 @@ CASES = {
     "se_r2_R8": (["-s2", "-r2", "-R8"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4327, n_prob=0.02, edge_frac=0.05)[0]),
     "se_r5_R8_N": (["-s3", "-r5", "-R8", "-N"], lambda ch: synth.make_reads(ch, 3000, 110, seed=4326, sub_lambda=1.5, n_prob=0.02, edge_frac=0.05)[0]),
 }
+# MLMode eMLuniq / eMLmulti (`-r3` / `-r4`): AssignMultiMatches (KAligner.cpp:5092) gives a multi-aligned read the locus that
+# clusters with other reads; on the repeat-family genome synth.cluster_genome(), whose index the reference builds here too
+CLUSTER_CASES = {
+    "se_r3_R8": ["-s2", "-r3", "-R8"],
+    "se_r4_R8": ["-s2", "-r4", "-R8"],
+}
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # case names: regenerate just these (others keep their files)
 PE_CASES = {
     "pe_u2": (["-s2", "-U2", "-d200", "-D600"], dict(seed=99, n_prob=0.02, random_mate_frac=0.03)),
@@ -41,10 +47,10 @@ PE_CASES = {
 }
 
 
-def run(tmp, name, args, files):
+def run(tmp, name, args, files, sfx=os.path.join(HERE, "g1.sfx")):
     sam = os.path.join(tmp, name + ".sam")
     log = os.path.join(tmp, name + ".log")
-    cmd = [NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", sam, "-T", "1" if "-r2" in args else "4", "-F", log] + args + files
+    cmd = [NGS, "kalign", "-I", sfx, "-o", sam, "-T", "1" if "-r2" in args else "4", "-F", log] + args + files
     subprocess.run(cmd, check=True, capture_output=True)
     hist = {}
     for line in open(log):
@@ -72,6 +78,22 @@ def main():
                 g.write(f.read())
             meta[name] = dict(args=args, nar=hist)
             print(name, hist)
+        if not ONLY or any(c in ONLY for c in CLUSTER_CASES):
+            names2, chroms2 = synth.cluster_genome()
+            g2fa, g2 = os.path.join(tmp, "g2.fa"), os.path.join(tmp, "g2.sfx")
+            synth.write_fasta(g2fa, chroms2, names=names2)
+            subprocess.run([NGS, "index", "-i", g2fa, "-o", g2, "-r", "g2", "-T", "4", "-F", os.path.join(tmp, "g2.log")],
+                           check=True, capture_output=True)
+            with open(g2, "rb") as f, lzma.open(os.path.join(HERE, "g2.sfx.xz"), "wb", preset=9) as g:
+                g.write(f.read())
+            fa = os.path.join(tmp, "cluster.fa")
+            synth.write_fasta(fa, synth.make_reads(chroms2, 9000, 80, seed=4402, n_prob=0.01, edge_frac=0.02)[0])
+            with open(fa, "rb") as f, lzma.open(os.path.join(HERE, "sam_se_cluster.fa.xz"), "wb", preset=9) as g:
+                g.write(f.read())
+            for name, args in CLUSTER_CASES.items():
+                hist = run(tmp, name, args, ["-i", fa], sfx=g2)
+                meta[name] = dict(args=args, nar=hist, index="g2", reads="sam_se_cluster.fa.xz")
+                print(name, hist)
         for name, (args, kw) in PE_CASES.items():
             if ONLY and name not in ONLY:
                 continue

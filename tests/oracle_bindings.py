@@ -220,6 +220,14 @@ class Oracle:
                     counters=dict(n_lookup=ctr.n_lookup, n_probe=ctr.n_probe, n_cand=ctr.n_cand))
 
 
+    def assign_multi_matches(self, out, hits, ml_mode, max_reads_len, threads=4):
+        """CKAligner::AssignMultiMatches (`-r3` / `-r4`) over kalign_batch(pe_mode=1) results, in place."""
+        n, max_ml = hits.shape
+        self.L.k4o_assign_multi_matches.restype = C.c_int64
+        return self.L.k4o_assign_multi_matches(C.c_int(ml_mode), C.c_int(max_reads_len), C.c_int64(n), C.c_int(max_ml),
+                                               C.c_void_p(out.ctypes.data), C.c_void_p(hits.ctypes.data), C.c_int(threads))
+
+
 def _kalign_pe(L, fn, h, reads1, reads2, pe_mode, pair_min_len, pair_max_len, pair_strand, threads, **kw):
     c1, o1, l1 = reads1 if isinstance(reads1, tuple) else flatten_reads(reads1)
     c2, o2, l2 = reads2 if isinstance(reads2, tuple) else flatten_reads(reads2)

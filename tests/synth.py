@@ -102,6 +102,26 @@ def golden_genome():
                        tandem=6)
 
 
+def cluster_genome():
+    """The genome behind tests/golden/g2.sfx.xz: many small repeat families (2-3 diverged copies each), so that plenty of
+    reads align to a few loci and sit among uniquely aligned ones -- what AssignMultiMatches (`-r3/-r4`) works on."""
+    names, chroms = make_genome([40000, 30000, 20000], seed=GENOME_SEED + 77)
+    rng = np.random.default_rng(GENOME_SEED + 78)
+    for _ in range(70):
+        ln = int(rng.integers(120, 320))
+        fam = rng.integers(0, 4, size=ln, dtype=np.uint8)
+        for _ in range(int(rng.integers(2, 4))):
+            c = int(rng.integers(0, len(chroms)))
+            p_ = int(rng.integers(0, len(chroms[c]) - ln))
+            copy = fam.copy()
+            m = rng.random(ln) < 0.015
+            copy[m] = (copy[m] + rng.integers(1, 4, size=int(m.sum()))) % 4
+            if rng.random() < 0.5:
+                copy = revcomp(copy)
+            chroms[c][p_:p_ + ln] = copy
+    return names, chroms
+
+
 BASES = "ACGTN"
 
 
@@ -143,7 +163,8 @@ def make_pe_reads(chroms, n_pairs, read_len, seed=READS_SEED + 3, frag_min=300, 
     return pe1, pe2, truth
 
 
-def write_fasta(path, reads, prefix="rd"):
+def write_fasta(path, reads, prefix="rd", names=None):
     with open(path, "w") as f:
         for i, r in enumerate(reads):
-            f.write(">%s%06d synthetic\n%s\n" % (prefix, i + 1, "".join(BASES[b] for b in r)))
+            hdr = names[i] if names else "%s%06d synthetic" % (prefix, i + 1)
+            f.write(">%s\n%s\n" % (hdr, "".join(BASES[b] for b in r)))

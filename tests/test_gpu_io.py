@@ -258,7 +258,7 @@ def test_k4align_edge_inputs(golden_dir, tmp_path):
     assert p.returncode == 0, p.stderr
     recs = [l for l in lines if not l.startswith("@")]
     assert len(recs) == 1 and recs[0].split("\t")[:4] == ["q1", "0", "chr2", "1001"]
-    p, _ = run(b">a\n" + seq + b"\n", "-r3")
+    p, _ = run(b">a\n" + seq + b"\n", "-r6")
     assert p.returncode != 0 and "not supported" in p.stderr
 
 

@@ -219,6 +219,7 @@ def _kalign_args(args):
         elif a.startswith("-R"): kw["max_ml"] = int(a[2:])
         elif a == "-r5": kw["pe_mode"] = max(kw.get("pe_mode", 0), 2)  # MLMode eMLall: every instance reported
         elif a == "-r2": kw["pe_mode"] = 2                              # MLMode eMLrand: ... then one of them picked
+        elif a in ("-r3", "-r4"): kw["pe_mode"] = 1                     # eMLuniq / eMLmulti: multi-aligned reads keep their loci
         elif a == "-X": kw["pe_mode"] = max(kw.get("pe_mode", 0), 3)   # ... reads over the -R limit clamped to it
         elif a == "-N": kw["pe_mode"] = 4                               # ... through LocateBestMatches
     return kw, pe
@@ -242,17 +243,23 @@ def _pick_rand_on_device(ix, out, hits):
 
 
 @pytest.mark.parametrize("case", sorted(SAM_CASES))
-def test_reference_sam_end_to_end(k4, golden_dir, case):
+def test_reference_sam_end_to_end(k4, golden_dir, g2_path, case):
     """The records `ngskit4b kalign` wrote (SE and PE incl. mate rescue) are reproduced from the GPU results."""
     kw, pe = _kalign_args(SAM_CASES[case]["args"])
-    ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    ix = k4.SfxIndex.open(g2_path if SAM_CASES[case].get("index") == "g2" else os.path.join(golden_dir, "g1.sfx"))
     ix.set_max_iter(5000 if kw["pmode"] == 0 else 10000)
     _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
     if case.startswith("se_"):
-        names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % case))
+        names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, SAM_CASES[case].get("reads", "sam_%s.fa.xz" % case)))
         r = ix.kalign_batch(reads, **kw)
         from test_oracle_sam_golden import expand_all_hits
 
+        clust = [int(a[2:]) for a in SAM_CASES[case]["args"] if a in ("-r3", "-r4")]
+        if clust:  # AssignMultiMatches on the device
+            multi = ((r["out"]["hit_rslt"] == 1) & (r["out"]["inst"] > 1)).sum()
+            r["out"], r["hits"], got = ix.assign_multi(r["out"], r["hits"], clust[0], max(len(x) for x in reads))
+            assert multi > 100 and 20 < got < multi and (r["hits"]["reserved"] == 0).all()
+            r["out"]["num_hits"][r["out"]["nar"] != 1] = 0
         if "-r2" in SAM_CASES[case]["args"]:
             r["out"], r["hits"] = _pick_rand_on_device(ix, r["out"], r["hits"])
         names, reads, res = expand_all_hits(names, reads, r["out"], r["hits"])
@@ -332,15 +339,16 @@ def _unxz(src, dst):
 
 
 @pytest.mark.parametrize("case", sorted(SAM_CASES))
-def test_k4align_writes_the_reference_sam(k4, golden_dir, tmp_path, case):
+def test_k4align_writes_the_reference_sam(k4, golden_dir, g2_path, tmp_path, case):
     """`k4align` (C++ over the C ABI) against the SAM `ngskit4b kalign` wrote for the same reads, index and options:
     identical header (but @PG) and identical records (the reference's order among equal keys is unspecified)."""
     exe = os.path.join(ROOT, "kit4b_amd", "k4align")
     assert os.path.exists(exe)
     out = str(tmp_path / "out.sam")
-    cmd = [exe, "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out] + SAM_CASES[case]["args"]
+    sfx = g2_path if SAM_CASES[case].get("index") == "g2" else os.path.join(golden_dir, "g1.sfx")
+    cmd = [exe, "-I", sfx, "-o", out] + SAM_CASES[case]["args"]
     if case.startswith("se_"):
-        cmd += ["-i", _unxz(os.path.join(golden_dir, "sam_%s.fa.xz" % case), str(tmp_path / "r.fa"))]
+        cmd += ["-i", _unxz(os.path.join(golden_dir, SAM_CASES[case].get("reads", "sam_%s.fa.xz" % case)), str(tmp_path / "r.fa"))]
     else:
         cmd += ["-i", _unxz(os.path.join(golden_dir, "sam_%s_1.fa.xz" % case), str(tmp_path / "r1.fa")),
                 "-u", _unxz(os.path.join(golden_dir, "sam_%s_2.fa.xz" % case), str(tmp_path / "r2.fa"))]
@@ -695,3 +703,60 @@ def test_reference_sam_on_5byte_index_with_64bit_table(k4, golden_dir, g1_el5_pa
         got = samutil.sam_records(names, reads, res, CHROMS, paired=True)
     assert sorted(got) == sorted(recs)
     ix.close()
+
+
+def _fabricated_loci(seed, n_reads, max_ml, span):
+    """AlignRead-like results made up directly: unique and multi-aligned reads piled densely on three chromosomes, the
+    third holding loci of multi-aligned reads only (so that loci get won by clustering with other multi-aligned reads and
+    the orphan walk has chains to follow)."""
+    import kit4b_amd as k4m
+
+    rng = np.random.default_rng(seed)
+    out = np.zeros(n_reads, dtype=k4m.RESULT_DTYPE)
+    hits = np.zeros((n_reads, max_ml), dtype=k4m.HIT_DTYPE)
+    hot = rng.integers(0, span, size=12)  # piles on chromosome 3
+    for i in range(n_reads):
+        u = rng.random()
+        if u < 0.05:
+            out[i]["hit_rslt"], out[i]["nar"] = 0, 3
+            continue
+        if u < 0.08:  # over the instance limit
+            out[i]["hit_rslt"], out[i]["inst"], out[i]["nar"] = 3, max_ml + 1, 5
+            continue
+        inst = 1 if u < 0.55 else int(rng.integers(2, max_ml + 1))
+        ln = int(rng.integers(50, 121))
+        seen = set()
+        for q in range(inst):
+            while True:
+                if inst > 1 and rng.random() < 0.45:
+                    c, p = 3, int(hot[rng.integers(0, len(hot))] + rng.integers(-60, 61)) % span
+                else:
+                    c, p = int(rng.integers(1, 3)), int(rng.integers(0, span))
+                s = int(rng.choice([43, 45]))
+                if (c, p, s) not in seen:
+                    seen.add((c, p, s))
+                    break
+            hits[i, q] = (c, p, ln, s, int(rng.integers(0, 4)), 0)
+        out[i]["hit_rslt"], out[i]["inst"], out[i]["low_mm"] = 1, inst, 0
+        out[i]["nar"], out[i]["num_hits"] = (1, 1) if inst == 1 else (5, inst)
+    return out, hits
+
+
+@pytest.mark.parametrize("ml_mode,seed,n_reads,span", [(4, 1, 6000, 3000), (3, 2, 6000, 3000), (4, 3, 30000, 40000), (3, 4, 2000, 400),
+                                                       (4, 5, 2000, 400)])
+def test_assign_multi_matches_vs_oracle(k4, oracle, ml_mode, seed, n_reads, span):
+    """k4_assign_multi_dev == the oracle's AssignMultiMatches restatement (pinned to the reference by the se_r3 / se_r4
+    goldens) on made-up loci dense enough for every branch: scores next to unique and next to multi-aligned reads, ties,
+    winners by clustering with multi-aligned reads and the orphan walk over them."""
+    out, hits = _fabricated_loci(seed, n_reads, 6, span)
+    o_out, o_hits = out.copy(), hits.copy()
+    want = oracle.assign_multi_matches(o_out, o_hits, ml_mode, 120, threads=1)
+    ix = k4.SfxIndex.open(os.path.join(GOLDEN, "g1.sfx"))
+    g_out, g_hits, got = ix.assign_multi(out, hits, ml_mode, 120)
+    ix.close()
+    assert got == want and want > 10
+    assert (g_out == o_out).all()
+    acc = g_out["nar"] == 1
+    assert (g_hits[acc, 0] == o_hits[acc, 0]).all() and (g_hits["reserved"] == 0).all()
+    changed = acc & (out["nar"] == 5)
+    assert changed.sum() == want

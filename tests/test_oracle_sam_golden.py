@@ -28,6 +28,7 @@ def kalign_args(args):
         elif a.startswith("-R"): kw["max_ml"] = int(a[2:])
         elif a == "-r5": kw["pe_mode"] = max(kw.get("pe_mode", 0), 2)  # MLMode eMLall: every instance reported
         elif a == "-r2": kw["pe_mode"] = 2                              # MLMode eMLrand: ... then one of them picked
+        elif a in ("-r3", "-r4"): kw["pe_mode"] = 1                     # eMLuniq / eMLmulti: multi-aligned reads keep their loci
         elif a == "-X": kw["pe_mode"] = max(kw.get("pe_mode", 0), 3)   # ... reads over the -R limit clamped to it
         elif a == "-N": kw["pe_mode"] = 4                               # ... through LocateBestMatches
     return kw, pe
@@ -64,19 +65,25 @@ def check_hist(nars, expect):
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if c.startswith("se_")))
-def test_se_matches_reference_sam(oracle, golden_dir, case):
+def test_se_matches_reference_sam(oracle, golden_dir, g2_path, case):
     kw, _ = kalign_args(CASES[case]["args"])
-    names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % case))
-    h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, CASES[case].get("reads", "sam_%s.fa.xz" % case)))
+    h = oracle.open(g2_path if CASES[case].get("index") == "g2" else os.path.join(golden_dir, "g1.sfx"))
     oracle.set_max_iter(h, 5000 if kw["pmode"] == 0 else 10000)
     r = oracle.kalign_batch(h, reads, **kw)
+    clust = [int(a[2:]) for a in CASES[case]["args"] if a in ("-r3", "-r4")]
+    if clust:  # AssignMultiMatches; the reference ran with 4 threads
+        multi = ((r["out"]["hit_rslt"] == 1) & (r["out"]["inst"] > 1)).sum()
+        got = oracle.assign_multi_matches(r["out"], r["hits"], clust[0], max(len(x) for x in reads), threads=4)
+        assert multi > 100 and 20 < got < multi
+        r["out"]["num_hits"][r["out"]["nar"] != 1] = 0
     rand = "-r2" in CASES[case]["args"]
     if rand:
         assert (r["out"]["num_hits"] > 1).sum() > 5
         pick_rand_hits(r["out"], r["hits"])
     names, reads, res = expand_all_hits(names, reads, r["out"], r["hits"])
     _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
-    if kw.get("pe_mode", 0) >= 2 and not rand:  # the reference's own tallies are per reported locus in this mode (KAligner.cpp:571-600)
+    if kw.get("pe_mode", 0) >= 2 and not rand and not clust:  # the reference's own tallies are per reported locus in this mode (KAligner.cpp:571-600)
         assert CASES[case]["nar"]["AA"] == len(recs) == sum(1 for x in res if x["nar"] == 1)
         assert (r["out"]["num_hits"] > 1).sum() > 5
     else:
