@@ -27,7 +27,8 @@
 namespace {
 
 struct Opts {
-  std::string in1, in2, sfx, out;
+  std::vector<std::string> in1, in2;  // -i / -u may repeat: the files are read one after the other (KAlignerCL.cpp: up to cRRMaxInFiles)
+  std::string sfx, out;
   int max_subs = 5, min_edit = 1, pmode = 0, max_ns = 1, pe_mode = 0, pair_min = 100, pair_max = 1000, pair_strand = 0;
   int min_len = 50, max_len = 500;  // cDfltMinAcceptReadLen / cDfltMaxAcceptReadLen, KAligner.h:112-113
   int ml_mode = 0, max_multi = 0;   // -r / -R (etMLMode, KAligner.h:250-258)
@@ -96,15 +97,28 @@ void free_parsed(Parsed& P) {
   P = Parsed();
 }
 
-// a reads file read in portions: buf holds the text not yet consumed
+// the reads files of one end, read in portions as one text (a file that lacks its last newline gets one): buf holds the
+// text not yet consumed
 struct Stream {
   gzFile f = nullptr;
+  std::vector<std::string> paths;
+  size_t next = 0;
   std::vector<uint8_t> buf;
   bool eof = false;
-  bool open(const std::string& path) {
-    f = gzopen(path.c_str(), "rb");
+  bool open_next() {
+    if (f) gzclose(f);
+    f = gzopen(paths[next++].c_str(), "rb");
     if (f) gzbuffer(f, 1 << 20);
     return f != nullptr;
+  }
+  bool open(const std::vector<std::string>& files) {
+    paths = files;
+    for (const std::string& q : paths) {  // all of them must be readable before anything is aligned
+      FILE* t = fopen(q.c_str(), "rb");
+      if (!t) { fprintf(stderr, "k4align: unable to open '%s'\n", q.c_str()); return false; }
+      fclose(t);
+    }
+    return !paths.empty() && open_next();
   }
   bool fill(uint64_t want) {  // until buf holds `want` bytes or the file ends
     while (!eof && buf.size() < want) {
@@ -114,7 +128,11 @@ struct Stream {
       const int got = gzread(f, buf.data() + old, (unsigned)step);
       if (got < 0) return false;
       buf.resize(old + (size_t)got);
-      if (got == 0) eof = true;
+      if (got == 0) {
+        if (next == paths.size()) { eof = true; break; }
+        if (!buf.empty() && buf.back() != '\n') buf.push_back('\n');
+        if (!open_next()) return false;
+      }
     }
     return true;
   }
@@ -126,8 +144,8 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 
 void usage() {
   fprintf(stderr,
-          "k4align -i reads.f[aq][.gz] [-u mates] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0|1|5] [-R maxmulti=5] [-X] [-N] [-S i/N] [-b MB per batch] [-g gpu=0]\n");
+          "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-S i/N] [-b MB per batch] [-g gpu=0]\n");
 }
 
 }  // namespace
@@ -164,8 +182,8 @@ int main(int argc, char** argv) {
     if (a.size() < 2 || a[0] != '-') { usage(); return 1; }
     auto val = [&]() -> std::string { return a.size() > 2 ? a.substr(2) : (i + 1 < argc ? std::string(argv[++i]) : std::string()); };
     switch (a[1]) {
-      case 'i': o.in1 = val(); break;
-      case 'u': o.in2 = val(); break;
+      case 'i': o.in1.push_back(val()); break;
+      case 'u': o.in2.push_back(val()); break;
       case 'I': o.sfx = val(); break;
       case 'o': o.out = val(); break;
       case 's': o.max_subs = atoi(val().c_str()); break;

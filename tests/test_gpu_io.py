@@ -386,3 +386,45 @@ def test_k4align_streamed_batches_equal_the_single_run(golden_dir, tmp_path, cas
     if "-r5" not in cases[case]["args"]:
         for name, n in cases[case]["nar"].items():
             assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["se_s2", "pe_u1"])
+def test_k4align_several_input_files(golden_dir, tmp_path, case):
+    """`-i a -i b [-u a2 -u b2]`: the files are read one after the other as `ngskit4b kalign` does (the reference run on the
+    split input writes the single-file golden SAM); one part gzipped, one without its last newline."""
+    import gzip
+    import json
+    import lzma
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(golden_dir, "sam_cases.json")))
+
+    def split(name, tag):
+        lines = lzma.open(os.path.join(golden_dir, name)).read().decode().splitlines()
+        cut = (len(lines) // 3) & ~1  # FASTA, two lines per read
+        a, b = str(tmp_path / (tag + "_a.fa")), str(tmp_path / (tag + "_b.fa.gz"))
+        open(a, "w").write("\n".join(lines[:cut]))  # no newline at the end
+        gzip.open(b, "wt").write("\n".join(lines[cut:]) + "\n")
+        return a, b
+
+    if case.startswith("se_"):
+        a, b = split("sam_%s.fa.xz" % case, "r")
+        files = ["-i", a, "-i", b]
+    else:
+        a1, b1 = split("sam_%s_1.fa.xz" % case, "r1")
+        a2, b2 = split("sam_%s_2.fa.xz" % case, "r2")
+        files = ["-i", a1, "-i", b1, "-u", a2, "-u", b2]
+    out = str(tmp_path / "o.sam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out]
+                       + cases[case]["args"] + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    want = [l for l in lzma.open(os.path.join(golden_dir, "sam_%s.sam.xz" % case)).read().decode().splitlines() if not l.startswith("@PG")]
+    assert sorted(got) == sorted(want)
+    for name, n in cases[case]["nar"].items():
+        assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-i", files[1],
+                        "-i", str(tmp_path / "missing.fa")], capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "unable to open" in p.stderr
