@@ -320,7 +320,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # K4_BENCH_FORCE_DIST=1: take the RCCL path with one rank too (a rehearsal of the N > 1 code on a one-GPU box)
+    use_dist = world > 1 or bool(os.environ.get("K4_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL over xGMI on ROCm
@@ -387,7 +389,7 @@ def main():
                                 hits.data_ptr(), stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -404,7 +406,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -418,7 +420,7 @@ def main():
         out[:, 4] = out_pe[:, 0]
         hits = out_pe[:, 6:10].contiguous()
     nar_hist = torch.bincount(out[:, 4].to(torch.int64), minlength=20)[:20]
-    if world > 1:
+    if use_dist:
         dist.all_reduce(nar_hist, op=dist.ReduceOp.SUM)  # RCCL: the only collective on this path
     nar = nar_hist.tolist()
 
@@ -584,7 +586,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     ix.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

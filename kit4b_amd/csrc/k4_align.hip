@@ -1672,6 +1672,28 @@ static int stage_in(k4_index* ix, int64_t n, const uint8_t* reads, const uint64_
   *max_len_out = max_len;
   int rc = k4_reserve(ix, n, max_len, max_hits);
   if (rc != K4_OK) return rc;
+  // small batch: everything through one pinned block (one copy up, one down instead of three and two from pageable memory)
+  const size_t in_bytes = (((size_t)n * 12 + 15) & ~(size_t)15) + tot + 64;
+  const size_t hits_off = ((size_t)n * 24 + 15) & ~(size_t)15;
+  const size_t out_bytes = hits_off + (size_t)n * max_hits * sizeof(k4_hit);
+  w.c_small = n <= K4_SMALL_READS && in_bytes <= K4_SMALL_STAGE / 2 && out_bytes <= K4_SMALL_STAGE / 2;
+  if (w.c_small) {
+    if (!w.h_small) {
+      K4_HIP(ix, hipHostMalloc((void**)&w.h_small, K4_SMALL_STAGE, hipHostMallocDefault));
+      K4_HIP(ix, hipMalloc((void**)&w.d_small, K4_SMALL_STAGE));
+    }
+    const size_t reads_off = ((size_t)n * 12 + 15) & ~(size_t)15;
+    memcpy(w.h_small, offs, (size_t)n * 8);
+    memcpy(w.h_small + (size_t)n * 8, lens, (size_t)n * 4);
+    memcpy(w.h_small + reads_off, reads, tot);
+    K4_HIP(ix, hipMemcpyAsync(w.d_small, w.h_small, reads_off + tot, hipMemcpyHostToDevice, ix->stream));
+    w.c_offs = (const uint64_t*)w.d_small;
+    w.c_lens = (const uint32_t*)(w.d_small + (size_t)n * 8);
+    w.c_reads = w.d_small + reads_off;
+    w.c_out = (int32_t*)(w.d_small + K4_SMALL_STAGE / 2);
+    w.c_hits = (k4_hit*)(w.d_small + K4_SMALL_STAGE / 2 + hits_off);
+    return K4_OK;
+  }
   if (tot + 64 > w.d_reads_cap) {
     if (w.d_reads) hipFree(w.d_reads);
     w.d_reads = nullptr;
@@ -1692,11 +1714,24 @@ static int stage_in(k4_index* ix, int64_t n, const uint8_t* reads, const uint64_
     w.stage_hits = mh;
   }
   (void)out_bytes_per_read;
+  w.c_reads = w.d_reads; w.c_offs = w.d_offs; w.c_lens = w.d_lens; w.c_out = w.d_out4; w.c_hits = w.d_hits;
   if (n) {
     K4_HIP(ix, hipMemcpyAsync(w.d_reads, reads, tot, hipMemcpyHostToDevice, ix->stream));
     K4_HIP(ix, hipMemcpyAsync(w.d_offs, offs, (size_t)n * 8, hipMemcpyHostToDevice, ix->stream));
     K4_HIP(ix, hipMemcpyAsync(w.d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
   }
+  return K4_OK;
+}
+
+// small batch: results and hits come down in one copy into the pinned block; returns where they are
+static int fetch_small(k4_index* ix, int64_t n, int max_hits, const int32_t** out, const k4_hit** hits) {
+  K4Workspace& w = ix->ws;
+  const size_t hits_off = ((size_t)n * 24 + 15) & ~(size_t)15;
+  const size_t bytes = hits_off + (size_t)n * max_hits * sizeof(k4_hit);
+  K4_HIP(ix, hipMemcpyAsync(w.h_small + K4_SMALL_STAGE / 2, w.d_small + K4_SMALL_STAGE / 2, bytes, hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipStreamSynchronize(ix->stream));
+  *out = (const int32_t*)(w.h_small + K4_SMALL_STAGE / 2);
+  *hits = (const k4_hit*)(w.h_small + K4_SMALL_STAGE / 2 + hits_off);
   return K4_OK;
 }
 
@@ -1714,24 +1749,25 @@ extern "C" int k4_align_reads_batch(k4_index* ix, const k4_align_params* p, int6
   rc = stage_in(ix, n, reads, offs, lens, p->max_hits, &max_len, 16);
   if (rc != K4_OK) return rc;
   K4Workspace& w = ix->ws;
-  int32_t* o = w.d_out4;
-  rc = k4_align_reads_batch_dev(ix, p, n, max_len, w.d_reads, w.d_offs, w.d_lens, o, o + n, o + 2 * n, o + 3 * n,
-                                w.d_hits, ix->stream);
+  int32_t* o = w.c_out;
+  rc = k4_align_reads_batch_dev(ix, p, n, max_len, w.c_reads, w.c_offs, w.c_lens, o, o + n, o + 2 * n, o + 3 * n,
+                                w.c_hits, ix->stream);
   if (rc != K4_OK) return rc;
-  if (n <= 4096) {  // small batch: one copy for the four result arrays (they are contiguous on the device), scattered here
-    int32_t tmp[4 * 4096];
-    K4_HIP(ix, hipMemcpyAsync(tmp, o, (size_t)n * 16, hipMemcpyDeviceToHost, ix->stream));
-    K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
-    K4_HIP(ix, hipStreamSynchronize(ix->stream));
-    memcpy(rslt, tmp, (size_t)n * 4); memcpy(inst, tmp + n, (size_t)n * 4);
-    memcpy(low, tmp + 2 * n, (size_t)n * 4); memcpy(nxt, tmp + 3 * n, (size_t)n * 4);
+  if (w.c_small) {
+    const int32_t* r;
+    const k4_hit* h;
+    rc = fetch_small(ix, n, p->max_hits, &r, &h);
+    if (rc != K4_OK) return rc;
+    memcpy(rslt, r, (size_t)n * 4); memcpy(inst, r + n, (size_t)n * 4);
+    memcpy(low, r + 2 * n, (size_t)n * 4); memcpy(nxt, r + 3 * n, (size_t)n * 4);
+    memcpy(hits, h, (size_t)n * p->max_hits * sizeof(k4_hit));
     return K4_OK;
   }
   K4_HIP(ix, hipMemcpyAsync(rslt, o, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(inst, o + n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(low, o + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(nxt, o + 3 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
-  K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(hits, w.c_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipStreamSynchronize(ix->stream));
   return K4_OK;
 }
@@ -1748,12 +1784,21 @@ extern "C" int k4_best_matches_batch(k4_index* ix, const k4_align_params* p, int
   rc = stage_in(ix, n, reads, offs, lens, p->max_hits, &max_len, 16);
   if (rc != K4_OK) return rc;
   K4Workspace& w = ix->ws;
-  int32_t* o = w.d_out4;
-  rc = k4_best_matches_batch_dev(ix, p, n, max_len, w.d_reads, w.d_offs, w.d_lens, o, o + n, w.d_hits, ix->stream);
+  int32_t* o = w.c_out;
+  rc = k4_best_matches_batch_dev(ix, p, n, max_len, w.c_reads, w.c_offs, w.c_lens, o, o + n, w.c_hits, ix->stream);
   if (rc != K4_OK) return rc;
+  if (w.c_small) {
+    const int32_t* r;
+    const k4_hit* h;
+    rc = fetch_small(ix, n, p->max_hits, &r, &h);
+    if (rc != K4_OK) return rc;
+    memcpy(rslt, r, (size_t)n * 4); memcpy(inst, r + n, (size_t)n * 4);
+    memcpy(hits, h, (size_t)n * p->max_hits * sizeof(k4_hit));
+    return K4_OK;
+  }
   K4_HIP(ix, hipMemcpyAsync(rslt, o, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipMemcpyAsync(inst, o + n, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
-  K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(hits, w.c_hits, (size_t)n * p->max_hits * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipStreamSynchronize(ix->stream));
   return K4_OK;
 }
@@ -1769,10 +1814,19 @@ extern "C" int k4_kalign_batch(k4_index* ix, const k4_kalign_params* p, int64_t 
   int rc = stage_in(ix, n, reads, offs, lens, p->max_ml, &max_len, 24);
   if (rc != K4_OK) return rc;
   K4Workspace& w = ix->ws;
-  rc = k4_kalign_batch_dev(ix, p, n, max_len, w.d_reads, w.d_offs, w.d_lens, w.d_out4, w.d_hits, ix->stream);
+  rc = k4_kalign_batch_dev(ix, p, n, max_len, w.c_reads, w.c_offs, w.c_lens, w.c_out, w.c_hits, ix->stream);
   if (rc != K4_OK) return rc;
-  K4_HIP(ix, hipMemcpyAsync(out, w.d_out4, (size_t)n * sizeof(k4_read_result), hipMemcpyDeviceToHost, ix->stream));
-  K4_HIP(ix, hipMemcpyAsync(hits, w.d_hits, (size_t)n * p->max_ml * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
+  if (w.c_small) {
+    const int32_t* r;
+    const k4_hit* h;
+    rc = fetch_small(ix, n, p->max_ml, &r, &h);
+    if (rc != K4_OK) return rc;
+    memcpy(out, r, (size_t)n * sizeof(k4_read_result));
+    memcpy(hits, h, (size_t)n * p->max_ml * sizeof(k4_hit));
+    return K4_OK;
+  }
+  K4_HIP(ix, hipMemcpyAsync(out, w.c_out, (size_t)n * sizeof(k4_read_result), hipMemcpyDeviceToHost, ix->stream));
+  K4_HIP(ix, hipMemcpyAsync(hits, w.c_hits, (size_t)n * p->max_ml * sizeof(k4_hit), hipMemcpyDeviceToHost, ix->stream));
   K4_HIP(ix, hipStreamSynchronize(ix->stream));
   return K4_OK;
 }

@@ -559,6 +559,8 @@ extern "C" void k4_close(k4_index* ix) {
                   w.slow_probe, w.slow_hash, w.d_reads, w.d_offs, w.d_lens, w.d_out4, w.d_hits};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  if (w.d_small) hipFree(w.d_small);
+  if (w.h_small) hipHostFree(w.h_small);
   for (void* p : {(void*)ix->pe_rr, (void*)ix->pe_hits, (void*)ix->pe_list, (void*)ix->pe_ctl, ix->rs_tasks, ix->rs_reads, ix->rs_res, ix->rs_hits})
     if (p) hipFree(p);
   if (ix->stream) hipStreamDestroy(ix->stream);

@@ -76,6 +76,12 @@ struct K4Workspace {
   int32_t* d_out4 = nullptr;     // rslt/inst/low/nxt or k4_read_result
   k4_hit* d_hits = nullptr;
   int64_t stage_reads = 0; int32_t stage_hits = 0;
+  // small host-pointer batches (the facade's AlignReads groups): one pinned block up, one down.  [0, K4_SMALL_STAGE/2):
+  // offs | lens | reads; [K4_SMALL_STAGE/2, K4_SMALL_STAGE): results | hits -- same layout in h_small and d_small
+  uint8_t* h_small = nullptr; uint8_t* d_small = nullptr;
+  // where the current host-pointer batch lives on the device (d_small or the d_* buffers above)
+  const uint8_t* c_reads = nullptr; const uint64_t* c_offs = nullptr; const uint32_t* c_lens = nullptr;
+  int32_t* c_out = nullptr; k4_hit* c_hits = nullptr; bool c_small = false;
 };
 
 struct k4_index {
@@ -125,6 +131,8 @@ int k4_check_hip(k4_index* ix, hipError_t e, const char* what);
 // k4_index.hip
 int k4i_build_device_structures(k4_index* ix, const void* d_seq_bytes, int kmer_k);
 // k4_align.hip
+#define K4_SMALL_STAGE (4u << 20)
+#define K4_SMALL_READS 4096
 int k4i_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len, const void* d_reads,
                          const void* d_offs, const void* d_lens, void* d_out, void* d_hits, void* stream, int sparse_hits);
 // k4_sabuild.hip
