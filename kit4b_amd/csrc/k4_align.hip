@@ -484,25 +484,32 @@ K4_DEV uint32_t k4d_pack_read(const uint8_t* __restrict__ src, int len, uint64_t
   constexpr int NW = NCH + 1;
   uint32_t fl = 0;
   n_ns = 0;
-  const bool aligned = (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+  // reads sit at any byte offset (150-byte reads back to back, parsed FASTQ): always load aligned words -- the word that
+  // holds the read's first byte may start up to 3 bytes before it, the one that holds its last byte may end up to 3 bytes
+  // after it, neither leaves the 4-byte cells the read itself occupies -- and shift the pair into place
+  const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3);
+  const uint32_t* __restrict__ src32 = reinterpret_cast<const uint32_t*>(src - sh);
+  const int span = len + (int)sh;  // bytes from src32 to the end of the read
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     uint64_t acc = 0;
     if (32 * c < len) {
-      uint32_t dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      const bool full = aligned && c * 32 + 32 <= len;
-      if (full) k4d_load_words<8>(reinterpret_cast<const uint32_t*>(src) + c * 8, dq);  // two 16-byte loads
+      uint32_t dq[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (c * 32 + 32 <= span) {  // two 16-byte loads
+        uint32_t d8[8];
+        k4d_load_words<8>(src32 + c * 8, d8);
+#pragma unroll
+        for (int q = 0; q < 8; q++) dq[q] = d8[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (c * 32 + q * 4 < span) dq[q] = src32[c * 8 + q];
+      }
+      if (c * 32 + 32 < span) dq[8] = src32[c * 8 + 8];
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const int base = c * 32 + q * 4;
-        uint32_t d = dq[q];
-        if (full) {
-        } else if (base + 4 <= len && aligned) d = reinterpret_cast<const uint32_t*>(src)[c * 8 + q];
-        else {
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (base + k < len) d |= (uint32_t)src[base + k] << (8 * k);
-        }
+        uint32_t d = __builtin_amdgcn_alignbyte(dq[q + 1], dq[q], sh);
         d &= 0x07070707u;
         if (base + 4 > len) d &= len > base ? (0xFFFFFFFFu >> (8 * (4 - (len - base)))) : 0u;  // bytes past the end
         // N / invalid detection on the four bytes at once: bit 2 set => symbol >= 4
