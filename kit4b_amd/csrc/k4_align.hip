@@ -30,6 +30,12 @@
 #ifndef K4_STEP_WAVES
 #define K4_STEP_WAVES 4  // waves per SIMD the step kernel is register-budgeted for
 #endif
+#ifndef K4_STEP_WAVES_LONG
+#define K4_STEP_WAVES_LONG 2  // ... for reads over 256 bp (16 packed words per strand; LDS allows one block per CU anyway)
+#endif
+#ifndef K4_STEP_WAVES_MID
+#define K4_STEP_WAVES_MID 3   // ... for 161..256 bp (8 words per strand; LDS allows three blocks per CU)
+#endif
 #define K4_CHUNK 512         // survivor slots a wave reserves per atomic
 #define K4_NO_READ 0xFFFFFFFFu  // hole in a survivor list
 #define K4_ROW_WORDS(nch) (2 * (nch) + 2)  // survivor row: forward + reverse-complement words, then the two offset-0 memos
@@ -194,15 +200,17 @@ K4_DEV void k4d_push_slow(const K4AlignArgs& a, int64_t i, int step) {
 }
 
 // ==== fast kernel ==================================================================================================
+// threads per block: the per-lane LDS columns of a 16-word read (257..512 bp) would leave room for one 256-thread block per CU
+#define K4_BS(nch) ((nch) >= 16 ? 128 : 256)
 template <int NCH>
 struct K4Lane {
-  const uint64_t* rd;  // LDS: word (s*NW + c) of this lane's read at rd[(s*NW + c) * 256]
-  uint32_t* ded;       // LDS: dedupe slot q at ded[q * 256]
+  const uint64_t* rd;  // LDS: word (s*NW + c) of this lane's read at rd[(s*NW + c) * K4_BS(NCH)]
+  uint32_t* ded;       // LDS: dedupe slot q at ded[q * K4_BS(NCH)]
   const uint32_t* sup; // LDS (block-shared): coarse exception bitmap, K4_SUP_WORDS words
   const uint64_t* ent; // LDS (block-shared): chromosome starts [0..K4_LDS_ENTRIES) then ends, when they fit
-  uint64_t* memo;      // LDS: what the offset-0 lookup of strand s found in the first phase, at memo[s * 256]
+  uint64_t* memo;      // LDS: what the offset-0 lookup of strand s found in the first phase, at memo[s * K4_BS(NCH)]
   static constexpr int NW = NCH + 1;
-  K4_DEV uint64_t word(int s, int c) const { return rd[(s * NW + c) * 256]; }
+  K4_DEV uint64_t word(int s, int c) const { return rd[(s * NW + c) * K4_BS(NCH)]; }
   K4_DEV uint64_t chunk_at(int s, int o) const {  // 32 bases of strand s starting at base o
     int w = o >> 5, sh = 2 * (o & 31);
     uint64_t hi = word(s, w);
@@ -339,7 +347,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       for (int j = 0; j < K4_PF; j++) {
         if (j < cnt) {
           if (!CAPTURE && j == 0 && first_group && tshift == 0) {
-            const uint64_t mv = ln.memo[s * 256];
+            const uint64_t mv = ln.memo[s * K4_BS(NCH)];
             const int kind = (int)(mv >> 62), fm = (int)((mv >> 48) & 0x3FFF), mmv = (int)((mv >> 40) & 0xFF);
             if (kind == 1 || (kind == 2 && fm < cl)) continue;                   // nothing starts with this core
             if (kind == 2 && mmv != 0xFF) {                                      // exactly the suffix at pos does
@@ -351,7 +359,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           const uint64_t code = ln.chunk_at(s, oo[j]) >> (64 - 2 * kk);
           k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j]);
           if (CAPTURE && j == 0 && first_group && tshift == 0) {
-            if (lb1[0] == lb0[0]) ln.memo[s * 256] = k4d_memo_pack(1, 0, 0, 0);
+            if (lb1[0] == lb0[0]) ln.memo[s * K4_BS(NCH)] = k4d_memo_pack(1, 0, 0, 0);
             else memo_pending = lb1[0] == lb0[0] + 1;
           }
           // a bucket of one suffix whose next bases already disagree with the core cannot hold a match: drop it here
@@ -362,7 +370,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
             if (df) {
               lb1[j] = lb0[j];
               if (CAPTURE && j == 0 && first_group) {
-                ln.memo[s * 256] = k4d_memo_pack(2, (uint64_t)ps0[0], 0xFF, kk + (__clz(df) >> 1));
+                ln.memo[s * K4_BS(NCH)] = k4d_memo_pack(2, (uint64_t)ps0[0], 0xFF, kk + (__clz(df) >> 1));
                 memo_pending = false;
               }
             }
@@ -398,7 +406,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           else {
             pr = k4d_probe<NCH>(ix, ln, s, o, cl, len, p);
             n_probe++;
-            if (CAPTURE && j == 0 && memo_pending) ln.memo[s * 256] = k4d_memo_pack(2, p, pr.mm > 254 ? 254 : pr.mm, pr.fm);
+            if (CAPTURE && j == 0 && memo_pending) ln.memo[s * K4_BS(NCH)] = k4d_memo_pack(2, p, pr.mm > 254 ? 254 : pr.mm, pr.fm);
           }
           if (pr.exc) return K4_NEED_SLOW;  // (handling it here instead costs the hot path 8 % in registers: measured)
           if (pr.cmp > 0) lo = mid + 1;
@@ -451,10 +459,10 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           if (e < 0 || left + (uint64_t)len - 1 > e_end) continue;
           const uint32_t targ_id = (uint32_t)(1 + p - (uint32_t)o);  // :6037 (truncation is the reference's)
           bool dup = false;
-          for (int q = 0; q < n_ded; q++) dup |= (ln.ded[q * 256] == targ_id);
+          for (int q = 0; q < n_ded; q++) dup |= (ln.ded[q * K4_BS(NCH)] == targ_id);
           if (dup) continue;
           if (n_ded >= K4_DEDUP_CAP) return K4_NEED_SLOW;
-          ln.ded[n_ded * 256] = targ_id;
+          ln.ded[n_ded * K4_BS(NCH)] = targ_id;
           n_ded++;
           iter++;
           n_cand++;
@@ -523,9 +531,9 @@ K4_DEV uint32_t k4d_pack_read(const uint8_t* __restrict__ src, int len, uint64_t
         acc = (acc << 8) | ((d & 3) << 6) | (((d >> 8) & 3) << 4) | (((d >> 16) & 3) << 2) | ((d >> 24) & 3);
       }
     }
-    col[c * 256] = acc;
+    col[c * K4_BS(NCH)] = acc;
   }
-  col[NCH * 256] = 0;
+  col[NCH * K4_BS(NCH)] = 0;
   if (n_ns) fl |= K4_RF_HAS_N;
   // reverse complement from the stored forward words: rc bases [32c, 32c+32) = complement of forward bases
   // [len-32(c+1), len-32c) in reverse order
@@ -537,22 +545,22 @@ K4_DEV uint32_t k4d_pack_read(const uint8_t* __restrict__ src, int len, uint64_t
       uint64_t f;
       if (o >= 0) {
         const int w = o >> 5, sh = 2 * (o & 31);
-        const uint64_t hi = col[w * 256];
-        f = sh ? (hi << sh) | (col[(w + 1) * 256] >> (64 - sh)) : hi;
+        const uint64_t hi = col[w * K4_BS(NCH)];
+        f = sh ? (hi << sh) | (col[(w + 1) * K4_BS(NCH)] >> (64 - sh)) : hi;
       } else
         f = col[0] >> (2 * (-o));  // fewer than 32 bases left: they sit at the low end, zeros above
       r = k4d_rev2(~f) & k4d_range_mask(0, len - 32 * c);
     }
-    col[(NW + c) * 256] = r;
+    col[(NW + c) * K4_BS(NCH)] = r;
   }
-  col[(NW + NCH) * 256] = 0;
+  col[(NW + NCH) * K4_BS(NCH)] = 0;
   return fl;
 }
 
 // One AlignReads phase per launch.  FIRST: lanes take reads j = 0..n_reads-1 and pack them; later steps take the
 // compacted survivors (ids + packed rows) of the previous step.
 template <int EL, int NCH, bool FIRST, typename KT>
-__global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs a, int step, const uint32_t* __restrict__ in_ids,
+__global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : NCH >= 8 ? K4_STEP_WAVES_MID : K4_STEP_WAVES)) k4k_align_step(K4AlignArgs a, int step, const uint32_t* __restrict__ in_ids,
                                                       const uint64_t* __restrict__ in_rows,
                                                       const uint32_t* __restrict__ in_count, uint32_t* __restrict__ out_ids,
                                                       uint64_t* __restrict__ out_rows, uint32_t* __restrict__ out_count) {
@@ -562,15 +570,15 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
   const int lane = tid & 63;
   K4Lane<NCH> ln;
   ln.rd = lds + tid;
-  ln.ded = reinterpret_cast<uint32_t*>(lds + 2 * NW * 256) + tid;
-  ln.memo = lds + 2 * NW * 256 + (K4_DEDUP_CAP * 256) / 2 + tid;
-  uint64_t* ent_l = lds + 2 * NW * 256 + (K4_DEDUP_CAP * 256) / 2 + 2 * 256;
+  ln.ded = reinterpret_cast<uint32_t*>(lds + 2 * NW * K4_BS(NCH)) + tid;
+  ln.memo = lds + 2 * NW * K4_BS(NCH) + (K4_DEDUP_CAP * K4_BS(NCH)) / 2 + tid;
+  uint64_t* ent_l = lds + 2 * NW * K4_BS(NCH) + (K4_DEDUP_CAP * K4_BS(NCH)) / 2 + 2 * K4_BS(NCH);
   uint32_t* sup_l = reinterpret_cast<uint32_t*>(ent_l + 2 * K4_LDS_ENTRIES);
   ln.ent = ent_l;
   ln.sup = sup_l;
-  for (int q = tid; q < K4_SUP_WORDS; q += 256) sup_l[q] = a.ix.excsup[q];
+  for (int q = tid; q < K4_SUP_WORDS; q += K4_BS(NCH)) sup_l[q] = a.ix.excsup[q];
   if (a.ix.n_entries <= K4_LDS_ENTRIES)
-    for (int q = tid; q < (int)a.ix.n_entries; q += 256) {
+    for (int q = tid; q < (int)a.ix.n_entries; q += K4_BS(NCH)) {
       ent_l[q] = a.ix.ent_start[q];
       ent_l[K4_LDS_ENTRIES + q] = a.ix.ent_end[q];
     }
@@ -578,12 +586,12 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
   uint64_t* col = lds + tid;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0, n_slow = 0, n_bases = 0, n_done = 0;
   const int64_t count = FIRST ? a.n_reads : (int64_t)*in_count;
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t stride = (int64_t)gridDim.x * K4_BS(NCH);
   // Survivor slots are reserved K4_CHUNK at a time (one atomic per chunk, not per wave iteration: a single counter
   // word serialises at ~88 atomics/us).  ch_cur / ch_left are wave-uniform: every lane of the wave runs every
   // iteration of this loop, inactive lanes masked, so the copies never diverge.  Unused slots hold K4_NO_READ.
   uint32_t ch_cur = 0, ch_left = 0;
-  for (int64_t jb = (int64_t)blockIdx.x * 256 + (tid & ~63); jb < count; jb += stride) {
+  for (int64_t jb = (int64_t)blockIdx.x * K4_BS(NCH) + (tid & ~63); jb < count; jb += stride) {
     const int64_t j = jb + lane;
     bool active = j < count;
     int64_t i = 0;
@@ -628,7 +636,7 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
         const uint64_t* row = in_rows + (int64_t)j * K4_ROW_WORDS(NCH);
         {
           const k4_u64x2_a8 mv = *reinterpret_cast<const k4_u64x2_a8*>(row + 2 * NCH);
-          ln.memo[0] = mv.x; ln.memo[256] = mv.y;
+          ln.memo[0] = mv.x; ln.memo[K4_BS(NCH)] = mv.y;
         }
         uint64_t rw[2 * NCH];
 #pragma unroll
@@ -638,11 +646,11 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-          col[c * 256] = rw[c];
-          col[(NW + c) * 256] = rw[NCH + c];
+          col[c * K4_BS(NCH)] = rw[c];
+          col[(NW + c) * K4_BS(NCH)] = rw[NCH + c];
         }
-        col[NCH * 256] = 0;
-        col[(NW + NCH) * 256] = 0;
+        col[NCH * K4_BS(NCH)] = 0;
+        col[(NW + NCH) * K4_BS(NCH)] = 0;
       }
       if (!skip && (rp.core_len < 1 || rp.max_hits < 1 || rp.max_hits > a.max_hits)) slow = true;  // the general kernel reports it
       if (!skip && !slow) {
@@ -659,7 +667,7 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
         k4_hit* hits = a.hits + i * a.max_hits;
         int inst = 0, low = 0, nxt = 0;
         const uint32_t c0 = n_lookup, c1 = n_probe, c2 = n_cand;
-        if (FIRST) { ln.memo[0] = K4_MEMO_NONE; ln.memo[256] = K4_MEMO_NONE; }
+        if (FIRST) { ln.memo[0] = K4_MEMO_NONE; ln.memo[K4_BS(NCH)] = K4_MEMO_NONE; }
         int rslt = k4d_lcm_fast<EL, NCH, KT, FIRST>(a, ln, len, allow, cl, delta, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
         if (rslt == K4_NEED_SLOW) {  // the general kernel redoes (and tallies) this phase
           slow = true;
@@ -692,13 +700,13 @@ __global__ void __launch_bounds__(256, K4_STEP_WAVES) k4k_align_step(K4AlignArgs
         for (int c = 0; c < NCH; c++) {
           k4_u64x2_a8 v;
           const int w0 = 2 * c, w1 = 2 * c + 1;
-          v.x = w0 < NCH ? col[w0 * 256] : col[(NW + w0 - NCH) * 256];
-          v.y = w1 < NCH ? col[w1 * 256] : col[(NW + w1 - NCH) * 256];
+          v.x = w0 < NCH ? col[w0 * K4_BS(NCH)] : col[(NW + w0 - NCH) * K4_BS(NCH)];
+          v.y = w1 < NCH ? col[w1 * K4_BS(NCH)] : col[(NW + w1 - NCH) * K4_BS(NCH)];
           *reinterpret_cast<k4_u64x2_a8*>(row + 2 * c) = v;
         }
         {
           k4_u64x2_a8 mv;
-          mv.x = ln.memo[0]; mv.y = ln.memo[256];
+          mv.x = ln.memo[0]; mv.y = ln.memo[K4_BS(NCH)];
           *reinterpret_cast<k4_u64x2_a8*>(row + 2 * NCH) = mv;
         }
       }
@@ -1489,14 +1497,14 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
 template <int EL, int NCH, typename KT>
 static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t st) {
   K4Workspace& w = ix->ws;
-  const size_t lds = (size_t)2 * (NCH + 1) * 256 * 8 + (size_t)K4_DEDUP_CAP * 256 * 4 + (size_t)2 * 256 * 8 + (size_t)2 * K4_LDS_ENTRIES * 8 +
+  const size_t lds = (size_t)2 * (NCH + 1) * K4_BS(NCH) * 8 + (size_t)K4_DEDUP_CAP * K4_BS(NCH) * 4 + (size_t)2 * K4_BS(NCH) * 8 + (size_t)2 * K4_LDS_ENTRIES * 8 +
                      (size_t)K4_SUP_WORDS * 4 + 16;
   if (lds > 48 * 1024) {
     K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, false, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   // grid-stride kernels: enough blocks to fill the chip at the kernel's occupancy, never more than the work
-  const unsigned full = 256 * 8;
+  const unsigned full = 256 * 8 * (256 / K4_BS(NCH));
   const bool timed = ix->timing && ix->ev_used < 4096;
   if (timed) {
     if (ix->ev_used == ix->ev0.size()) {
@@ -1508,12 +1516,12 @@ static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t s
     }
     K4_HIP(ix, hipEventRecord(ix->ev0[ix->ev_used], st));
   }
-  unsigned grid0 = (unsigned)std::min<int64_t>((a.n_reads + 255) / 256, full);
-  hipLaunchKernelGGL((k4k_align_step<EL, NCH, true, KT>), dim3(grid0), dim3(256), lds, st, a, 0, (const uint32_t*)nullptr,
+  unsigned grid0 = (unsigned)std::min<int64_t>((a.n_reads + K4_BS(NCH) - 1) / K4_BS(NCH), full);
+  hipLaunchKernelGGL((k4k_align_step<EL, NCH, true, KT>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, 0, (const uint32_t*)nullptr,
                      (const uint64_t*)nullptr, (const uint32_t*)nullptr, w.ids[0], w.rows[0], w.ctl + 2);
   for (int t = 1; t < n_steps; t++) {
     const int in = (t - 1) & 1, out = t & 1;
-    hipLaunchKernelGGL((k4k_align_step<EL, NCH, false, KT>), dim3(grid0), dim3(256), lds, st, a, t, w.ids[in], w.rows[in],
+    hipLaunchKernelGGL((k4k_align_step<EL, NCH, false, KT>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, t, w.ids[in], w.rows[in],
                        w.ctl + 2 + (t - 1), w.ids[out], w.rows[out], w.ctl + 2 + t);
   }
   if (timed) {
