@@ -33,6 +33,9 @@
 #ifndef K4_STEP_WAVES_LONG
 #define K4_STEP_WAVES_LONG 2  // ... for reads over 256 bp (16 packed words per strand; LDS allows one block per CU anyway)
 #endif
+#ifndef K4_STEP_WAVES_5
+#define K4_STEP_WAVES_5 4     // ... for 129..160 bp (5 words per strand); 3 (no spills) measured 8 % slower on C3
+#endif
 #ifndef K4_STEP_WAVES_MID
 #define K4_STEP_WAVES_MID 3   // ... for 161..256 bp (8 words per strand; LDS allows three blocks per CU)
 #endif
@@ -560,7 +563,7 @@ K4_DEV uint32_t k4d_pack_read(const uint8_t* __restrict__ src, int len, uint64_t
 // One AlignReads phase per launch.  FIRST: lanes take reads j = 0..n_reads-1 and pack them; later steps take the
 // compacted survivors (ids + packed rows) of the previous step.
 template <int EL, int NCH, bool FIRST, typename KT>
-__global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : NCH >= 8 ? K4_STEP_WAVES_MID : K4_STEP_WAVES)) k4k_align_step(K4AlignArgs a, int step, const uint32_t* __restrict__ in_ids,
+__global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : NCH >= 8 ? K4_STEP_WAVES_MID : NCH == 5 ? K4_STEP_WAVES_5 : K4_STEP_WAVES)) k4k_align_step(K4AlignArgs a, int step, const uint32_t* __restrict__ in_ids,
                                                       const uint64_t* __restrict__ in_rows,
                                                       const uint32_t* __restrict__ in_count, uint32_t* __restrict__ out_ids,
                                                       uint64_t* __restrict__ out_rows, uint32_t* __restrict__ out_count) {
