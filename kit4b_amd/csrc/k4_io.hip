@@ -513,70 +513,117 @@ __global__ void __launch_bounds__(256) k4k_sam_line_lens(K4SamArgs a, const uint
   if (j < m) ll[j] = k4d_sam_line_len(a, order[j]);
 }
 
-// 16 lanes per line, four lines per wave: QNAME FLAG RNAME POS MAPQ <len>M RNEXT PNEXT TLEN SEQ * (AddAlignment,
-// SAMfile.cpp:2194-2377).  The group's first lane formats the numeric fields into LDS, then the 16 lanes copy the pieces.
-__global__ void __launch_bounds__(64) k4k_sam_write(K4SamArgs a, const uint32_t* __restrict__ order, const uint64_t* __restrict__ loff,
-                                                    uint64_t m, char* __restrict__ out) {
-  __shared__ char mid[4][2][64];
-  __shared__ uint32_t midn[4][2];
-  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
-  for (uint64_t jb = (uint64_t)blockIdx.x * 4; jb < m; jb += (uint64_t)gridDim.x * 4) {
-    const uint64_t j = jb + grp;
-    const bool on = j < m;
-    int64_t v = 0, i = 0;
-    k4_hit h;
-    memset(&h, 0, sizeof(h));
-    if (on) {
-      v = order[j];
-      h = k4d_sam_hit(a, v);
-      i = k4d_sam_read(a, v);
-    }
-    __syncthreads();
-    if (on && gl == 0) {
-      const K4SamFields f = k4d_sam_fields(a, v, h);
-      char* p = mid[grp][0];
-      uint32_t n = 0;
-      p[n++] = '\t'; n += k4d_put_uint(p + n, f.flag); p[n++] = '\t';
-      midn[grp][0] = n;
-      p = mid[grp][1];
-      n = 0;
-      p[n++] = '\t'; n += k4d_put_uint(p + n, f.pos);
-      p[n++] = '\t'; n += k4d_put_uint(p + n, f.mapq);
-      p[n++] = '\t'; n += k4d_put_uint(p + n, f.len); p[n++] = 'M';
-      p[n++] = '\t'; p[n++] = f.mate_eq ? '=' : '*';
-      p[n++] = '\t'; n += k4d_put_uint(p + n, f.pnext);
-      p[n++] = '\t';
-      if (f.tlen < 0) p[n++] = '-';
-      n += k4d_put_uint(p + n, (uint32_t)(f.tlen < 0 ? -(int64_t)f.tlen : f.tlen));
-      p[n++] = '\t';
-      midn[grp][1] = n;
-    }
-    __syncthreads();
-    if (!on) continue;
+// QNAME FLAG RNAME POS MAPQ <len>M RNEXT PNEXT TLEN SEQ * (AddAlignment, SAMfile.cpp:2194-2377).  The lines of the sorted
+// order are consecutive in the output, so a wave takes a tile of 64 / LPL of them, LPL lanes per line write the line
+// into the wave's LDS buffer (sub-lane 0 the fields, all of them a share of SEQ), and the wave then streams the tile out
+// with 16-byte stores (the buffer is offset so that LDS and global addresses agree modulo 16).  A tile that does not
+// fit (very long reads or names) is written straight to global memory by the same code.
+#define K4_SAM_WAVE_BUF 12288
+// four bytes of a read starting at any byte offset p >= 0 (aligned word loads, as k4d_pack_read: never outside the 4-byte
+// cells the read occupies); bytes past `len` come back as whatever the cell holds or zero
+K4_DEV uint32_t k4d_read4(const uint32_t* __restrict__ s32, uint32_t sh, uint32_t span, uint32_t p) {
+  const uint32_t bo = p + sh, wi = bo >> 2, r = bo & 3;
+  const uint32_t lo = s32[wi];
+  const uint32_t hi = (r && 4 * (wi + 1) < span) ? s32[wi + 1] : 0u;
+  return __builtin_amdgcn_alignbyte(hi, lo, r);
+}
+// one line (or sub-lane `sub`'s share of it) at `line`; inlined once with an LDS and once with a global destination
+K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int64_t i, char* line, uint32_t line_len, int sub,
+                             int lpl) {
+  const uint32_t len = a.lens[i];
+  char* seq = line + line_len - 3 - len;
+  if (sub == 0) {
+    const K4SamFields f = k4d_sam_fields(a, v, h);
     const int w = a.pe ? (int)(i & 1) : 0;
     const int64_t rec = a.pe ? (i >> 1) : i;
-    char* dst = out + loff[j];
+    char* p = line;
     const uint8_t* nm = a.text[w] + a.name_off[w][rec];
     const uint32_t nl_ = a.name_len[w][rec];
-    for (uint32_t q = gl; q < nl_; q += 16) dst[q] = (char)nm[q];
-    dst += nl_;
-    const uint32_t n0 = midn[grp][0], n1 = midn[grp][1];
-    for (uint32_t q = gl; q < n0; q += 16) dst[q] = mid[grp][0][q];
-    dst += n0;
+    for (uint32_t q = 0; q < nl_; q++) p[q] = (char)nm[q];
+    p += nl_;
+    *p++ = '\t'; p += k4d_put_uint(p, f.flag); *p++ = '\t';
     const char* cn = a.cnames + (size_t)(h.chrom_id - 1) * K4_SAM_NAME_STRIDE;
     const uint32_t cl = a.cname_len[h.chrom_id - 1];
-    for (uint32_t q = gl; q < cl; q += 16) dst[q] = cn[q];
-    dst += cl;
-    for (uint32_t q = gl; q < n1; q += 16) dst[q] = mid[grp][1][q];
-    dst += n1;
-    const uint8_t* s = a.reads + a.offs[i];
-    const uint32_t len = a.lens[i];
-    if (h.strand == '+')
-      for (uint32_t q = gl; q < len; q += 16) { const uint8_t b = s[q] & 7; dst[q] = "ACGTN"[b > 4 ? 4 : b]; }
-    else
-      for (uint32_t q = gl; q < len; q += 16) { const uint8_t b = s[len - 1 - q] & 7; dst[q] = b <= 3 ? "TGCA"[b] : 'N'; }  // :6279
-    dst += len;
-    if (gl == 0) { dst[0] = '\t'; dst[1] = '*'; dst[2] = '\n'; }
+    for (uint32_t q = 0; q < cl; q++) p[q] = cn[q];
+    p += cl;
+    *p++ = '\t'; p += k4d_put_uint(p, f.pos);
+    *p++ = '\t'; p += k4d_put_uint(p, f.mapq);
+    *p++ = '\t'; p += k4d_put_uint(p, f.len); *p++ = 'M';
+    *p++ = '\t'; *p++ = f.mate_eq ? '=' : '*';
+    *p++ = '\t'; p += k4d_put_uint(p, f.pnext);
+    *p++ = '\t';
+    if (f.tlen < 0) *p++ = '-';
+    p += k4d_put_uint(p, (uint32_t)(f.tlen < 0 ? -(int64_t)f.tlen : f.tlen));
+    *p++ = '\t';
+    seq[len] = '\t'; seq[len + 1] = '*'; seq[len + 2] = '\n';
+  }
+  const uint8_t* s = a.reads + a.offs[i];
+  const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3);
+  const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(s - sh);
+  const uint32_t span = len + sh;
+  const uint32_t q0 = (uint32_t)((uint64_t)len * sub / lpl), q1 = (uint32_t)((uint64_t)len * (sub + 1) / lpl);
+  const uint64_t fwd = 0x4E4E4E4E54474341ull, rev = 0x4E4E4E4E41434754ull;  // "ACGTNNNN" / "TGCANNNN" by symbol (:6279)
+  if (h.strand == '+') {
+    for (uint32_t q = q0; q < q1; q += 4) {
+      const uint32_t d = k4d_read4(s32, sh, span, q);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        if (q + k < q1) seq[q + k] = (char)(fwd >> (8 * ((d >> (8 * k)) & 7)));
+    }
+  } else {
+    for (uint32_t q = q0; q < q1; q += 4) {  // seq[q + k] = complement of s[len - 1 - q - k]
+      const uint32_t top = len - 1 - q;      // highest source byte of this group
+      if (top >= 3) {
+        const uint32_t d = k4d_read4(s32, sh, span, top - 3);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+          if (q + k < q1) seq[q + k] = (char)(rev >> (8 * ((d >> (8 * (3 - k))) & 7)));
+      } else {
+        for (uint32_t k = 0; k <= top && q + k < q1; k++) seq[q + k] = (char)(rev >> (8 * (s[top - k] & 7)));
+      }
+    }
+  }
+}
+
+template <int LPL>
+__global__ void __launch_bounds__(256) k4k_sam_write(K4SamArgs a, const uint32_t* __restrict__ order, const uint64_t* __restrict__ loff,
+                                                     uint64_t m, char* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char sm[4][K4_SAM_WAVE_BUF];
+  constexpr int TL = 64 / LPL;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane / LPL, sub = lane % LPL;
+  char* buf = sm[wave];
+  for (uint64_t jb = (uint64_t)blockIdx.x * 4 * TL; jb < m; jb += (uint64_t)gridDim.x * 4 * TL) {  // same trip count for the block
+    const uint64_t j0 = jb + (uint64_t)wave * TL;
+    const int nl = j0 < m ? (int)min((uint64_t)TL, m - j0) : 0;
+    uint64_t b0 = 0, b1 = 0;
+    if (nl) { b0 = loff[j0]; b1 = loff[j0 + nl]; }
+    const uint32_t pad = (uint32_t)(b0 & 15);
+    const bool fits = nl && (b1 - b0) + pad <= (uint64_t)K4_SAM_WAVE_BUF;
+    if (li < nl) {
+      const uint64_t j = j0 + li;
+      const int64_t v = order[j];
+      const k4_hit h = k4d_sam_hit(a, v);
+      const int64_t i = k4d_sam_read(a, v);
+      const uint64_t l0 = loff[j], l1 = loff[j + 1];
+      if (fits) k4d_sam_put_line(a, v, h, i, &sm[wave][pad + (uint32_t)(l0 - b0)], (uint32_t)(l1 - l0), sub, LPL);
+      else k4d_sam_put_line(a, v, h, i, out + l0, (uint32_t)(l1 - l0), sub, LPL);
+    }
+    __syncthreads();
+    if (fits) {
+      const uint32_t total = (uint32_t)(b1 - b0);
+      const uint32_t head = pad ? min(16u - pad, total) : 0u;
+      char* dst = out + b0;
+      const char* src = buf + pad;
+      if ((uint32_t)lane < head) dst[lane] = src[lane];
+      const uint32_t body = (total - head) / 16;
+      const uint4* s4 = reinterpret_cast<const uint4*>(src + head);
+      uint4* d4 = reinterpret_cast<uint4*>(dst + head);
+      for (uint32_t q = lane; q < body; q += 64) d4[q] = s4[q];
+      const uint32_t done = head + body * 16;
+      if ((uint32_t)lane < total - done) dst[done + lane] = src[done + lane];
+    }
+    __syncthreads();
   }
 }
 
@@ -752,7 +799,15 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
   K4_HIP(ix, hipMemcpy(&total, lo.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost));
   char* out = nullptr;
   K4_HIP(ix, hipMalloc(&out, total + 16));
-  hipLaunchKernelGGL(k4k_sam_write, dim3((unsigned)std::min<uint64_t>((m + 3) / 4, 1u << 16)), dim3(64), 0, st, a, order, lo.as<uint64_t>(), m, out);
+  {  // lines per wave tile: as many as fit the wave's LDS buffer at 1.25 x the average line
+    const uint64_t avg = total / m + 1;
+    const int lpl = avg * 64 * 5 / 4 <= K4_SAM_WAVE_BUF ? 1 : avg * 32 * 5 / 4 <= K4_SAM_WAVE_BUF ? 2 : 4;
+    const uint64_t per_block = 4 * (64 / lpl);
+    const dim3 grid((unsigned)std::min<uint64_t>((m + per_block - 1) / per_block, 1u << 16));
+    if (lpl == 1) hipLaunchKernelGGL(k4k_sam_write<1>, grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+    else if (lpl == 2) hipLaunchKernelGGL(k4k_sam_write<2>, grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+    else hipLaunchKernelGGL(k4k_sam_write<4>, grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+  }
   int rc = k4_check_hip(ix, hipGetLastError(), "SAM write");
   if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(st), "SAM write");
   if (rc != K4_OK) {
