@@ -45,6 +45,9 @@
 #ifndef K4_PF
 #define K4_PF 4  // k-mer table entries fetched ahead per strand pass
 #endif
+#ifndef K4_PF5
+#define K4_PF5 4 // ... in the 5-word (129..160 bp) instantiation (3 measured +1 % on C3: noise)
+#endif
 #ifndef K4_SLOW_KB
 #define K4_SLOW_KB 1  // general kernel: suffixes per lane per walk step (measured: 2 and 4 cost occupancy and lose 25 %)
 #endif
@@ -328,12 +331,13 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
     while (more && !stop) {
       // The core offsets of a strand pass depend only on (len, cl, delta) (:5948-5959), so the k-mer table entries of
       // the next K4_PF cores are fetched together before any of them is searched: one memory round trip, not K4_PF.
-      int oo[K4_PF];
-      KT lb0[K4_PF], ps0[K4_PF], lb1[K4_PF];
-      uint32_t sig[K4_PF];
+      constexpr int PFN = NCH == 5 ? K4_PF5 : K4_PF;
+      int oo[PFN];
+      KT lb0[PFN], ps0[PFN], lb1[PFN];
+      uint32_t sig[PFN];
       int cnt = 0;
 #pragma unroll
-      for (int j = 0; j < K4_PF; j++) {
+      for (int j = 0; j < PFN; j++) {
         oo[j] = 0; lb0[j] = 0; ps0[j] = 0; lb1[j] = 0; sig[j] = 0;
         if (cnt == j && slides < rp.max_slides && o_next <= len - cl && cur_delta > cl / 3) {
           if (o_next + cl + cur_delta > len) cur_delta = len - (o_next + cl);
@@ -343,11 +347,11 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           o_next += cur_delta;
         }
       }
-      more = cnt == K4_PF;
+      more = cnt == PFN;
       bool memo_hit = false, memo_pending = false;
       int memo_mm = 0;
 #pragma unroll
-      for (int j = 0; j < K4_PF; j++) {
+      for (int j = 0; j < PFN; j++) {
         if (j < cnt) {
           if (!CAPTURE && j == 0 && first_group && tshift == 0) {
             const uint64_t mv = ln.memo[s * K4_BS(NCH)];
@@ -384,11 +388,11 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       // L2) while the cores are searched one after the other below
       uint32_t touch = 0;
 #pragma unroll
-      for (int j = 0; j < K4_PF; j++)
+      for (int j = 0; j < PFN; j++)
         if (j < cnt && tshift == 0 && lb1[j] > lb0[j] && !(j == 0 && memo_hit)) touch |= ix.ref2[((int64_t)ps0[j] - oo[j]) >> 4];
 
 #pragma unroll
-      for (int j = 0; j < K4_PF; j++) {
+      for (int j = 0; j < PFN; j++) {
         if (j >= cnt || stop) continue;
         const int o = oo[j];
         n_lookup++;
