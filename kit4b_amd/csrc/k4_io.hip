@@ -773,10 +773,12 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
     hipLaunchKernelGGL(k4k_sam_key_major, dim3(mb), dim3(256), 0, st, a, vb.current(), m, k64a.as<uint64_t>());
     rocprim::double_buffer<uint64_t> kb2(k64a.as<uint64_t>(), k64b.as<uint64_t>());
     size_t tb2 = 0;
-    K4_HIP(ix, rocprim::radix_sort_pairs(nullptr, tb2, kb2, vb, (size_t)m, 0u, 64u, st));
+    unsigned top = 33;  // key = chrom << 32 | start: only the bits chromosome ids can reach are sorted on
+    while (top < 64 && (a.n_entries >> (top - 32)) != 0) top++;
+    K4_HIP(ix, rocprim::radix_sort_pairs(nullptr, tb2, kb2, vb, (size_t)m, 0u, top, st));
     Buf t3;
     K4_HIP(ix, t3.alloc(tb2));
-    K4_HIP(ix, rocprim::radix_sort_pairs(t3.p, tb2, kb2, vb, (size_t)m, 0u, 64u, st));
+    K4_HIP(ix, rocprim::radix_sort_pairs(t3.p, tb2, kb2, vb, (size_t)m, 0u, top, st));
     K4_HIP(ix, hipStreamSynchronize(st));
     order = vb.current();
   }
