@@ -102,10 +102,37 @@ __global__ void __launch_bounds__(64) k4k_fastx_count(const uint8_t* __restrict_
   }
 }
 
-// one wave per record: the sequence bytes of its span, white space squeezed out, as etSeqBase codes
+// FASTQ, the usual case: the sequence line holds bases only (and perhaps a '\r'), so its length is the base count -- one
+// thread per record instead of a pass over the text; k4k_fastx_encode checks the assumption and the exact count is redone
+// when it does not hold anywhere
+__global__ void __launch_bounds__(256) k4k_fastq_lens(const uint8_t* __restrict__ text, const uint32_t* __restrict__ seq_off,
+                                                      const uint32_t* __restrict__ seq_span, int64_t n_rec,
+                                                      uint32_t* __restrict__ lens, unsigned long long* __restrict__ tot) {
+  unsigned long long sum = 0;
+  uint32_t mx = 0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rec; r += (int64_t)gridDim.x * 256) {
+    uint32_t n = seq_span[r];
+    if (n && text[seq_off[r] + n - 1] == '\r') n--;
+    lens[r] = n;
+    sum += n;
+    mx = max(mx, n);
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    sum += __shfl_down(sum, d, 64);
+    mx = max(mx, (uint32_t)__shfl_down(mx, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (sum) atomicAdd(&tot[0], sum);
+    if (mx) atomicMax(&tot[1], (unsigned long long)mx);
+  }
+}
+
+// one wave per record: the sequence bytes of its span, white space squeezed out, as etSeqBase codes; expect (optional):
+// the base counts the offsets were laid out with -- *mismatch is raised when a record holds a different number
 __global__ void __launch_bounds__(64) k4k_fastx_encode(const uint8_t* __restrict__ text, const uint32_t* __restrict__ seq_off,
                                                        const uint32_t* __restrict__ seq_span, const uint64_t* __restrict__ offs,
-                                                       int64_t n_rec, uint8_t* __restrict__ reads) {
+                                                       int64_t n_rec, uint8_t* __restrict__ reads,
+                                                       const uint32_t* __restrict__ expect, uint32_t* __restrict__ mismatch) {
   const int lane = threadIdx.x;
   for (int64_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
     const uint8_t* src = text + seq_off[r];
@@ -119,6 +146,7 @@ __global__ void __launch_bounds__(64) k4k_fastx_encode(const uint8_t* __restrict
       if (keep) dst[done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k4d_base_code(c);
       done += (uint32_t)__popcll(m);
     }
+    if (expect && lane == 0 && done != expect[r]) *mismatch = 1u;
   }
 }
 
@@ -282,9 +310,15 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
   a.seq_off = so.as<uint32_t>(); a.seq_span = ss.as<uint32_t>(); a.lens = (uint32_t*)d_lens;
   a.name_off = (uint64_t*)d_name_off; a.name_len = (uint32_t*)d_name_len; a.tot = tot.as<unsigned long long>();
   hipLaunchKernelGGL(k4k_fastx_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k4k_fastx_count, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 14)), dim3(64), 0, st, text, so.as<uint32_t>(),
-                     ss.as<uint32_t>(), n_rec, (uint32_t*)d_lens, tot.as<unsigned long long>());
-  {
+  // tot: [0] bases, [1] longest, [2] malformed records, [3] (as uint32) FASTQ fast-path mismatch
+  bool exact = !fastq;
+  for (;;) {
+    if (exact)
+      hipLaunchKernelGGL(k4k_fastx_count, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 14)), dim3(64), 0, st, text, so.as<uint32_t>(),
+                         ss.as<uint32_t>(), n_rec, (uint32_t*)d_lens, tot.as<unsigned long long>());
+    else
+      hipLaunchKernelGGL(k4k_fastq_lens, dim3((unsigned)std::min<int64_t>((n_rec + 255) / 256, 4096)), dim3(256), 0, st, text,
+                         so.as<uint32_t>(), ss.as<uint32_t>(), n_rec, (uint32_t*)d_lens, tot.as<unsigned long long>());
     size_t tb = 0;
     K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, (const uint32_t*)d_lens, (uint64_t*)d_offs, reads_base, (size_t)n_rec,
                                        rocprim::plus<uint64_t>(), st));
@@ -293,9 +327,16 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
     K4_HIP(ix, rocprim::exclusive_scan(tmp3.p, tb, (const uint32_t*)d_lens, (uint64_t*)d_offs, reads_base, (size_t)n_rec,
                                        rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL(k4k_fastx_encode, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 16)), dim3(64), 0, st, text, so.as<uint32_t>(),
-                       ss.as<uint32_t>(), (const uint64_t*)d_offs, n_rec, (uint8_t*)d_reads);
+                       ss.as<uint32_t>(), (const uint64_t*)d_offs, n_rec, (uint8_t*)d_reads,
+                       exact ? (const uint32_t*)nullptr : (const uint32_t*)d_lens, reinterpret_cast<uint32_t*>(tot.as<unsigned long long>() + 3));
     K4_HIP(ix, hipGetLastError());
     K4_HIP(ix, hipStreamSynchronize(st));  // tmp3 is released here
+    if (exact) break;
+    uint32_t mis = 0;
+    K4_HIP(ix, hipMemcpy(&mis, tot.as<unsigned long long>() + 3, 4, hipMemcpyDeviceToHost));
+    if (!mis) break;
+    K4_HIP(ix, hipMemsetAsync(tot.p, 0, 16, st));  // bases and longest are counted again, exactly
+    exact = true;
   }
   unsigned long long t[3] = {0, 0, 0};
   K4_HIP(ix, hipMemcpy(t, tot.p, 24, hipMemcpyDeviceToHost));

@@ -79,12 +79,14 @@ def _fasta(rng, n, wrap, crlf, trailing_nl=True):
     return t + (eol if trailing_nl else b"")
 
 
-def _fastq(rng, n, crlf, trailing_nl=True):
+def _fastq(rng, n, crlf, trailing_nl=True, dirty=False):
     eol = b"\r\n" if crlf else b"\n"
     out = []
     for i in range(n):
         L = int(rng.integers(1, 300))
         seq = bytes(rng.choice(list(b"ACGTN"), size=L, p=[.24, .24, .24, .24, .04]).tolist())
+        if dirty and i % 7 == 2:  # characters CFasta sloughs, inside and at the end of the sequence line
+            seq = seq[:L // 2] + b" 4*." + seq[L // 2:] + b"  "
         qual = bytes(rng.integers(33, 74, size=L).astype(np.uint8).tolist())
         if i % 5 == 0:
             qual = b"@" + qual[1:]  # a quality line may begin with '@'
@@ -124,6 +126,16 @@ def test_fastq_ingest(ix, crlf, trail):
     _check(ix, text)
     for chunk in (1500, 8192, 100000):
         _check(ix, text, chunk=chunk)
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_fastq_ingest_with_sloughed_characters(ix, crlf):
+    """a sequence line that holds more than bases: the parser's one-thread-per-record length (line length) is found wrong by
+    the encoder and the exact count is redone"""
+    rng = np.random.default_rng(29)
+    text = _fastq(rng, 600, crlf, True, dirty=True)
+    _check(ix, text)
+    _check(ix, text, chunk=3000)
 
 
 def test_ingest_rejects_other_text(ix, k4):
