@@ -133,20 +133,27 @@ __global__ void __launch_bounds__(64) k4k_fastx_encode(const uint8_t* __restrict
                                                        const uint32_t* __restrict__ seq_span, const uint64_t* __restrict__ offs,
                                                        int64_t n_rec, uint8_t* __restrict__ reads,
                                                        const uint32_t* __restrict__ expect, uint32_t* __restrict__ mismatch) {
-  const int lane = threadIdx.x;
-  for (int64_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
-    const uint8_t* src = text + seq_off[r];
-    const uint32_t span = seq_span[r];
-    uint8_t* dst = reads + offs[r];
+  // four records per wave, 16 lanes each: a record is a chain of dependent loads (its offsets, then its bytes), and one
+  // chain per wave at a time left the kernel waiting on them
+  const int lane = threadIdx.x, grp = lane >> 4, gl = lane & 15;
+  for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < n_rec; r0 += (int64_t)gridDim.x * 4) {
+    const int64_t r = r0 + grp;
+    const bool on = r < n_rec;
+    const uint8_t* src = text + (on ? seq_off[r] : 0u);
+    const uint32_t span = on ? seq_span[r] : 0u;
+    uint8_t* dst = reads + (on ? offs[r] : 0ull);
+    uint32_t span_max = span;
+    span_max = max(span_max, (uint32_t)__shfl_xor(span_max, 16, 64));
+    span_max = max(span_max, (uint32_t)__shfl_xor(span_max, 32, 64));
     uint32_t done = 0;
-    for (uint32_t q = 0; q < span; q += 64) {
-      const uint8_t c = q + lane < span ? src[q + lane] : (uint8_t)' ';
+    for (uint32_t q = 0; q < span_max; q += 16) {
+      const uint8_t c = q + gl < span ? src[q + gl] : (uint8_t)' ';
       const bool keep = !k4d_seq_skip(c);
-      const unsigned long long m = __ballot(keep);
-      if (keep) dst[done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k4d_base_code(c);
-      done += (uint32_t)__popcll(m);
+      const uint32_t m = (uint32_t)(__ballot(keep) >> (16 * grp)) & 0xFFFFu;
+      if (keep) dst[done + (uint32_t)__popc(m & ((1u << gl) - 1u))] = k4d_base_code(c);
+      done += (uint32_t)__popc(m);
     }
-    if (expect && lane == 0 && done != expect[r]) *mismatch = 1u;
+    if (expect && on && gl == 0 && done != expect[r]) *mismatch = 1u;
   }
 }
 
@@ -326,7 +333,7 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
     K4_HIP(ix, tmp3.alloc(tb));
     K4_HIP(ix, rocprim::exclusive_scan(tmp3.p, tb, (const uint32_t*)d_lens, (uint64_t*)d_offs, reads_base, (size_t)n_rec,
                                        rocprim::plus<uint64_t>(), st));
-    hipLaunchKernelGGL(k4k_fastx_encode, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 16)), dim3(64), 0, st, text, so.as<uint32_t>(),
+    hipLaunchKernelGGL(k4k_fastx_encode, dim3((unsigned)std::min<int64_t>((n_rec + 3) / 4, 1 << 16)), dim3(64), 0, st, text, so.as<uint32_t>(),
                        ss.as<uint32_t>(), (const uint64_t*)d_offs, n_rec, (uint8_t*)d_reads,
                        exact ? (const uint32_t*)nullptr : (const uint32_t*)d_lens, reinterpret_cast<uint32_t*>(tot.as<unsigned long long>() + 3));
     K4_HIP(ix, hipGetLastError());
