@@ -77,26 +77,37 @@ __global__ void __launch_bounds__(256) k4k_fastx_records(K4FastxArgs a) {
   if (bad) atomicAdd(&a.tot[2], 1ull);
 }
 
-// one wave per record: bases = bytes of the sequence span that are not white space (coalesced along the span)
+// four records per wave (16 lanes each): bases = bytes of the sequence span that CFasta keeps
 __global__ void __launch_bounds__(64) k4k_fastx_count(const uint8_t* __restrict__ text, const uint32_t* __restrict__ seq_off,
                                                       const uint32_t* __restrict__ seq_span, int64_t n_rec,
                                                       uint32_t* __restrict__ lens, unsigned long long* __restrict__ tot) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, grp = lane >> 4, gl = lane & 15;
   unsigned long long sum = 0;
   uint32_t mx = 0;
-  for (int64_t r = blockIdx.x; r < n_rec; r += gridDim.x) {
-    const uint8_t* src = text + seq_off[r];
-    const uint32_t span = seq_span[r];
+  for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < n_rec; r0 += (int64_t)gridDim.x * 4) {
+    const int64_t r = r0 + grp;
+    const bool on = r < n_rec;
+    const uint8_t* src = text + (on ? seq_off[r] : 0u);
+    const uint32_t span = on ? seq_span[r] : 0u;
+    uint32_t span_max = span;
+    span_max = max(span_max, (uint32_t)__shfl_xor(span_max, 16, 64));
+    span_max = max(span_max, (uint32_t)__shfl_xor(span_max, 32, 64));
     uint32_t n = 0;
-    for (uint32_t q = 0; q < span; q += 64) {
-      const bool keep = q + lane < span && !k4d_seq_skip(src[q + lane]);
-      n += (uint32_t)__popcll(__ballot(keep));
+    for (uint32_t q = 0; q < span_max; q += 16) {
+      const bool keep = q + gl < span && !k4d_seq_skip(src[q + gl]);
+      n += (uint32_t)__popc((uint32_t)(__ballot(keep) >> (16 * grp)) & 0xFFFFu);
     }
-    if (lane == 0) lens[r] = n;
-    sum += n;
-    mx = max(mx, n);
+    if (on && gl == 0) {
+      lens[r] = n;
+      sum += n;
+      mx = max(mx, n);
+    }
   }
-  if (lane == 0) {  // (the tallies are wave-uniform)
+  for (int d = 32; d > 0; d >>= 1) {
+    sum += __shfl_down(sum, d, 64);
+    mx = max(mx, (uint32_t)__shfl_down(mx, d, 64));
+  }
+  if (lane == 0) {
     if (sum) atomicAdd(&tot[0], sum);
     if (mx) atomicMax(&tot[1], (unsigned long long)mx);
   }
@@ -321,7 +332,7 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
   bool exact = !fastq;
   for (;;) {
     if (exact)
-      hipLaunchKernelGGL(k4k_fastx_count, dim3((unsigned)std::min<int64_t>(n_rec, 1 << 14)), dim3(64), 0, st, text, so.as<uint32_t>(),
+      hipLaunchKernelGGL(k4k_fastx_count, dim3((unsigned)std::min<int64_t>((n_rec + 3) / 4, 1 << 14)), dim3(64), 0, st, text, so.as<uint32_t>(),
                          ss.as<uint32_t>(), n_rec, (uint32_t*)d_lens, tot.as<unsigned long long>());
     else
       hipLaunchKernelGGL(k4k_fastq_lens, dim3((unsigned)std::min<int64_t>((n_rec + 255) / 256, 4096)), dim3(256), 0, st, text,
