@@ -15,8 +15,11 @@ the per-rank NAR histogram after the timed region (the "final aligned-read count
 Setup that is NOT timed: genome + reads synthesis on the GPU (torch RNG), suffix-array construction on the GPU
 (k4_build_sa_device), index packing + k-mer table (k4_open_device), workspace reservation.
 Extra objects in the JSON line: "roofline" (algorithmic bytes of SURVEY.md 8(d) with run-time counted lookups and
-candidates / live HIP-event duration of k4k_align_fast) and "cpu_baseline" (the CPU oracle, all host cores, on a bounded
-sample of the same reads and the same index; also used as a read-for-read parity check at full scale).
+candidates / live HIP-event duration of the k4k_align_step launches of a batch; `traffic` = the PMC-measured HBM bytes of
+the same launches, quoted only while profiles/pmc_hbm_<workload>.json was taken on this build's kernel sources),
+"cpu_baseline" (the reference binary on the host cores when it travelled with the snapshot, else the CPU oracle; the
+oracle also serves as a read-for-read parity check at full scale) and "e2e" (FASTQ text in host memory -> SAM text in
+host memory through the overlapped pipeline; PCIe-inclusive, never `value`).
 """
 import argparse
 import ctypes as C
@@ -271,7 +274,11 @@ def time_reference(ix, reads, pe, L, max_subs, cores, sample, dev, log_fn):
                 "sample": "first %d reads, oracle/_ref/ngskit4b kalign -s%d -T%d on the same index as a %.1f GB .sfx file; "
                           "align phase %.1f s by its log (includes kit4b's 5 s start-up sleep, worker threads already "
                           "running), whole run %.1f s" % (sample, max_subs, cores, os.path.getsize(sfx) / 1e9, t_al, wall),
-                "align_s": t_al, "wall_s": wall, "nar": {k: v for k, v in hist.items() if v}}
+                "align_s": t_al, "wall_s": wall,
+                # the same interval net of the fixed 5 s sleep (an upper bound on the reference's rate: its
+                # workers do align during the sleep)
+                "value_net_of_sleep": (sample / (t_al - 5.0) / 1e6) if t_al > 5.5 else None,
+                "nar": {k: v for k, v in hist.items() if v}}
     except Exception as e:  # the port's number is still reported
         log_fn("reference baseline failed: %r" % (e,))
         return None
@@ -279,53 +286,217 @@ def time_reference(ix, reads, pe, L, max_subs, cores, sample, dev, log_fn):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def main():
+WORKLOADS = {  # chroms, units (reads / pairs) per GPU per step, read length, -s, paired, Mbp per chromosome, implanted repeats
+    "c1": (5, 10_000, 100, 0, False, 1.0, 0),
+    "c2": (24, 50_000_000, 100, 2, False, 125.0, 0),
+    "c3": (24, 50_000_000, 150, 2, True, 125.0, 0),
+    "c5": (120, 40_000_000, 150, 3, True, 125.0, 0),
+    "rep": (8, 50_000_000, 100, 2, False, 125.0, 40_000),
+}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c5"], default="c2",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c1: 10 k x 100 bp SE vs 5 x 1 Mbp, -s0 (the reference's own CPU-runnable case; launch-bound here); "
                          "c2 (default, the BASELINE metric's configuration): 50 M x 100 bp SE vs 3 Gbp, -s2; "
                          "c3: 50 M pairs 2x150 bp vs 3 Gbp, -s2 -U2 -d200 -D600; c5: 2x150 bp pairs vs 15 Gbp, -s3 -U2 "
-                         "(40 M pairs per step: the 200 M of BASELINE config 5 do not fit one GPU next to the 162 GB index)")
+                         "(40 M pairs per step: the 200 M of BASELINE config 5 do not fit one GPU next to the 162 GB index); "
+                         "rep: 50 M x 100 bp SE vs a repeat-rich 1 Gbp genome (40 000 implanted copies, N runs), -s2 -- the "
+                         "secondary tracked line for real-genome-like input, bound by the general kernel")
     ap.add_argument("--chroms", type=int, default=None)
     ap.add_argument("--chrom-mbp", type=float, default=None)
     ap.add_argument("--reads", type=int, default=None, help="reads (SE) or pairs (PE) per GPU per step")
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--max-subs", type=int, default=None)
     ap.add_argument("--kmer-k", type=int, default=0)
-    ap.add_argument("--repeats", type=int, default=0, help="implant this many repeat copies and N runs (stress; not the BASELINE workload)")
+    ap.add_argument("--repeats", type=int, default=None, help="implant this many repeat copies and N runs (stress; not the BASELINE workload)")
     ap.add_argument("--n-frac", type=float, default=0.0, help="fraction of reads given one N (general-kernel stress; not the BASELINE workload)")
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="upper bound on reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--ref-sample", type=int, default=8_000_000,
                     help="reads given to the real reference binary (oracle/_ref/ngskit4b) when it is present (0 = skip)")
-    args = ap.parse_args()
-    wl = {"c1": (5, 10_000, 100, 0, False, 1.0), "c2": (24, 50_000_000, 100, 2, False, 125.0),
-          "c3": (24, 50_000_000, 150, 2, True, 125.0), "c5": (120, 40_000_000, 150, 3, True, 125.0)}[args.workload]
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000,
+                    help="reads of the end-to-end leg (FASTQ text in host memory -> SAM text in host memory; C2 at N=1 only, 0 = skip)")
+    args = ap.parse_args(argv)
+    wl = WORKLOADS[args.workload]
     args.chroms = wl[0] if args.chroms is None else args.chroms
     args.reads = wl[1] if args.reads is None else args.reads
     args.read_len = wl[2] if args.read_len is None else args.read_len
     args.max_subs = wl[3] if args.max_subs is None else args.max_subs
-    pe = wl[4]
+    args.pe = wl[4]
     args.chrom_mbp = wl[5] if args.chrom_mbp is None else args.chrom_mbp
-    std_cfg = ((args.chroms, args.reads, args.read_len, args.max_subs) == wl[:4] and args.chrom_mbp == wl[5] and args.n_frac == 0
-               and args.repeats == 0)
+    args.repeats = wl[6] if args.repeats is None else args.repeats
+    args.std_cfg = ((args.chroms, args.reads, args.read_len, args.max_subs) == wl[:4] and args.chrom_mbp == wl[5]
+                    and args.n_frac == 0 and args.repeats == wl[6])
+    return args
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+# ---- the rank / shard / collective arithmetic of the N > 1 path (tests/test_multirank_gloo.py runs exactly these) -------
+def rank_env():
+    """(rank, local_rank, world) as torch.distributed.run exports them; a plain `python bench.py` is rank 0 of 1"""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_seed(pe, rank):
+    """every rank synthesises its OWN shard of reads (weak scaling: per-GPU work is fixed); pairs stay on one rank"""
+    return READS_SEED + (2 if pe else 0) + rank
+
+
+def dist_setup(backend, world, dev):
+    """one process per GPU; backend "nccl" is RCCL over xGMI on ROCm (tests: "gloo" on the CPU).  K4_BENCH_FORCE_DIST=1
+    takes this path with one rank too (a rehearsal of the N > 1 code on a one-GPU box)."""
+    if not (world > 1 or bool(os.environ.get("K4_BENCH_FORCE_DIST"))):
+        return None
+    import torch.distributed as dist
+
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    return dist
+
+
+def timed_steps(step, sync, dist, steps, warmup, dev, before_timing=None):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + device synchronise on both sides; the MAX over
+    ranks of the elapsed time (the job is as slow as its slowest rank)"""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    if before_timing is not None:
+        before_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def merge_counts(nar_column, dist):
+    """the ONLY collective on this path, after the timed region: all-reduce(SUM) of the per-rank NAR histogram (north
+    star: "RCCL ... only for the final aligned-read count/merge")"""
+    hist = torch.bincount(nar_column.to(torch.int64), minlength=20)[:20]
+    if dist is not None:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    return hist.tolist()
+
+
+def job_value(reads_per_rank, world, steps, elapsed):
+    """whole-job throughput in M reads/s: the reads ALL ranks processed in the timed steps / the slowest rank's time"""
+    return reads_per_rank * world * steps / elapsed / 1e6
+
+
+def kernel_src_sha256():
+    """hash of the sources the step kernels are compiled from: a PMC record (profiles/pmc_hbm_<workload>.json) is only
+    quoted as `roofline.traffic` while it was taken on exactly these"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("k4_align.hip", "k4_device.h", "k4_internal.h"):
+        h.update(open(os.path.join(ROOT, "kit4b_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+class GpuEngine:
+    """the product path: libk4sfx.so (hand-written HIP, gfx950) through its C ABI"""
+    backend = "nccl"
+    is_gpu = True
+
+    def device(self, local_rank):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        return torch.device("cuda", local_rank)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def build_index(self, seq, n_chrom, chrom_len, kmer_k, log_fn):
+        n = seq.numel()
+        dev = seq.device
+        t0 = time.time()
+        self.el = 4 if n < 4_000_000_000 else 5  # cThres8ByteSfxEls, libkit4b/SfxArray.h:184
+        self.sa = torch.empty(n * self.el + 16, dtype=torch.uint8, device=dev)
+        k4.build_sa_device(n, self.el, seq.data_ptr(), self.sa.data_ptr(), device=self.local_rank)
+        self.t_sa = time.time() - t0
+        log_fn("suffix array (%d elements) built on the GPU in %.1fs" % (n, self.t_sa))
+        t0 = time.time()
+        self.names = ["chr%d" % (i + 1) for i in range(n_chrom)]
+        ents = k4.make_entries(self.names, [chrom_len] * n_chrom)
+        self.ix = k4.SfxIndex.from_device(n, self.el, seq.data_ptr(), self.sa.data_ptr(), ents, dataset="syn3g",
+                                          device=self.local_rank, kmer_k=kmer_k, keep=(self.sa,))
+        self.info = self.ix.info()
+        self.ix.set_max_iter(5000)  # cDfltKASensCoreIters, KAligner.cpp:373-388
+        log_fn("index packed: k=%d, %.1f GB in HBM, %.1fs" % (self.info["kmer_k"], self.info["device_bytes"] / 1e9, time.time() - t0))
+
+    def prepare(self, reads, n_units, L, pe, max_subs):
+        dev = reads.device
+        n_reads = reads.shape[0]
+        self.pe, self.n_units, self.n_reads, self.L = pe, n_units, n_reads, L
+        self.reads = reads
+        self.offs = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
+        self.lens = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
+        if pe:
+            self.out_pe = torch.zeros((n_reads, 10), dtype=torch.int32, device=dev)  # k4_pe_read records (40 B)
+        else:
+            self.out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
+            self.hits = torch.zeros((n_reads, 4), dtype=torch.int32, device=dev)
+        self.kp = k4.KalignParams(max_subs, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+        self.pp = k4.PeParams(2, 200, 600, 0)  # -U2 -d200 -D600
+        self.ix.reserve(n_reads, L, 10 if pe else 1)
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def step(self):
+        if self.pe:
+            self.ix.kalign_pe_batch_dev(self.kp, self.pp, self.n_units, self.L, self.reads.data_ptr(), self.offs.data_ptr(),
+                                        self.lens.data_ptr(), self.out_pe.data_ptr(), self.stream)
+        else:
+            self.ix.kalign_batch_dev(self.kp, self.n_reads, self.L, self.reads.data_ptr(), self.offs.data_ptr(),
+                                     self.lens.data_ptr(), self.out.data_ptr(), self.hits.data_ptr(), self.stream)
+
+    def timing_begin(self):
+        self.ix.reset_counters()
+        self.ix.enable_kernel_timing(True)
+        self.ix.kernel_times()
+
+    def timing_end(self):
+        fast_ms, launches = self.ix.kernel_times()
+        self.ix.enable_kernel_timing(False)
+        return fast_ms, launches, self.ix.counters()
+
+    def results(self):
+        """(out [n, 6] i32: the k4_read_result columns, hits [n, 4] i32: the 16-byte hit, out_pe or None)"""
+        if self.pe:  # the SE-shaped views of the PE records: nar, and the 16-byte hit
+            out = torch.zeros((self.n_reads, 6), dtype=torch.int32, device=self.reads.device)
+            out[:, 4] = self.out_pe[:, 0]
+            return out, self.out_pe[:, 6:10].contiguous(), self.out_pe
+        return self.out, self.hits, None
+
+    def close(self):
+        self.ix.close()
+
+
+def run(args, engine):
+    rank, local_rank, world = rank_env()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # K4_BENCH_FORCE_DIST=1: take the RCCL path with one rank too (a rehearsal of the N > 1 code on a one-GPU box)
-    use_dist = world > 1 or bool(os.environ.get("K4_BENCH_FORCE_DIST"))
-    if use_dist:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL over xGMI on ROCm
+    dev = engine.device(local_rank)
+    dist = dist_setup(engine.backend, world, dev)
+    pe = args.pe
 
     chrom_len = int(args.chrom_mbp * 1e6)
     n_chrom = args.chroms
@@ -335,94 +506,34 @@ def main():
     if args.repeats:
         implant_repeats(seq, n_chrom, chrom_len, args.repeats, dev)
     n = seq.numel()
-    torch.cuda.synchronize()
+    engine.sync()
     log(rank, "genome %d x %d bp = %.3f Gbp in %.1fs" % (n_chrom, chrom_len, n_chrom * chrom_len / 1e9, time.time() - t0))
-    t0 = time.time()
-    el = 4 if n < 4_000_000_000 else 5  # cThres8ByteSfxEls, libkit4b/SfxArray.h:184
-    sa = torch.empty(n * el + 16, dtype=torch.uint8, device=dev)
-    k4.build_sa_device(n, el, seq.data_ptr(), sa.data_ptr(), device=local_rank)
-    t_sa = time.time() - t0
-    log(rank, "suffix array (%d elements) built on the GPU in %.1fs" % (n, t_sa))
-    t0 = time.time()
-    names = ["chr%d" % (i + 1) for i in range(n_chrom)]
-    ents = k4.make_entries(names, [chrom_len] * n_chrom)
-    ix = k4.SfxIndex.from_device(n, el, seq.data_ptr(), sa.data_ptr(), ents, dataset="syn3g", device=local_rank,
-                                 kmer_k=args.kmer_k, keep=(sa,))
-    info = ix.info()
-    ix.set_max_iter(5000)  # cDfltKASensCoreIters, KAligner.cpp:373-388
-    log(rank, "index packed: k=%d, %.1f GB in HBM, %.1fs" % (info["kmer_k"], info["device_bytes"] / 1e9, time.time() - t0))
+    engine.build_index(seq, n_chrom, chrom_len, args.kmer_k, lambda *a: log(rank, *a))
+    el, info = engine.el, engine.info
 
     t0 = time.time()
     n_units = args.reads                    # reads (SE) or pairs (PE)
     n_reads = 2 * n_units if pe else n_units  # reads through the SE pass
     if pe:
-        reads, truth = make_pe_reads(seq, n_chrom, chrom_len, n_units, L, READS_SEED + 2 + rank, dev)
+        reads, truth = make_pe_reads(seq, n_chrom, chrom_len, n_units, L, shard_seed(pe, rank), dev)
     else:
-        reads, truth = make_reads(seq, n_chrom, chrom_len, n_reads, L, READS_SEED + rank, dev)
+        reads, truth = make_reads(seq, n_chrom, chrom_len, n_reads, L, shard_seed(pe, rank), dev)
     if args.n_frac > 0:
         g2 = torch.Generator(device=dev)
         g2.manual_seed(7)
         sel = torch.nonzero(torch.rand(n_reads, device=dev, generator=g2) < args.n_frac).flatten()
         reads[sel, torch.randint(0, L, (sel.numel(),), device=dev, generator=g2)] = 4
         truth[sel, 3] = 99  # excluded from the truth property below
-    offs = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
-    lens = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
-    if pe:
-        out_pe = torch.zeros((n_reads, 10), dtype=torch.int32, device=dev)  # k4_pe_read records (40 B)
-    else:
-        out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
-        hits = torch.zeros((n_reads, 4), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
+    engine.prepare(reads, n_units, L, pe, args.max_subs)
+    engine.sync()
     log(rank, "%d reads x %d bp synthesised in %.1fs" % (n_reads, L, time.time() - t0))
 
-    kp = k4.KalignParams(args.max_subs, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
-    pp = k4.PeParams(2, 200, 600, 0)  # -U2 -d200 -D600
-    ix.reserve(n_reads, L, 10 if pe else 1)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        if pe:
-            ix.kalign_pe_batch_dev(kp, pp, n_units, L, reads.data_ptr(), offs.data_ptr(), lens.data_ptr(),
-                                   out_pe.data_ptr(), stream)
-        else:
-            ix.kalign_batch_dev(kp, n_reads, L, reads.data_ptr(), offs.data_ptr(), lens.data_ptr(), out.data_ptr(),
-                                hits.data_ptr(), stream)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ix.reset_counters()
-    ix.enable_kernel_timing(True)
-    ix.kernel_times()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    fast_ms, launches = ix.kernel_times()
-    ix.enable_kernel_timing(False)
-    ctr = ix.counters()
+    elapsed = timed_steps(engine.step, engine.sync, dist, args.steps, args.warmup, dev, before_timing=engine.timing_begin)
+    fast_ms, launches, ctr = engine.timing_end()
 
     # ---- after the timed region: the count/merge collective and the parity checks --------------------------------
-    if pe:  # the SE-shaped views of the PE records: nar, and the 16-byte hit
-        out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
-        out[:, 4] = out_pe[:, 0]
-        hits = out_pe[:, 6:10].contiguous()
-    nar_hist = torch.bincount(out[:, 4].to(torch.int64), minlength=20)[:20]
-    if use_dist:
-        dist.all_reduce(nar_hist, op=dist.ReduceOp.SUM)  # RCCL: the only collective on this path
-    nar = nar_hist.tolist()
+    out, hits, out_pe = engine.results()
+    nar = merge_counts(out[:, 4], dist)
 
     # (1) truth property on i.i.d. genomes: AA at the truth locus with Mismatches == nsubs iff nsubs <= MaxTotMM, else NL
     max_tot_mm = 0 if args.max_subs == 0 else max(1, int(0.5 + L * args.max_subs / 100.0))
@@ -448,86 +559,17 @@ def main():
     # (2) CPU baseline = the oracle on all host cores over a bounded sample, same index, same reads (rank 0, N=1 only)
     cpu = None
     parity_sample = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_bindings import Entry as OEntry, Oracle
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and engine.is_gpu:
+        cpu, parity_sample = cpu_baseline(args, engine, seq, reads, out, hits, out_pe, n, el, n_chrom, chrom_len, L, pe, dev, rank)
 
-        O = Oracle()
-        t0 = time.time()
-        seq_h = seq.cpu().numpy()
-        sa_h = sa[: n * el].cpu().numpy()
-        oents = (OEntry * n_chrom)()
-        for i in range(n_chrom):
-            oents[i].entry_id = i + 1
-            oents[i].fblock_id = 1
-            oents[i].name = names[i].encode()
-            oents[i].seq_len = chrom_len
-            oents[i].start_ofs = i * (chrom_len + 1)
-            oents[i].end_ofs = i * (chrom_len + 1) + chrom_len - 1
-        ho = O.L.k4o_from_parts(n, el, seq_h.ctypes.data, sa_h.ctypes.data, n_chrom, oents, b"syn3g")
-        O.set_max_iter(ho, 5000)
-        log(rank, "index copied to the host for the CPU baseline in %.1fs" % (time.time() - t0))
-        # the GPU box gives one GPU a 16-core CPU share (os.cpu_count() reports the whole host)
-        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
-        l_all = np.full(min(args.cpu_sample, n_reads), L, dtype=np.uint32)
-
-        def run_cpu(a, b):  # reads [a, b) (PE: a and b even, i.e. whole pairs)
-            if pe:
-                from oracle_bindings import oracle_kalign_pe
-
-                m = (b - a) // 2
-                c1 = reads[a:b:2].cpu().numpy().reshape(-1)
-                c2 = reads[a + 1:b:2].cpu().numpy().reshape(-1)
-                o_h = (np.arange(m, dtype=np.uint64) * L)
-                t0 = time.perf_counter()
-                r = oracle_kalign_pe(O, ho, (c1, o_h, l_all[:m]), (c2, o_h, l_all[:m]), pe_mode=2, pair_min_len=200,
-                                     pair_max_len=600, threads=cores, max_subs=args.max_subs)
-                return r, time.perf_counter() - t0
-            cat = reads[a:b].cpu().numpy().reshape(-1)
-            o_h = (np.arange(b - a, dtype=np.uint64) * L)
-            t0 = time.perf_counter()
-            r = O.kalign_batch(ho, (cat, o_h, l_all[: b - a]), max_subs=args.max_subs, threads=cores)
-            return r, time.perf_counter() - t0
-
-        # pilot on 50k reads (also warms the page cache of the 15 GB index), then a sample sized for ~15 s of CPU work
-        S0 = min(50_000, n_reads)
-        _, t_pilot = run_cpu(0, S0)
-        S = int(max(S0, min(args.cpu_sample, n_reads, 15.0 * S0 / max(t_pilot, 1e-3)))) & ~1
-        ro, t_cpu = run_cpu(0, S)
-        cpu = {"value": S / t_cpu / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port",
-               "sample": "first %d of the %d reads, same index (%.2f Gbp), oracle/k4oracle.c on %d threads, %.1f s"
-                         % (S, n_reads, n_chrom * chrom_len / 1e9, cores, t_cpu)}
-        if pe:
-            g_rec = out_pe[:S].cpu().numpy().view(np.uint8).reshape(S, 40)
-            o_rec = ro.view(np.uint8).reshape(S, 40)
-            acc = g_rec.view(np.int32)[:, 0] == k4.NAR_ACCEPTED
-            parity_sample = {"reads": S, "result_mismatches": int((g_rec[:, :24] != o_rec[:, :24]).any(axis=1).sum()),
-                             "hit_mismatches": int((g_rec[acc, 24:] != o_rec[acc, 24:]).any(axis=1).sum())}
-        else:
-            g_out = out[:S].cpu().numpy()
-            g_hits = hits[:S].cpu().numpy().view(np.uint8).reshape(S, 16)
-            o_out = ro["out"].view(np.int32).reshape(S, 6)
-            o_hits = ro["hits"][:, 0].view(np.uint8).reshape(S, 16)
-            parity_sample = {"reads": S, "result_mismatches": int((g_out != o_out).any(axis=1).sum()),
-                             "hit_mismatches": int((g_hits != o_hits).any(axis=1).sum())}
-        O.close(ho)
-        del seq_h, sa_h
-        # the reference itself, when its binary travelled with the snapshot: that number becomes cpu_baseline, the
-        # port's stays beside it (and is what the read-for-read comparison above ran against)
-        if args.ref_sample > 0 and n_reads >= 1_000_000:  # (kit4b's fixed 5 s start-up sleep would swamp a small sample)
-            Sr = min(args.ref_sample, n_reads) & ~1
-            ref = time_reference(ix, reads, pe, L, args.max_subs, cores, Sr, dev, lambda *a: log(rank, *a))
-            if ref is not None:
-                g_nar = torch.bincount(out[:Sr, 4].to(torch.int64), minlength=20).tolist()
-                ref["nar_equal_to_gpu"] = all(ref["nar"].get(k, 0) == g_nar[c] for k, c in
-                                              (("AA", 1), ("EN", 2), ("NL", 3), ("MH", 4), ("ML", 5), ("UP", 15)))
-                ref["port"] = cpu
-                cpu = ref
+    # (3) end to end: FASTQ text in host memory -> SAM text in host memory through the overlapped pipeline (never `value`)
+    e2e = None
+    if rank == 0 and world == 1 and engine.is_gpu and args.e2e_reads > 0 and not pe and hasattr(engine, "e2e"):
+        e2e = engine.e2e(reads, min(args.e2e_reads, n_reads), L, args.max_subs, lambda *a: log(rank, *a))
 
     if rank == 0:
-        total_reads = n_reads * world * args.steps
-        value = total_reads / elapsed / 1e6
-        # roofline of the dominant kernel (k4k_align_fast), SURVEY.md 8(d) algorithmic bytes, counted at run time
+        value = job_value(n_reads, world, args.steps, elapsed)
+        # roofline of the dominant kernel (k4k_align_step), SURVEY.md 8(d) algorithmic bytes, counted at run time
         Lbits = math.ceil(math.log2(n))
         E = el
         per_launch = {k: ctr[k] / max(launches, 1) for k in ("n_reads", "n_lookup", "n_probe", "n_cand", "n_slow")}
@@ -536,14 +578,24 @@ def main():
         alg_bytes = per_launch["n_lookup"] * b_lookup + per_launch["n_cand"] * b_cand + per_launch["n_reads"] * (L + 16)
         k_ms = fast_ms / max(launches, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        full = args.workload == "c2" and std_cfg
+        # PMC-measured HBM bytes of the same launches (profiles/run_profile_pmc.sh + summarize.py): quoted only for the
+        # named configuration and only while the record was taken on exactly the kernel sources of this run
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-        if full and os.path.exists(pmc):  # PMC-measured HBM bytes of the same launches (profiles/run_profile_pmc.sh)
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        traffic_source = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_hbm_%s.json" % args.workload)
+        if os.path.exists(pmc) and engine.is_gpu:
+            rec = json.load(open(pmc))
+            cur = kernel_src_sha256()
+            match = rec.get("kernel_src_sha256") == cur
+            traffic_source = {"file": "profiles/pmc_hbm_%s.json" % args.workload, "tag": rec.get("tag"), "head": rec.get("head"),
+                              "kernel_src_sha256": rec.get("kernel_src_sha256"), "matches_this_build": match,
+                              "named_configuration": bool(args.std_cfg)}
+            if match and args.std_cfg:
+                traffic = rec.get("hbm_bytes_per_launch")
         line = {
-            "metric": "Mreads/sec aligned (100 bp SE vs 3 Gbp .sfx)" if not pe else
-                      "Mreads/sec aligned (2x%d bp PE vs %.0f Gbp .sfx; both ends counted)" % (L, n_chrom * chrom_len / 1e9),
+            "metric": "Mreads/sec aligned (100 bp SE vs 3 Gbp .sfx)" if args.workload == "c2" else
+                      "Mreads/sec aligned (%s%d bp %s vs %.0f Gbp .sfx%s)" % ("2x" if pe else "", L, "PE" if pe else "SE",
+                                                                            n_chrom * chrom_len / 1e9, "; both ends counted" if pe else ""),
             "value": value,
             "unit": "Mreads/s",
             "n_gpus": world,
@@ -556,20 +608,27 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": ("%s: %d x %s%d bp %s per GPU vs %.2f Gbp synthetic genome (%d x %d bp), kalign -s%d%s"
+                "workload": ("%s: %d x %s%d bp %s per GPU vs %.2f Gbp synthetic genome (%d x %d bp%s), kalign -s%d%s"
                              % (args.workload.upper(), n_units, "2x" if pe else "", L, "pairs" if pe else "SE reads",
-                                n_chrom * chrom_len / 1e9, n_chrom, chrom_len, args.max_subs,
+                                n_chrom * chrom_len / 1e9, n_chrom, chrom_len,
+                                ", %d implanted repeat copies + N runs" % args.repeats if args.repeats else "", args.max_subs,
                                 " -U2 -d200 -D600" if pe else ""))
-                + ("" if std_cfg else " [REDUCED: not the named configuration]")
+                + ("" if args.std_cfg else " [REDUCED: not the named configuration]")
                 + ("" if args.workload == "c2" else " [not the BASELINE metric's configuration, which is C2]"),
                 "reads_per_gpu": n_reads, "read_len": L, "genome_bp": n_chrom * chrom_len, "sfx_el_size": el,
                 "kmer_table_k": info["kmer_k"], "index_hbm_gb": round(info["device_bytes"] / 1e9, 2),
                 "parallelism": "reads sharded per GPU, index replicated, RCCL all-reduce of NAR counts only",
-                "sa_build_s": round(t_sa, 1),
+                "sa_build_s": round(engine.t_sa, 1),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+                "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if (traffic and k_ms > 0) else None,
+                "traffic_frac": (traffic / (k_ms * 1e-3) / HBM_PEAK) if (traffic and k_ms > 0) else None,
+                "traffic_source": traffic_source,
+                "definition": "achieved/frac: ALGORITHMIC bytes (SURVEY 8(d): lookups x ceil(log2 N) x (E+8) + candidates x (E+8 ceil(R/32)) "
+                              "+ R+16 per read, lookups and candidates counted at run time) / HIP-event time of the step kernels; "
+                              "traffic*: HBM bytes measured by the PMC passes (FETCH_SIZE x2 + WRITE_SIZE) over the same time",
                 "kernel": "k4k_align_step (the launches of one batch: one per AlignReads phase)", "kernel_ms": k_ms,
                 "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -580,14 +639,101 @@ def main():
                 "slow_path_reads_per_launch": per_launch["n_slow"],
             },
             "cpu_baseline": cpu,
+            "e2e": e2e,
             "parity": {"nar_histogram": {"AA": nar[1], "EN": nar[2], "NL": nar[3], "MH": nar[4], "ML": nar[5], "UP": nar[15],
                                          "other": int(sum(nar)) - nar[1] - nar[2] - nar[3] - nar[4] - nar[5] - nar[15]},
                        "truth_property_violations_rank0": truth_viol, "oracle_sample": parity_sample},
         }
         print(json.dumps(line), flush=True)
-    ix.close()
-    if use_dist:
+    engine.close()
+    if dist is not None:
         dist.destroy_process_group()
+
+
+def cpu_baseline(args, engine, seq, reads, out, hits, out_pe, n, el, n_chrom, chrom_len, L, pe, dev, rank):
+    """rank 0, N = 1: the oracle port on the host cores over a bounded sample (also a read-for-read parity check at full
+    scale) and, when its binary travelled with the snapshot, the reference itself (which then is `cpu_baseline`)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_bindings import Entry as OEntry, Oracle
+
+    n_reads = reads.shape[0]
+    names, sa, ix = engine.names, engine.sa, engine.ix
+    O = Oracle()
+    t0 = time.time()
+    seq_h = seq.cpu().numpy()
+    sa_h = sa[: n * el].cpu().numpy()
+    oents = (OEntry * n_chrom)()
+    for i in range(n_chrom):
+        oents[i].entry_id = i + 1
+        oents[i].fblock_id = 1
+        oents[i].name = names[i].encode()
+        oents[i].seq_len = chrom_len
+        oents[i].start_ofs = i * (chrom_len + 1)
+        oents[i].end_ofs = i * (chrom_len + 1) + chrom_len - 1
+    ho = O.L.k4o_from_parts(n, el, seq_h.ctypes.data, sa_h.ctypes.data, n_chrom, oents, b"syn3g")
+    O.set_max_iter(ho, 5000)
+    log(rank, "index copied to the host for the CPU baseline in %.1fs" % (time.time() - t0))
+    # the GPU box gives one GPU a 16-core CPU share (os.cpu_count() reports the whole host)
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    l_all = np.full(min(args.cpu_sample, n_reads), L, dtype=np.uint32)
+
+    def run_cpu(a, b):  # reads [a, b) (PE: a and b even, i.e. whole pairs)
+        if pe:
+            from oracle_bindings import oracle_kalign_pe
+
+            m = (b - a) // 2
+            c1 = reads[a:b:2].cpu().numpy().reshape(-1)
+            c2 = reads[a + 1:b:2].cpu().numpy().reshape(-1)
+            o_h = (np.arange(m, dtype=np.uint64) * L)
+            t0 = time.perf_counter()
+            r = oracle_kalign_pe(O, ho, (c1, o_h, l_all[:m]), (c2, o_h, l_all[:m]), pe_mode=2, pair_min_len=200,
+                                 pair_max_len=600, threads=cores, max_subs=args.max_subs)
+            return r, time.perf_counter() - t0
+        cat = reads[a:b].cpu().numpy().reshape(-1)
+        o_h = (np.arange(b - a, dtype=np.uint64) * L)
+        t0 = time.perf_counter()
+        r = O.kalign_batch(ho, (cat, o_h, l_all[: b - a]), max_subs=args.max_subs, threads=cores)
+        return r, time.perf_counter() - t0
+
+    # pilot on 50k reads (also warms the page cache of the 15 GB index), then a sample sized for ~15 s of CPU work
+    S0 = min(50_000, n_reads)
+    _, t_pilot = run_cpu(0, S0)
+    S = int(max(S0, min(args.cpu_sample, n_reads, 15.0 * S0 / max(t_pilot, 1e-3)))) & ~1
+    ro, t_cpu = run_cpu(0, S)
+    cpu = {"value": S / t_cpu / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port",
+           "sample": "first %d of the %d reads, same index (%.2f Gbp), oracle/k4oracle.c on %d threads, %.1f s"
+                     % (S, n_reads, n_chrom * chrom_len / 1e9, cores, t_cpu)}
+    if pe:
+        g_rec = out_pe[:S].cpu().numpy().view(np.uint8).reshape(S, 40)
+        o_rec = ro.view(np.uint8).reshape(S, 40)
+        acc = g_rec.view(np.int32)[:, 0] == k4.NAR_ACCEPTED
+        parity_sample = {"reads": S, "result_mismatches": int((g_rec[:, :24] != o_rec[:, :24]).any(axis=1).sum()),
+                         "hit_mismatches": int((g_rec[acc, 24:] != o_rec[acc, 24:]).any(axis=1).sum())}
+    else:
+        g_out = out[:S].cpu().numpy()
+        g_hits = hits[:S].cpu().numpy().view(np.uint8).reshape(S, 16)
+        o_out = ro["out"].view(np.int32).reshape(S, 6)
+        o_hits = ro["hits"][:, 0].view(np.uint8).reshape(S, 16)
+        parity_sample = {"reads": S, "result_mismatches": int((g_out != o_out).any(axis=1).sum()),
+                         "hit_mismatches": int((g_hits != o_hits).any(axis=1).sum())}
+    O.close(ho)
+    del seq_h, sa_h
+    # the reference itself, when its binary travelled with the snapshot: that number becomes cpu_baseline, the
+    # port's stays beside it (and is what the read-for-read comparison above ran against)
+    if args.ref_sample > 0 and n_reads >= 1_000_000:  # (kit4b's fixed 5 s start-up sleep would swamp a small sample)
+        Sr = min(args.ref_sample, n_reads) & ~1
+        ref = time_reference(ix, reads, pe, L, args.max_subs, cores, Sr, dev, lambda *a: log(rank, *a))
+        if ref is not None:
+            g_nar = torch.bincount(out[:Sr, 4].to(torch.int64), minlength=20).tolist()
+            ref["nar_equal_to_gpu"] = all(ref["nar"].get(k, 0) == g_nar[c] for k, c in
+                                          (("AA", 1), ("EN", 2), ("NL", 3), ("MH", 4), ("ML", 5), ("UP", 15)))
+            ref["port"] = cpu
+            cpu = ref
+    return cpu, parity_sample
+
+
+def main(argv=None, engine=None):
+    run(parse_args(argv), engine if engine is not None else GpuEngine())
 
 
 if __name__ == "__main__":

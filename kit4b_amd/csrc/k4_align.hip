@@ -1441,6 +1441,12 @@ static uint32_t next_pow2(uint64_t v) {
   return p;
 }
 
+// slots of one survivor buffer for batches of up to cap reads (see k4_reserve)
+static size_t k4_survivor_slots(size_t cap) {
+  static_assert(K4_CHUNK * 7 >= 8 * 63, "cap / 7 must cover the abandoned chunk tails");
+  return cap + cap / 7 + (size_t)2048 * 4 * K4_CHUNK + K4_CHUNK;
+}
+
 static int nch_for(int max_len) {
   if (max_len <= 128) return 4;
   if (max_len <= 160) return 5;
@@ -1460,14 +1466,21 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
     cap = (cap + 255) / 256 * 256;
     int len = std::max(fast_len, w.cap_len);
     int nch = nch_for(len);
+    // the capacities say what the pointers below can hold: zero while they are being replaced, so that a failed
+    // allocation leaves a workspace every *_dev call refuses (K4_ERR_PARAMS) instead of one with null buffers
+    w.cap_reads = 0;
+    w.cap_len = 0;
     for (void* q : {(void*)w.ids[0], (void*)w.ids[1], (void*)w.rows[0], (void*)w.rows[1], (void*)w.slow_list, (void*)w.slow_step,
                     (void*)w.huge_list, (void*)w.huge_step})
       if (q) hipFree(q);
     w.ids[0] = w.ids[1] = nullptr; w.rows[0] = w.rows[1] = nullptr; w.slow_list = nullptr; w.slow_step = nullptr;
     w.huge_list = nullptr; w.huge_step = nullptr;
-    // survivors of step t (ids + packed rows, 2*nch words each) ping-pong between two buffers
-    // every wave of the (at most 2048-block) grid may leave one partly used chunk behind
-    const size_t slots = (size_t)cap + (size_t)2048 * 4 * K4_CHUNK;
+    // Survivors of step t (ids + packed rows) ping-pong between two buffers.  Slots are handed out K4_CHUNK at a time
+    // per wave; a wave abandons the tail of its chunk (at most 63 slots) when the next ballot does not fit, and leaves
+    // one partly used chunk behind when it ends.  Step t+1 walks over step t's slots, holes included, but places only
+    // real survivors again.  So every chunk a wave has moved on from holds at least K4_CHUNK - 63 real entries: a step
+    // uses at most n * K4_CHUNK / (K4_CHUNK - 63) slots plus one chunk per wave of the (at most 2048-block) grid.
+    const size_t slots = k4_survivor_slots((size_t)cap);
     for (int b = 0; b < 2; b++) {
       K4_HIP(ix, hipMalloc(&w.ids[b], slots * 4));
       K4_HIP(ix, hipMalloc(&w.rows[b], slots * K4_ROW_WORDS(nch) * 8));
@@ -1585,7 +1598,7 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
 static int run_dev(k4_index* ix, K4AlignArgs& a, int max_len, void* stream) {
   K4Workspace& w = ix->ws;
   if (a.n_reads > w.cap_reads || std::min(max_len, K4_MAX_FAST_READ_LEN) > w.cap_len || a.max_hits > w.cap_hits ||
-      !w.slow_hash)
+      !w.slow_hash || !w.ids[0] || !w.ids[1] || !w.rows[0] || !w.rows[1] || !w.slow_list || !w.huge_list || !w.ctl)
     return k4_fail(ix, K4_ERR_PARAMS, "k4_reserve(%lld, %d, %d) must precede the *_dev call", (long long)a.n_reads,
                    max_len, a.max_hits);
   a.ix = ix->d;

@@ -1,5 +1,9 @@
 """Summarise a gpurun_out/prof_<tag> directory written by profiles/run_profile_pmc.sh into profiles/<tag>/ and refresh
-profiles/r01_pmc_hbm.json (the `traffic` figure bench.py reports).
+profiles/pmc_hbm_<workload>.json (the `traffic` figure bench.py reports).  The record carries the hash of the kernel
+sources it was taken on (as they were on the GPU box) and the commit: bench.py quotes it only while that hash equals
+the sources of the build it runs.
+
+    python profiles/summarize.py <tag> [workload=c2]
 
 HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are KB from separate --pmc passes;
 on gfx950 FETCH_SIZE tallies 64 B per 128-B request (calibrated in this run on tools/randgather: one TCC_EA0_RDREQ and
@@ -14,6 +18,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -48,9 +53,37 @@ def per_batch(kind, counter):
 
 fetch_kb, write_kb = per_batch("pmc_fetch", "FETCH_SIZE"), per_batch("pmc_write", "WRITE_SIZE")
 rdreq = per_batch("pmc_tcc", "TCC_EA0_RDREQ_sum")
-hbm = {"tag": tag, "kernel": "k4k_align_step (all phases of one 50 M-read batch)",
+import hashlib
+import subprocess
+
+h = hashlib.sha256()
+box = {}
+shaf = os.path.join(src, "kernel_src.sha256")
+if os.path.exists(shaf):
+    shutil.copy(shaf, os.path.join(dst, "kernel_src.sha256"))
+    for ln in open(shaf):
+        v, f = ln.split()
+        box[os.path.basename(f)] = v
+same = True
+for f in ("k4_align.hip", "k4_device.h", "k4_internal.h"):
+    data = open(os.path.join("kit4b_amd", "csrc", f), "rb").read()
+    h.update(data)
+    same &= box.get(f, hashlib.sha256(data).hexdigest()) == hashlib.sha256(data).hexdigest()
+head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "status", "--porcelain", "kit4b_amd/csrc"], capture_output=True, text=True).stdout.strip())
+line = {}
+try:
+    line = json.loads([l for l in open(os.path.join(src, "bench_trace.json")) if l.startswith("{")][-1])
+except Exception:
+    pass
+hbm = {"tag": tag, "workload": workload, "kernel": "k4k_align_step (all phases of one batch)",
+       "config": line.get("config", {}).get("workload"),
        "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_EA0_RDREQ": rdreq,
        "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+       "kernel_src_sha256": h.hexdigest() if same else None,
+       "kernel_src_note": "sha256 over k4_align.hip + k4_device.h + k4_internal.h; null when the sources profiled on the GPU box "
+                          "differ from the working tree at summarise time",
+       "head": head + ("+uncommitted" if dirty else ""),
        "note": "read side doubled per MI355X_MICROARCH.md (FETCH_SIZE tallies 64 B per 128-B request on gfx950)"}
-json.dump(hbm, open(os.path.join("profiles", "r01_pmc_hbm.json"), "w"), indent=1)
+json.dump(hbm, open(os.path.join("profiles", "pmc_hbm_%s.json" % workload), "w"), indent=1)
 print(json.dumps(hbm, indent=1))

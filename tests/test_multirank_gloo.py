@@ -1,67 +1,92 @@
-"""The N>1 path of bench.py on CPU: world size 2, gloo.  Checks the parts that do not need a GPU: rank/shard
-arithmetic (every read owned by exactly one rank, per-rank seeds differ), the only collective on the path (all-reduce of
-the NAR histogram and MAX of the elapsed time) and the aggregate-throughput formula."""
+"""The N>1 path of bench.py on the CPU: world size 2, gloo.  The workers call bench.run() itself -- the argument
+handling, rank environment, per-rank read shards, warm-up / barrier / timed steps, the MAX all-reduce of the elapsed time,
+the SUM all-reduce of the NAR histogram (the only collective on the path) and the JSON line are the code the driver runs
+on 8 GPUs; only the engine is swapped (tests/bench_cpu_engine.py: the CPU oracle instead of the HIP kernels, gloo
+instead of RCCL).  A bug in the real rank path turns this red."""
+import json
 import os
 import subprocess
 import sys
 import textwrap
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--steps", "2", "--warmup", "1", "--workload", "c1", "--chroms", "2", "--chrom-mbp", "0.03",
+        "--reads", "500", "--max-subs", "2"]
 
 WORKER = textwrap.dedent(
     """
-    import os, sys, json
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    import os, sys
     sys.path.insert(0, %(root)r)
     sys.path.insert(0, os.path.join(%(root)r, "tests"))
     import bench
-    import synth
-    from oracle_bindings import Oracle
-
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo")
-    # every rank holds the whole index (replicated) and aligns its own shard of reads; the CPU oracle stands in for
-    # the GPU path here -- this test is about the sharding and the collective, not the kernels
-    O = Oracle()
-    names, chroms = synth.make_genome([40000, 30000], seed=bench.GENOME_SEED)
-    h = O.build(names, chroms, threads=2)
-    n_per_rank = 600
-    reads, truth = synth.make_reads(chroms, n_per_rank, 100, seed=bench.READS_SEED + rank)
-    r = O.kalign_batch(h, reads, max_subs=2, threads=2)
-    hist = torch.from_numpy(np.bincount(r["out"]["nar"], minlength=8)[:8].astype(np.int64))
-    local = hist.clone()
-    dist.all_reduce(hist, op=dist.ReduceOp.SUM)             # the "final aligned-read count/merge"
-    t = torch.tensor([0.5 + 0.25 * rank], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)                # max over ranks of the timed region
-    first = torch.tensor([int(np.concatenate(reads[:4]).sum())], dtype=torch.int64)
-    gathered = [torch.zeros_like(first) for _ in range(world)]
-    dist.all_gather(gathered, first)
-    if rank == 0:
-        print(json.dumps(dict(total=int(hist.sum()), local=int(local.sum()), aa=int(hist[1]), tmax=float(t),
-                              value=n_per_rank * world * 3 / float(t) / 1e6,
-                              distinct_shards=len(set(int(g) for g in gathered)))))
-    dist.destroy_process_group()
+    from bench_cpu_engine import OracleEngine
+    # rank 1 is made 0.25 s per step slower: the job's time must be ITS time (MAX over ranks)
+    bench.main(["--gpus", os.environ["WORLD_SIZE"]] + %(args)r, engine=OracleEngine(step_sleep=lambda rank: 0.25 * rank))
     """
 )
 
 
-def test_world_size_2_gloo(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % dict(root=ROOT))
+def _run(tmp_path, world, port):
+    script = tmp_path / ("worker%d.py" % world)
+    script.write_text(WORKER % dict(root=ROOT, args=ARGS))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("K4_BENCH_FORCE_DIST", None)
     p = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-         "--master-port", "29531", str(script)],
-        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr",
+         "127.0.0.1", "--master-port", str(port), str(script)],
+        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    import json
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
 
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["local"] == 600 and d["total"] == 1200          # both shards counted exactly once
-    assert d["distinct_shards"] == 2                           # ranks aligned different reads
-    assert abs(d["tmax"] - 0.75) < 1e-9                        # MAX over ranks
-    assert abs(d["value"] - 1200 * 3 / 0.75 / 1e6) < 1e-12    # aggregate = all ranks' units / max time
-    assert 0.8 * 1200 < d["aa"] <= 1200
+
+def _shard_histogram(rank):
+    """what rank `rank` must have contributed, recomputed here from bench.py's own generators and seeds"""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle_bindings import Oracle
+
+    a = bench.parse_args(["--gpus", "1"] + ARGS)
+    dev = torch.device("cpu")
+    chrom_len = int(a.chrom_mbp * 1e6)
+    seq = bench.make_genome(dev, a.chroms, chrom_len)
+    reads, _ = bench.make_reads(seq, a.chroms, chrom_len, a.reads, a.read_len, bench.shard_seed(False, rank), dev)
+    O = Oracle()
+    s = seq.numpy()
+    chroms = [s[c * (chrom_len + 1): c * (chrom_len + 1) + chrom_len].copy() for c in range(a.chroms)]
+    h = O.build(["chr%d" % (i + 1) for i in range(a.chroms)], chroms, threads=2)
+    O.set_max_iter(h, 5000)
+    n, L = reads.shape
+    r = O.kalign_batch(h, (reads.numpy().reshape(-1), np.arange(n, dtype=np.uint64) * L, np.full(n, L, dtype=np.uint32)),
+                       max_subs=a.max_subs, threads=2)
+    O.close(h)
+    return np.bincount(r["out"]["nar"], minlength=20)[:20], reads.numpy()
+
+
+def test_bench_rank_code_world_size_2_gloo(tmp_path):
+    d = _run(tmp_path, 2, 29531)
+    h0, r0 = _shard_histogram(0)
+    h1, r1 = _shard_histogram(1)
+    assert not np.array_equal(r0, r1)                       # the ranks aligned different reads (per-rank seeds)
+    want = h0 + h1
+    nh = d["parity"]["nar_histogram"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1
+    assert nh["AA"] == int(want[1]) and nh["NL"] == int(want[3]) and nh["ML"] == int(want[5])
+    assert nh["AA"] + nh["EN"] + nh["NL"] + nh["MH"] + nh["ML"] + nh["UP"] + nh["other"] == 1000  # both shards, each exactly once
+    assert 0.8 * 1000 < nh["AA"] <= 1000
+    # elapsed = MAX over ranks: rank 1 sleeps 0.25 s in each of the 2 timed steps, rank 0 does not
+    assert d["ms_per_step"] >= 250.0
+    # whole-job value = the reads ALL ranks processed / the slowest rank's time
+    assert abs(d["value"] - 500 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3) / 1e6) < 1e-9 * max(1.0, d["value"])
+    assert d["parity"]["truth_property_violations_rank0"] == 0
+    assert d["roofline"]["traffic"] is None and d["cpu_baseline"] is None
+
+
+def test_bench_single_process_takes_no_collective(tmp_path):
+    d = _run(tmp_path, 1, 29533)
+    h0, _ = _shard_histogram(0)
+    assert d["n_gpus"] == 1 and d["parity"]["nar_histogram"]["AA"] == int(h0[1])
+    assert d["ms_per_step"] < 250.0
