@@ -13,7 +13,7 @@
  * Not restated (out of scope): bisulfite, colourspace, chimeric trimming, microInDel, splice.
  */
 #define _GNU_SOURCE
-#include "k4oracle.h"
+#include "k4oracle_priv.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,26 +23,6 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
-
-#define K4O_HDR_SIZE 1224       /* sizeof(tsSfxHeaderV3), pack(4) */
-#define K4O_BLOCK_HDR 20        /* tsSfxBlock up to SeqSuffix[0], pack(1) */
-#define K4O_ENTRY_SIZE 111      /* sizeof(tsSfxEntry), pack(1) */
-#define K4O_MAX_IDENT_NODES 1024000 /* cMaxNumIdentNodes, SfxArray.h:15 */
-#define K4O_DFLT_MAX_ITER 50000 /* cDfltMaxIter, SfxArray.h:12 */
-
-struct k4o_index {
-  uint64_t n;  /* ConcatSeqLen: bases + one EOS per entry == number of SA elements */
-  uint32_t el; /* SfxElSize 4|5 */
-  uint8_t* seq;
-  uint8_t* sa;
-  uint32_t n_entries;
-  k4o_entry* entries;
-  char dataset[81];
-  int max_iter;
-  void* map; /* non-NULL when seq/sa point into an mmap of the file */
-  size_t map_len;
-  int owns;  /* seq/sa malloc'd by us */
-};
 
 /* ------------------------------------------------------------------------------------------------ */
 static uint64_t rd_u64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -322,7 +302,8 @@ int k4o_write(const k4o_index* ix, const char* path) {
 }
 
 /* ---- MapChunkHit2Entry, SfxArray.cpp:2609-2654 ---------------------------------------------------- */
-static const k4o_entry* map_chunk_hit2entry(const k4o_index* ix, uint64_t ofs) {
+#define map_chunk_hit2entry k4oi_map_chunk_hit2entry
+const k4o_entry* k4oi_map_chunk_hit2entry(const k4o_index* ix, uint64_t ofs) {
   int64_t lo = 0, hi = (int64_t)ix->n_entries - 1;
   while (hi >= lo) {
     int64_t mid = (hi + lo) / 2;
@@ -351,7 +332,8 @@ void k4o_revcomp(uint8_t* s, int len) {
 }
 
 /* probe vs suffix over len bases: target EOS => probe < target.  CmpProbeTarg, SfxArray.cpp:2508-2525 */
-static int cmp_probe_targ(const uint8_t* probe, const uint8_t* targ, int len) {
+#define cmp_probe_targ k4oi_cmp_probe_targ
+int k4oi_cmp_probe_targ(const uint8_t* probe, const uint8_t* targ, int len) {
   for (int i = 0; i < len; i++) {
     uint8_t t = targ[i] & 0x0f;
     if (t == K4O_EOS) return -1;
@@ -398,19 +380,23 @@ int64_t k4o_locate_first_exact(const k4o_index* ix, const uint8_t* probe, int pr
 }
 
 /* ---- dedupe set for TargSeqIDs: per strand pass, SfxArray.cpp:5845,5946,6037-6055 ---------------- */
-typedef struct { uint64_t* slot; uint32_t cap; uint32_t* used; uint32_t n_used; } idset; /* slot = id+1, 0 = empty */
-static void idset_init(idset* s) {
+typedef k4oi_idset idset;
+void k4oi_idset_init(k4oi_idset* s) {
   s->cap = 1u << 12;
   s->slot = (uint64_t*)calloc(s->cap, sizeof(uint64_t));
   s->used = (uint32_t*)malloc(sizeof(uint32_t) * s->cap);
   s->n_used = 0;
 }
-static void idset_clear(idset* s) {
+void k4oi_idset_clear(k4oi_idset* s) {
   for (uint32_t i = 0; i < s->n_used; i++) s->slot[s->used[i]] = 0;
   s->n_used = 0;
 }
-static void idset_free(idset* s) { free(s->slot); free(s->used); }
-static int idset_insert(idset* s, uint32_t id) { /* 1 if new */
+void k4oi_idset_free(k4oi_idset* s) { free(s->slot); free(s->used); }
+#define idset_init k4oi_idset_init
+#define idset_clear k4oi_idset_clear
+#define idset_free k4oi_idset_free
+#define idset_insert k4oi_idset_insert
+int k4oi_idset_insert(k4oi_idset* s, uint32_t id) { /* 1 if new */
   if (s->n_used * 2 >= s->cap) { /* grow */
     uint32_t ncap = s->cap * 2;
     uint64_t* nslot = (uint64_t*)calloc(ncap, sizeof(uint64_t));

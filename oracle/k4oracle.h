@@ -42,8 +42,33 @@ typedef struct {
   uint16_t match_len;  /* Seg[0].MatchLen = ProbeLen */
   uint8_t strand;      /* '+' or '-' */
   uint8_t mismatches;  /* Seg[0].Mismatches */
-  uint32_t reserved;   /* 0 */
+  uint32_t ext;        /* 0 for the default path; the optional phases: bits 0-11 Seg[0].TrimLeft, 12-23 Seg[0].TrimRight,
+                        * 24 FlgChimeric, 25 FlgInDel, 26 FlgInsert, 27 FlgSplice, 28 FlgNonOrphan (same as k4_hit.ext) */
 } k4o_hit;
+#define K4O_EXT_CHIMERIC (1u << 24)
+#define K4O_EXT_INDEL (1u << 25)
+#define K4O_EXT_INSERT (1u << 26)
+#define K4O_EXT_SPLICE (1u << 27)
+#define K4O_EXT_NONORPHAN (1u << 28)
+
+/* Seg[1] of a two-segment hit (microInDel / splice junction: those phases report at most one hit per read) and the
+ * tsHitLoci.Score; 16 bytes, same layout as k4_seg2 in include/k4sfx.h.  All zero for a one-segment result. */
+typedef struct {
+  uint32_t chrom_id;   /* Seg[1].ChromID */
+  uint32_t match_loci; /* Seg[1].MatchLoci */
+  uint16_t match_len;  /* Seg[1].MatchLen */
+  uint16_t read_ofs;   /* Seg[1].ReadOfs */
+  uint8_t mismatches;  /* Seg[1].Mismatches */
+  uint8_t reserved;
+  uint16_t score;      /* tsHitLoci.Score */
+} k4o_seg2;
+
+/* the three arguments of CSfxArray::AlignReads that switch its optional phases on (SfxArray.cpp:7894-7930) */
+typedef struct {
+  int min_chimeric_len;     /* MinChimericLen: 0, or 15..99 (% of the read that must remain after flank trimming) */
+  int micro_indel_len;      /* microInDelLen: 0..20 */
+  int max_splice_junct_len; /* MaxSpliceJunctLen: 0, or 25..100000 */
+} k4o_ext_params;
 
 typedef struct {
   uint32_t entry_id;   /* tsSfxEntry.EntryID (1..n) */
@@ -96,6 +121,28 @@ int k4o_align_reads(const k4o_index* ix, int tot_mm, int core_len, int core_delt
                     int mm_delta, int strand, int* inst, int* low, int* nxt, uint8_t* probe, int probe_len,
                     int max_hits, k4o_hit* hits, k4o_counters* ctr);          /* SfxArray.cpp:7838-7933 */
 
+/* ---- the optional phases of AlignReads: oracle/k4oracle_ext.c ------------------------------- */
+int k4o_adaptive_trim(uint32_t seq_len, const uint8_t* probe, const uint8_t* targ, uint32_t min_trim_len, uint32_t max_mm,
+                      uint32_t min_flank_matches, uint32_t* trim_seq_len, uint32_t* trim_start, uint32_t* trim_end,
+                      uint32_t* trim_mms);                                     /* SfxArray.cpp:5561-5795 */
+int k4o_locate_core_multiples_chimeric(const k4o_index* ix, int min_chimeric_len, int max_tot_mm, int core_len, int core_delta,
+                                       int max_slides, int mm_delta, int strand, int* inst, int* low, int* nxt,
+                                       uint8_t* probe, int probe_len, int max_hits, k4o_hit* hits,
+                                       k4o_counters* ctr);                     /* SfxArray.cpp:5806-6369 incl. :6064-6189 */
+int k4o_locate_indels(const k4o_index* ix, int micro_indel_len, int max_tot_mm, int core_len, int strand, int* inst, int* low,
+                      int* nxt, uint8_t* probe, int probe_len, int max_hits, k4o_hit* hit, k4o_seg2* seg2, int* score,
+                      k4o_counters* ctr);                                      /* SfxArray.cpp:7526-7832, 9277-9735 */
+int k4o_locate_splice_juncts(const k4o_index* ix, int max_splice_junct_len, int max_tot_mm, int core_len, int strand, int* inst,
+                             int* low, int* nxt, uint8_t* probe, int probe_len, int max_hits, k4o_hit* hit, k4o_seg2* seg2,
+                             int* score, k4o_counters* ctr);                   /* SfxArray.cpp:7208-7523, 8771-9265 */
+/* AlignReads with all of its arguments (SfxArray.cpp:7838-7933); seg2: one record (slot 0's second segment) */
+int k4o_align_reads_ext(const k4o_index* ix, const k4o_ext_params* ext, int tot_mm, int core_len, int core_delta, int max_slides,
+                        int min_core_len, int mm_delta, int strand, int* inst, int* low, int* nxt, uint8_t* probe,
+                        int probe_len, int max_hits, k4o_hit* hits, k4o_seg2* seg2, k4o_counters* ctr);
+int k4o_align_reads_ext_batch(const k4o_index* ix, const k4o_ext_params* ext, int tot_mm, int core_len, int core_delta,
+                              int max_slides, int min_core_len, int mm_delta, int strand, int max_hits, int64_t n_reads,
+                              const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int32_t* rslt, int32_t* inst,
+                              int32_t* low, int32_t* nxt, k4o_hit* hits, k4o_seg2* seg2, int nthreads, k4o_counters* ctr);
 /* ---- CKAligner::AlignRead level ------------------------------------------------------------------- */
 typedef struct {
   int max_subs;      /* -s: allowed substitutions per 100 bp (KAlignerCL.cpp:796) */
@@ -107,6 +154,9 @@ typedef struct {
   int pe_mode;       /* 0 SE classification, 1 PE classification (KAligner.cpp:9982-10023) */
   int min_core_len;  /* 0 = derive from the index (KAligner.cpp:9367-9393) */
   int max_num_slides;/* 0 = derive from pmode */
+  int min_chimeric_len;     /* -c (pPars->MinChimericLen) */
+  int micro_indel_len;      /* -a (pPars->microInDelLen) */
+  int max_splice_junct_len; /* -A (pPars->SpliceJunctLen) */
 } k4o_kalign_params;
 
 typedef struct {
@@ -127,6 +177,23 @@ int k4o_align_read(const k4o_index* ix, const k4o_kalign_params* kp, const uint8
 int k4o_align_batch(const k4o_index* ix, const k4o_kalign_params* kp, int64_t n_reads, const uint8_t* reads,
                     const uint64_t* offs, const uint32_t* lens, k4o_read_result* out, k4o_hit* hits,
                     int nthreads, k4o_counters* ctr);                          /* KAligner.cpp:10110-10263 */
+
+/* CKAligner::AlignRead over a batch with kp->min_chimeric_len / micro_indel_len / max_splice_junct_len honoured; seg2: one
+ * record per read */
+int k4o_align_ext_batch(const k4o_index* ix, const k4o_kalign_params* kp, int64_t n_reads, const uint8_t* reads,
+                        const uint64_t* offs, const uint32_t* lens, k4o_read_result* out, k4o_hit* hits, k4o_seg2* seg2,
+                        int nthreads, k4o_counters* ctr);
+/* the post-alignment stages those options bring with them (SE): eNAR values KAligner.h:136-158 */
+enum { K4O_NAR_TRIM = 6, K4O_NAR_SPLICEJCTN = 7, K4O_NAR_MICROINDEL = 8 };
+/* CKAligner::AutoTrimFlanks (KAligner.cpp:1714-1917; `-x`, implied by `-A` without `-c`): returns the number of reads
+ * eliminated; reads / offs / lens as for the batch calls, hits: max_ml per read (slot 0 is the reported one) */
+int64_t k4o_auto_trim_flanks(const k4o_index* ix, int min_flank_exacts, int pe, int64_t n_reads, const uint8_t* reads,
+                             const uint64_t* offs, const uint32_t* lens, int max_ml, k4o_read_result* rr, k4o_hit* hits,
+                             const k4o_seg2* seg2);
+/* CKAligner::RemoveOrphanSpliceJuncts / RemoveOrphanMicroInDels (KAligner.cpp:2406-2594): which = K4O_EXT_SPLICE or
+ * K4O_EXT_INDEL; returns the number of orphans removed */
+int64_t k4o_remove_orphan_juncts(uint32_t which, int64_t n_reads, int max_ml, k4o_read_result* rr, k4o_hit* hits,
+                                 const k4o_seg2* seg2);
 
 /* raw AlignReads over a batch with uniform explicit parameters (the CSfxArray boundary) */
 int k4o_align_reads_batch(const k4o_index* ix, int tot_mm, int core_len, int core_delta, int max_slides,

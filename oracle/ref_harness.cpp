@@ -126,4 +126,63 @@ int k4ref_align_paired_read(void* vh, int b3prime_extend, int antisense, uint32_
   return rslt;
 }
 
+// ---- the optional phases of AlignReads --------------------------------------------------------------------
+struct k4ref_xhit {           // flat copy of one tsHitLoci (libkit4b/SfxArray.h:239-260), both segments
+  uint32_t chrom_id;          // Seg[0]
+  uint64_t match_loci;
+  uint16_t match_len;
+  uint8_t strand;
+  uint8_t mismatches;
+  uint16_t trim_left;
+  uint16_t trim_right;
+  uint8_t flags;              // bit 0 FlgChimeric, 1 FlgInDel, 2 FlgInsert, 3 FlgSplice, 4 FlgNonOrphan
+  uint8_t seg1_mismatches;    // Seg[1]
+  uint16_t score;
+  uint32_t seg1_chrom_id;
+  uint64_t seg1_match_loci;
+  uint16_t seg1_match_len;
+  uint16_t seg1_read_ofs;
+};
+
+// CSfxArray::AlignReads with every argument (SfxArray.cpp:7838): MinChimericLen, microInDelLen and MaxSpliceJunctLen included.
+int k4ref_align_reads_ext(void* vh, int min_chimeric_len, int micro_indel_len, int max_splice_junct_len, int tot_mm,
+                          int core_len, int core_delta, int max_slides, int min_core_len, int mm_delta, int strand,
+                          uint8_t* probe, int probe_len, int max_hits, int* inst, int* low, int* nxt, k4ref_xhit* out_hits) {
+  k4ref_handle* h = (k4ref_handle*)vh;
+  tsHitLoci* hits = new tsHitLoci[max_hits + 2];
+  memset(hits, 0, sizeof(tsHitLoci) * (max_hits + 2));
+  int rslt = h->sfx->AlignReads(0, 1, min_chimeric_len, tot_mm, core_len, core_delta, max_slides, min_core_len, mm_delta,
+                                (eALStrand)strand, micro_indel_len, max_splice_junct_len, inst, low, nxt, (etSeqBase*)probe,
+                                probe_len, max_hits, hits, cMaxNumIdentNodes, h->nodes);
+  for (int i = 0; i < max_hits; i++) {
+    k4ref_xhit& o = out_hits[i];
+    memset(&o, 0, sizeof(o));
+    o.chrom_id = hits[i].Seg[0].ChromID;
+    o.match_loci = hits[i].Seg[0].MatchLoci;
+    o.match_len = hits[i].Seg[0].MatchLen;
+    o.strand = hits[i].Seg[0].Strand;
+    o.mismatches = hits[i].Seg[0].Mismatches;
+    o.trim_left = hits[i].Seg[0].TrimLeft;
+    o.trim_right = hits[i].Seg[0].TrimRight;
+    o.flags = (uint8_t)(hits[i].FlgChimeric | (hits[i].FlgInDel << 1) | (hits[i].FlgInsert << 2) | (hits[i].FlgSplice << 3) |
+                        (hits[i].FlgNonOrphan << 4));
+    o.score = hits[i].Score;
+    o.seg1_chrom_id = hits[i].Seg[1].ChromID;
+    o.seg1_match_loci = hits[i].Seg[1].MatchLoci;
+    o.seg1_match_len = hits[i].Seg[1].MatchLen;
+    o.seg1_read_ofs = hits[i].Seg[1].ReadOfs;
+    o.seg1_mismatches = hits[i].Seg[1].Mismatches;
+  }
+  delete[] hits;
+  return rslt;
+}
+
+// CSfxArray::AdaptiveTrim (SfxArray.cpp:5561) on caller-supplied sequences; out = {TrimSeqLen, TrimStart, TrimEnd, TrimMMs}
+int k4ref_adaptive_trim(void* vh, uint32_t seq_len, uint8_t* probe, uint8_t* targ, uint32_t min_trim_len, uint32_t max_mm,
+                        uint32_t min_flank, uint32_t* out4) {
+  k4ref_handle* h = (k4ref_handle*)vh;
+  return h->sfx->AdaptiveTrim(seq_len, (etSeqBase*)probe, (etSeqBase*)targ, 1, seq_len, min_trim_len, max_mm, min_flank, &out4[0],
+                              &out4[1], &out4[2], &out4[3]);
+}
+
 }  // extern "C"

@@ -28,13 +28,33 @@ HIT_DTYPE = np.dtype(
 RESULT_DTYPE = np.dtype(
     [("hit_rslt", "<i4"), ("inst", "<i4"), ("low_mm", "<i4"), ("nxt_mm", "<i4"), ("nar", "<i4"), ("num_hits", "<i4")]
 )
+# the hit record's fourth word ("reserved" in the dtype, k4_hit.ext / k4o_hit.ext in C): trims and tsHitLoci flags of the
+# optional AlignReads phases; 0 on the default path
+EXT_CHIMERIC, EXT_INDEL, EXT_INSERT, EXT_SPLICE, EXT_NONORPHAN = 1 << 24, 1 << 25, 1 << 26, 1 << 27, 1 << 28
+NAR_TRIM, NAR_SPLICEJCTN, NAR_MICROINDEL = 6, 7, 8
+# Seg[1] of a two-segment hit + Score (k4_seg2 / k4o_seg2), one per read
+SEG2_DTYPE = np.dtype(
+    [("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"), ("read_ofs", "<u2"), ("mismatches", "u1"),
+     ("reserved", "u1"), ("score", "<u2")]
+)
+
+
+class ExtParams(C.Structure):
+    _fields_ = [("min_chimeric_len", C.c_int), ("micro_indel_len", C.c_int), ("max_splice_junct_len", C.c_int)]
+
+
+def ext_trims(hits):
+    """(TrimLeft, TrimRight) of hit records"""
+    e = hits["reserved"]
+    return e & 0xFFF, (e >> 12) & 0xFFF
 
 
 class KalignParams(C.Structure):
     _fields_ = [
         ("max_subs", C.c_int), ("min_edit_dist", C.c_int), ("max_ns", C.c_int), ("pmode", C.c_int),
         ("strand", C.c_int), ("max_ml", C.c_int), ("pe_mode", C.c_int), ("min_core_len", C.c_int),
-        ("max_num_slides", C.c_int),
+        ("max_num_slides", C.c_int), ("min_chimeric_len", C.c_int), ("micro_indel_len", C.c_int),
+        ("max_splice_junct_len", C.c_int),
     ]
 
 
@@ -220,6 +240,70 @@ class Oracle:
                     counters=dict(n_lookup=ctr.n_lookup, n_probe=ctr.n_probe, n_cand=ctr.n_cand))
 
 
+    # -- the optional phases of AlignReads (oracle/k4oracle_ext.c) ---------------------------------------------------
+    def align_reads_ext_batch(self, h, reads, tot_mm, core_len, core_delta, max_slides, min_core_len=0, mm_delta=1,
+                              strand=STRAND_BOTH, max_hits=1, min_chimeric_len=0, micro_indel_len=0,
+                              max_splice_junct_len=0, threads=4):
+        """CSfxArray::AlignReads with MinChimericLen / microInDelLen / MaxSpliceJunctLen over a batch"""
+        cat, offs, lens = reads if isinstance(reads, tuple) else flatten_reads(reads)
+        n = len(lens)
+        rslt = np.zeros(n, np.int32); inst = np.zeros(n, np.int32); low = np.zeros(n, np.int32)
+        nxt = np.zeros(n, np.int32)
+        hits = np.zeros((n, max_hits), dtype=HIT_DTYPE)
+        seg2 = np.zeros(n, dtype=SEG2_DTYPE)
+        ext = ExtParams(min_chimeric_len, micro_indel_len, max_splice_junct_len)
+        vp = C.c_void_p
+        self.L.k4o_align_reads_ext_batch(vp(h), C.byref(ext), tot_mm, core_len, core_delta, max_slides, min_core_len, mm_delta,
+                                         strand, max_hits, C.c_int64(n), vp(cat.ctypes.data), vp(offs.ctypes.data),
+                                         vp(lens.ctypes.data), vp(rslt.ctypes.data), vp(inst.ctypes.data), vp(low.ctypes.data),
+                                         vp(nxt.ctypes.data), vp(hits.ctypes.data), vp(seg2.ctypes.data), threads, None)
+        return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits, seg2=seg2)
+
+    def kalign_ext_batch(self, h, reads, max_subs=5, min_edit_dist=1, max_ns=1, pmode=0, strand=STRAND_BOTH, max_ml=1,
+                         pe_mode=0, min_core_len=0, max_num_slides=0, min_chimeric_len=0, micro_indel_len=0,
+                         max_splice_junct_len=0, threads=4):
+        """CKAligner::AlignRead over a batch with `-c` / `-a` / `-A`"""
+        cat, offs, lens = reads if isinstance(reads, tuple) else flatten_reads(reads)
+        n = len(lens)
+        kp = KalignParams(max_subs, min_edit_dist, max_ns, pmode, strand, max_ml, pe_mode, min_core_len, max_num_slides,
+                          min_chimeric_len, micro_indel_len, max_splice_junct_len)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        hits = np.zeros((n, max(1, max_ml)), dtype=HIT_DTYPE)
+        seg2 = np.zeros(n, dtype=SEG2_DTYPE)
+        vp = C.c_void_p
+        self.L.k4o_align_ext_batch(vp(h), C.byref(kp), C.c_int64(n), vp(cat.ctypes.data), vp(offs.ctypes.data),
+                                   vp(lens.ctypes.data), vp(out.ctypes.data), vp(hits.ctypes.data), vp(seg2.ctypes.data),
+                                   threads, None)
+        return dict(out=out, hits=hits, seg2=seg2)
+
+    def adaptive_trim(self, probe, targ, min_trim_len, max_mm, min_flank=3):
+        """CSfxArray::AdaptiveTrim -> (return value, TrimSeqLen, TrimStart, TrimEnd, TrimMMs)"""
+        probe = np.ascontiguousarray(probe, dtype=np.uint8)
+        targ = np.ascontiguousarray(targ, dtype=np.uint8)
+        o = (C.c_uint32 * 4)()
+        vp = C.c_void_p
+        r = self.L.k4o_adaptive_trim(C.c_uint32(len(probe)), vp(probe.ctypes.data), vp(targ.ctypes.data),
+                                     C.c_uint32(min_trim_len), C.c_uint32(max_mm), C.c_uint32(min_flank),
+                                     C.byref(o, 0), C.byref(o, 4), C.byref(o, 8), C.byref(o, 12))
+        return (r, o[0], o[1], o[2], o[3])
+
+    def auto_trim_flanks(self, h, reads, out, hits, seg2, min_flank_exacts, pe=False):
+        """CKAligner::AutoTrimFlanks, in place; returns the number of reads eliminated"""
+        cat, offs, lens = reads if isinstance(reads, tuple) else flatten_reads(reads)
+        vp = C.c_void_p
+        self.L.k4o_auto_trim_flanks.restype = C.c_int64
+        return self.L.k4o_auto_trim_flanks(vp(h), C.c_int(min_flank_exacts), C.c_int(1 if pe else 0), C.c_int64(len(lens)),
+                                           vp(cat.ctypes.data), vp(offs.ctypes.data), vp(lens.ctypes.data),
+                                           C.c_int(hits.shape[1]), vp(out.ctypes.data), vp(hits.ctypes.data),
+                                           vp(seg2.ctypes.data))
+
+    def remove_orphan_juncts(self, which, out, hits, seg2):
+        """CKAligner::RemoveOrphanSpliceJuncts (which=EXT_SPLICE) / RemoveOrphanMicroInDels (EXT_INDEL), in place"""
+        vp = C.c_void_p
+        self.L.k4o_remove_orphan_juncts.restype = C.c_int64
+        return self.L.k4o_remove_orphan_juncts(C.c_uint32(which), C.c_int64(len(out)), C.c_int(hits.shape[1]),
+                                               vp(out.ctypes.data), vp(hits.ctypes.data), vp(seg2.ctypes.data))
+
     def assign_multi_matches(self, out, hits, ml_mode, max_reads_len, threads=4):
         """CKAligner::AssignMultiMatches (`-r3` / `-r4`) over kalign_batch(pe_mode=1) results, in place."""
         n, max_ml = hits.shape
@@ -248,6 +332,13 @@ def oracle_kalign_pe(O, h, reads1, reads2, pe_mode=2, pair_min_len=100, pair_max
     """CKAligner PE flow (ProcCoredApprox + ProcessPairedEnds) on the CPU oracle; out[2i] = PE1, out[2i+1] = PE2."""
     return _kalign_pe(O.L, O.L.k4o_kalign_pe_batch, h, reads1, reads2, pe_mode, pair_min_len, pair_max_len, pair_strand,
                       threads, **kw)
+
+
+class _RefXHit(C.Structure):
+    _fields_ = [("chrom_id", C.c_uint32), ("match_loci", C.c_uint64), ("match_len", C.c_uint16), ("strand", C.c_uint8),
+                ("mismatches", C.c_uint8), ("trim_left", C.c_uint16), ("trim_right", C.c_uint16), ("flags", C.c_uint8),
+                ("seg1_mismatches", C.c_uint8), ("score", C.c_uint16), ("seg1_chrom_id", C.c_uint32),
+                ("seg1_match_loci", C.c_uint64), ("seg1_match_len", C.c_uint16), ("seg1_read_ofs", C.c_uint16)]
 
 
 class _RefHit(C.Structure):
@@ -313,3 +404,49 @@ class Ref:
                 hits[i, k] = (rh[k].chrom_id, rh[k].match_loci & 0xFFFFFFFF, rh[k].match_len, rh[k].strand,
                               rh[k].mismatches, 0)
         return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits)
+
+    def align_reads_ext_batch(self, h, reads, tot_mm, core_len, core_delta, max_slides, min_core_len=0, mm_delta=1,
+                              strand=STRAND_BOTH, max_hits=1, min_chimeric_len=0, micro_indel_len=0,
+                              max_splice_junct_len=0):
+        """the real CSfxArray::AlignReads with every argument; same record layout as Oracle.align_reads_ext_batch
+        (slots the caller of AlignReads would not look at are zeroed)"""
+        if isinstance(reads, tuple):
+            cat, offs, lens = reads
+            reads = [cat[int(o):int(o) + int(l)] for o, l in zip(offs, lens)]
+        n = len(reads)
+        rslt = np.zeros(n, np.int32); inst = np.zeros(n, np.int32); low = np.zeros(n, np.int32)
+        nxt = np.zeros(n, np.int32)
+        hits = np.zeros((n, max_hits), dtype=HIT_DTYPE)
+        seg2 = np.zeros(n, dtype=SEG2_DTYPE)
+        rh = (_RefXHit * max_hits)()
+        fn = self.L.k4ref_align_reads_ext
+        fn.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                       C.POINTER(C.c_int), C.POINTER(_RefXHit)]
+        for i, rd in enumerate(reads):
+            buf = np.ascontiguousarray(rd, dtype=np.uint8).copy()
+            a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+            rslt[i] = fn(h, min_chimeric_len, micro_indel_len, max_splice_junct_len, tot_mm, core_len, core_delta, max_slides,
+                         min_core_len, mm_delta, strand, buf.ctypes.data, len(buf), max_hits, C.byref(a), C.byref(b), C.byref(c), rh)
+            assert np.array_equal(buf, np.asarray(rd, dtype=np.uint8)), "reference did not restore the probe"
+            inst[i], low[i], nxt[i] = a.value, b.value, c.value
+            if rslt[i] not in (HR_HITS, HR_MMDELTA, HR_HITINSTS):
+                continue
+            for k in range(min(int(inst[i]), max_hits)):
+                x = rh[k]
+                fl = x.flags
+                ext = (x.trim_left & 0xFFF) | ((x.trim_right & 0xFFF) << 12) | ((fl & 1) << 24) | (((fl >> 1) & 1) << 25) | \
+                    (((fl >> 2) & 1) << 26) | (((fl >> 3) & 1) << 27) | (((fl >> 4) & 1) << 28)
+                hits[i, k] = (x.chrom_id, x.match_loci & 0xFFFFFFFF, x.match_len, x.strand, x.mismatches, ext)
+                if k == 0 and (fl & 0x0A):
+                    seg2[i] = (x.seg1_chrom_id, x.seg1_match_loci & 0xFFFFFFFF, x.seg1_match_len, x.seg1_read_ofs,
+                               x.seg1_mismatches, 0, x.score)
+        return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits, seg2=seg2)
+
+    def adaptive_trim(self, h, probe, targ, min_trim_len, max_mm, min_flank=3):
+        probe = np.ascontiguousarray(probe, dtype=np.uint8).copy()
+        targ = np.ascontiguousarray(targ, dtype=np.uint8).copy()
+        o = (C.c_uint32 * 4)()
+        fn = self.L.k4ref_adaptive_trim
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        r = fn(h, len(probe), probe.ctypes.data, targ.ctypes.data, min_trim_len, max_mm, min_flank, o)
+        return (r, o[0], o[1], o[2], o[3])

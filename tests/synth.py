@@ -168,3 +168,80 @@ def write_fasta(path, reads, prefix="rd", names=None):
         for i, r in enumerate(reads):
             hdr = names[i] if names else "%s%06d synthetic" % (prefix, i + 1)
             f.write(">%s\n%s\n" % (hdr, "".join(BASES[b] for b in r)))
+
+
+# ---- reads for the optional AlignReads phases ----------------------------------------------------------------
+def plant_splice_sites(chroms, n_sites, seed=77, min_gap=30, max_gap=3000, flank=120):
+    """Chooses n_sites introns (chrom, donor position, gap) and writes the canonical GT..AG (or, every third, CT..AC)
+    dinucleotides at their ends INTO the genome; call before the index is built.  Returns the site list."""
+    rng = np.random.default_rng(seed)
+    sites = []
+    for k in range(n_sites):
+        c = int(rng.integers(0, len(chroms)))
+        gap = int(rng.integers(min_gap, max_gap))
+        if len(chroms[c]) < 2 * flank + gap + 10:
+            continue
+        d = int(rng.integers(flank, len(chroms[c]) - flank - gap))
+        if k % 4 != 3:  # every fourth stays non-canonical
+            don, acc = ((2, 3), (0, 2)) if k % 3 else ((1, 3), (0, 1))
+            chroms[c][d:d + 2] = don
+            chroms[c][d + gap - 2:d + gap] = acc
+        sites.append((c, d, gap))
+    return sites
+
+
+def _mutate(r, rng, nsubs):
+    if nsubs:
+        pos = rng.choice(len(r), size=nsubs, replace=False)
+        r[pos] = (r[pos] + rng.integers(1, 4, size=nsubs)) % 4
+    return r
+
+
+def make_ext_reads(chroms, n_reads, read_len, kind, seed=91, sites=None, max_subs=2):
+    """kind 'chimeric': genome slice whose 5' and/or 3' flank (5..45 % of the read) is foreign sequence;
+    'indel': slice with 1..20 bases deleted or 1..20 random bases inserted at an interior position;
+    'splice': slice that jumps over one of `sites` (plant_splice_sites);  each with 0..max_subs substitutions and a random
+    strand.  Returns the list of reads."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    while len(reads) < n_reads:
+        c = int(rng.integers(0, len(chroms)))
+        g = chroms[c]
+        if kind == "splice":
+            c, d, gap = sites[int(rng.integers(0, len(sites)))]
+            g = chroms[c]
+            left = int(rng.integers(12, read_len - 12))
+            a = d - left
+            if a < 0 or d + gap + (read_len - left) > len(g):
+                continue
+            r = np.concatenate([g[a:d], g[d + gap:d + gap + read_len - left]]).copy()
+        elif kind == "indel":
+            span = read_len + 25
+            if len(g) <= span + 2:
+                continue
+            a = int(rng.integers(0, len(g) - span))
+            cut = int(rng.integers(10, read_len - 10))
+            gl = int(rng.integers(1, 21))
+            if rng.random() < 0.5:  # deletion from the read
+                r = np.concatenate([g[a:a + cut], g[a + cut + gl:a + gl + read_len]]).copy()
+            else:                   # insertion into the read
+                r = np.concatenate([g[a:a + cut], rng.integers(0, 4, gl).astype(np.uint8), g[a + cut:a + read_len - gl]]).copy()
+        else:
+            if len(g) <= read_len + 2:
+                continue
+            a = int(rng.integers(0, len(g) - read_len))
+            r = g[a:a + read_len].copy()
+            which = int(rng.integers(0, 3))
+            if which in (0, 2):
+                f = int(rng.integers(max(2, read_len // 20), read_len * 45 // 100))
+                r[:f] = rng.integers(0, 4, f)
+            if which in (1, 2):
+                f = int(rng.integers(max(2, read_len // 20), read_len * 45 // 100))
+                r[-f:] = rng.integers(0, 4, f)
+        if len(r) != read_len or (r > 3).any():
+            continue
+        r = _mutate(r, rng, int(rng.integers(0, max_subs + 1)))
+        if rng.random() < 0.5:
+            r = revcomp(r)
+        reads.append(r.astype(np.uint8))
+    return reads
