@@ -43,3 +43,23 @@ def g1_el5_path(golden_dir, tmp_path_factory):
     with lzma.open(os.path.join(golden_dir, "g1_el5.sfx.xz"), "rb") as f, open(p, "wb") as g:
         g.write(f.read())
     return str(p)
+
+
+def _unxz(golden_dir, tmp_path_factory, name):
+    import lzma
+
+    p = tmp_path_factory.mktemp("golden") / name
+    with lzma.open(os.path.join(golden_dir, name + ".xz"), "rb") as f, open(p, "wb") as g:
+        g.write(f.read())
+    return str(p)
+
+
+@pytest.fixture(scope="session")
+def g3_path(golden_dir, tmp_path_factory):
+    """tests/golden/g3.sfx.xz (the genome of the optional-phase vectors: planted introns) unpacked to a temp file"""
+    return _unxz(golden_dir, tmp_path_factory, "g3.sfx")
+
+
+@pytest.fixture(scope="session")
+def g3_el5_path(golden_dir, tmp_path_factory):
+    return _unxz(golden_dir, tmp_path_factory, "g3_el5.sfx")

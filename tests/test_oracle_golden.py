@@ -10,7 +10,8 @@ import synth
 from oracle_bindings import HIT_DTYPE, Oracle, Ref, ref_available
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "align_*.npz")))
+CASES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "align_*.npz"))
+               if not os.path.basename(p).startswith("align_ext_"))  # (the optional-phase vectors: test_*_ext.py)
 
 
 def check_against(res, exp, max_hits):
