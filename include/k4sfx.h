@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define K4_ABI_VERSION 1
+#define K4_ABI_VERSION 2  /* 2: optional AlignReads phases (k4_hit.ext, k4_seg2, *_ext entry points), pipeline, comm */
 
 /* teBSFrsltCodes values used by this library (libkit4b/ErrorCodes.h:15-97) */
 enum {
@@ -48,20 +48,40 @@ enum { K4_HR_NONE = 0, K4_HR_HITS = 1, K4_HR_MMDELTA = 2, K4_HR_HITINSTS = 3, K4
 enum { K4_STRAND_BOTH = 0, K4_STRAND_WATSON = 1, K4_STRAND_CRICK = 2 };
 /* eNAR values AlignRead can assign, ngskit4b/KAligner.h:136-158 */
 enum { K4_NAR_UNALIGNED = 0, K4_NAR_ACCEPTED = 1, K4_NAR_NS = 2, K4_NAR_NOHIT = 3, K4_NAR_MMDELTA = 4,
-       K4_NAR_MULTIALIGN = 5 };
+       K4_NAR_MULTIALIGN = 5, K4_NAR_TRIM = 6, K4_NAR_SPLICEJCTN = 7, K4_NAR_MICROINDEL = 8 };
 
 typedef struct k4_index k4_index; /* opaque: the HBM-resident index (replaces a loaded CSfxArray) */
 
-/* What the default alignment path stores in tsHitLoci.Seg[0] (libkit4b/SfxArray.h:239-260, filled at
- * SfxArray.cpp:6264-6307).  16 bytes. */
+/* One tsHitLoci (libkit4b/SfxArray.h:239-260): Seg[0] as the default path fills it at SfxArray.cpp:6264-6307, plus -- in
+ * `ext` -- what the optional phases of AlignReads add: Seg[0].TrimLeft / TrimRight and the Flg* bits.  16 bytes; `ext` is 0
+ * on the default path.  The second segment of a microInDel / splice-junction hit lives in a k4_seg2 record. */
 typedef struct {
   uint32_t chrom_id;   /* Seg[0].ChromID: 1-based tsSfxEntry.EntryID */
   uint32_t match_loci; /* Seg[0].MatchLoci: 0-based in the chromosome (the reference truncates to uint32) */
-  uint16_t match_len;  /* Seg[0].MatchLen == probe length */
+  uint16_t match_len;  /* Seg[0].MatchLen: the probe length; the first segment's length in a two-segment hit */
   uint8_t strand;      /* Seg[0].Strand: '+' or '-' */
   uint8_t mismatches;  /* Seg[0].Mismatches == Seg[0].TrimMismatches */
-  uint32_t reserved;   /* 0 */
+  uint32_t ext;        /* bits 0-11 Seg[0].TrimLeft, 12-23 Seg[0].TrimRight, then K4_EXT_* */
 } k4_hit;
+#define K4_EXT_CHIMERIC (1u << 24)  /* FlgChimeric: flank-trimmed alignment (`-c`, SfxArray.cpp:6064-6189) */
+#define K4_EXT_INDEL (1u << 25)     /* FlgInDel: two segments around a microInDel (`-a`, :7526) */
+#define K4_EXT_INSERT (1u << 26)    /* FlgInsert: the InDel is an insertion into the read */
+#define K4_EXT_SPLICE (1u << 27)    /* FlgSplice: two segments around a splice junction (`-A`, :7208) */
+#define K4_EXT_NONORPHAN (1u << 28) /* FlgNonOrphan: another read shares the junction (KAligner.cpp:2456-2465) */
+#define K4_HIT_TRIM_LEFT(h) ((h).ext & 0xFFFu)
+#define K4_HIT_TRIM_RIGHT(h) (((h).ext >> 12) & 0xFFFu)
+
+/* Seg[1] of a two-segment hit and tsHitLoci.Score; one record per READ (LocateInDels / LocateSpliceJuncts report at most
+ * one hit).  All zero unless hit slot 0 carries K4_EXT_INDEL or K4_EXT_SPLICE.  16 bytes. */
+typedef struct {
+  uint32_t chrom_id;   /* Seg[1].ChromID */
+  uint32_t match_loci; /* Seg[1].MatchLoci */
+  uint16_t match_len;  /* Seg[1].MatchLen */
+  uint16_t read_ofs;   /* Seg[1].ReadOfs */
+  uint8_t mismatches;  /* Seg[1].Mismatches */
+  uint8_t reserved;
+  uint16_t score;      /* Score */
+} k4_seg2;
 
 /* tsSfxEntry (libkit4b/SfxArray.h:98-106) without packing */
 typedef struct {
@@ -87,17 +107,20 @@ typedef struct {
   char dataset[81];      /* CSfxArray::GetDatasetName */
 } k4_info_t;
 
-/* The arguments of CSfxArray::AlignReads (libkit4b/SfxArray.h:614-634) that the default path uses.
- * MinChimericLen, microInDelLen and MaxSpliceJunctLen are fixed at 0 (those phases are out of scope). */
+/* The arguments of CSfxArray::AlignReads (libkit4b/SfxArray.h:614-634). */
 typedef struct {
   int32_t tot_mm;          /* TotMM */
   int32_t core_len;        /* CoreLen */
   int32_t core_delta;      /* CoreDelta */
   int32_t max_core_slides; /* MaxNumCoreSlides */
-  int32_t min_core_len;    /* MinCoreLen (only used by the chimeric phase in the reference; kept for parity of the call) */
+  int32_t min_core_len;    /* MinCoreLen (used by the chimeric phase only, SfxArray.cpp:7925) */
   int32_t mm_delta;        /* MMDelta */
   int32_t strand;          /* Align2Strand: K4_STRAND_* */
   int32_t max_hits;        /* MaxHits */
+  /* the optional phases a read enters when the ones above found nothing (SfxArray.cpp:7894-7930); 0 = off */
+  int32_t min_chimeric_len;     /* MinChimericLen: 15..99, % of the read that must survive flank trimming */
+  int32_t micro_indel_len;      /* microInDelLen: 1..20; needs the *_ext entry points (k4_seg2 output) */
+  int32_t max_splice_junct_len; /* MaxSpliceJunctLen: 25..100000; needs the *_ext entry points */
 } k4_align_params;
 
 /* What CKAligner::AlignRead derives per read and how it classifies (ngskit4b/KAligner.cpp:9583-10105) */
@@ -115,6 +138,9 @@ typedef struct {
                            * 4 = 3 through CSfxArray::LocateBestMatches (`-N`, SfxArray.cpp:6836-7205) instead of AlignReads */
   int32_t min_core_len;   /* 0: derive as LocateCoredApprox does (KAligner.cpp:9367-9393) */
   int32_t max_num_slides; /* 0: derive from pmode */
+  int32_t min_chimeric_len;     /* -c (pPars->MinChimericLen, KAligner.cpp:9801): 0 or 15..99 */
+  int32_t micro_indel_len;      /* -a (pPars->microInDelLen): 0..20; SE only; needs the *_ext entry points */
+  int32_t max_splice_junct_len; /* -A (pPars->SpliceJunctLen): 0 or 25..100000; SE only; needs the *_ext entry points */
 } k4_kalign_params;
 
 typedef struct {
@@ -188,6 +214,33 @@ int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n_reads
                         const void* d_reads, const void* d_offs, const void* d_lens, void* d_out, void* d_hits,
                         void* stream);
 int k4_min_core_len(const k4_index* ix, int pmode, int* max_num_slides); /* <- LocateCoredApprox, KAligner.cpp:9367-9393 */
+/* The same two calls with the k4_seg2 output the microInDel / splice phases need: seg2 holds n_reads
+ * records.  <- CSfxArray::AlignReads incl. LocateInDels (SfxArray.cpp:7526), LocateSpliceJuncts (:7208) and the chimeric
+ * LocateCoreMultiples pass (:6064-6189, AdaptiveTrim :5561); <- CKAligner::AlignRead with -c / -a / -A. */
+int k4_align_reads_ext_batch(k4_index* ix, const k4_align_params* p, int64_t n_reads, const uint8_t* reads,
+                             const uint64_t* offs, const uint32_t* lens, int32_t* rslt, int32_t* inst, int32_t* low,
+                             int32_t* nxt, k4_hit* hits, k4_seg2* seg2);
+int k4_align_reads_ext_batch_dev(k4_index* ix, const k4_align_params* p, int64_t n_reads, int32_t max_read_len,
+                                 const void* d_reads, const void* d_offs, const void* d_lens, void* d_rslt, void* d_inst,
+                                 void* d_low, void* d_nxt, void* d_hits, void* d_seg2, void* stream);
+int k4_kalign_ext_batch(k4_index* ix, const k4_kalign_params* p, int64_t n_reads, const uint8_t* reads,
+                        const uint64_t* offs, const uint32_t* lens, k4_read_result* out, k4_hit* hits, k4_seg2* seg2);
+int k4_kalign_ext_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n_reads, int32_t max_read_len,
+                            const void* d_reads, const void* d_offs, const void* d_lens, void* d_out, void* d_hits,
+                            void* d_seg2, void* stream);
+/* The post-alignment stages `kalign -A / -a / -x` run on the SE results (device arrays as k4_kalign_ext_batch_dev left them):
+ * k4_auto_trim_flanks_dev     <- CKAligner::AutoTrimFlanks (KAligner.cpp:1714-1917): trims the flanks of one-segment hits
+ *                                back to min_flank_exacts exactly matching bases (TrimLeft / TrimRight in k4_hit.ext); a read
+ *                                that cannot keep half its length becomes K4_NAR_TRIM.  pe: the PE variant (no elimination).
+ * k4_remove_orphan_juncts_dev <- RemoveOrphanSpliceJuncts / RemoveOrphanMicroInDels (KAligner.cpp:2406-2594), which =
+ *                                K4_EXT_SPLICE or K4_EXT_INDEL: a junction no other read shares (within 3 bp at both ends)
+ *                                loses its alignment (K4_NAR_SPLICEJCTN / K4_NAR_MICROINDEL).
+ * Both wait for `stream` and return counts. */
+int k4_auto_trim_flanks_dev(k4_index* ix, int32_t min_flank_exacts, int pe, int64_t n_reads, int32_t max_ml, void* d_rr,
+                            void* d_hits, const void* d_reads, const void* d_offs, const void* d_lens, int64_t* n_eliminated,
+                            void* stream);
+int k4_remove_orphan_juncts_dev(k4_index* ix, uint32_t which, int64_t n_reads, int32_t max_ml, void* d_rr, void* d_hits,
+                                const void* d_seg2, int64_t* n_removed, void* stream);
 /* k4_best_matches_batch <- CSfxArray::LocateBestMatches (SfxArray.h:793, SfxArray.cpp:6836-7205; CKAligner's `-N`) for
  * n_reads reads: at most p->max_hits alignments with no more than p->tot_mm mismatches, sorted by mismatches; rslt = the
  * call's return value (0 none, 1..max_hits, max_hits+1 when further matches were sloughed), inst = alignments in the
@@ -293,6 +346,12 @@ int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, c
                       const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens,
                       const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
                       uint8_t* chrom_hit /* host, n_entries + 1 bytes, or NULL */, void* stream);
+/* the same with the second segments (d_seg2: one k4_seg2 per read, or NULL): CIGAR with soft clips for trimmed hits and
+ * I / D / N between the segments, MAPQ scaled as ReportBAMread does (KAligner.cpp:6148-6233) */
+int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                          const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
+                          const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
+                          uint8_t* chrom_hit, void* stream);
 /* k4_select_hits_dev <- MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962) after k4_kalign_batch_dev with pe_mode 2: every accepted
  * read keeps ONE instance, hits[choice[i] % NumHits] moved to slot 0, NumHits = 1.  d_choice: uint32 per read, the caller's
  * draws (the reference: rand() once per read within the limit, in load order when it runs one thread). */

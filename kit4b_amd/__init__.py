@@ -25,6 +25,13 @@ HIT_DTYPE = np.dtype(
 RESULT_DTYPE = np.dtype(
     [("hit_rslt", "<i4"), ("inst", "<i4"), ("low_mm", "<i4"), ("nxt_mm", "<i4"), ("nar", "<i4"), ("num_hits", "<i4")]
 )
+# k4_hit.ext (the dtype's "reserved" word): TrimLeft | TrimRight << 12 | K4_EXT_*; k4_seg2: Seg[1] of a two-segment hit
+EXT_CHIMERIC, EXT_INDEL, EXT_INSERT, EXT_SPLICE, EXT_NONORPHAN = 1 << 24, 1 << 25, 1 << 26, 1 << 27, 1 << 28
+SEG2_DTYPE = np.dtype(
+    [("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"), ("read_ofs", "<u2"), ("mismatches", "u1"),
+     ("reserved", "u1"), ("score", "<u2")]
+)
+NAR_TRIM, NAR_SPLICEJCTN, NAR_MICROINDEL = 6, 7, 8
 
 
 class K4Error(RuntimeError):
@@ -49,13 +56,15 @@ class Info(C.Structure):
 class AlignParams(C.Structure):
     _fields_ = [("tot_mm", C.c_int32), ("core_len", C.c_int32), ("core_delta", C.c_int32),
                 ("max_core_slides", C.c_int32), ("min_core_len", C.c_int32), ("mm_delta", C.c_int32),
-                ("strand", C.c_int32), ("max_hits", C.c_int32)]
+                ("strand", C.c_int32), ("max_hits", C.c_int32), ("min_chimeric_len", C.c_int32),
+                ("micro_indel_len", C.c_int32), ("max_splice_junct_len", C.c_int32)]
 
 
 class KalignParams(C.Structure):
     _fields_ = [("max_subs", C.c_int32), ("min_edit_dist", C.c_int32), ("max_ns", C.c_int32), ("pmode", C.c_int32),
                 ("strand", C.c_int32), ("max_ml", C.c_int32), ("pe_mode", C.c_int32), ("min_core_len", C.c_int32),
-                ("max_num_slides", C.c_int32)]
+                ("max_num_slides", C.c_int32), ("min_chimeric_len", C.c_int32), ("micro_indel_len", C.c_int32),
+                ("max_splice_junct_len", C.c_int32)]
 
 
 class PeParams(C.Structure):
@@ -102,7 +111,8 @@ ABI_SYMBOLS = [
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
     "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
     "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",
-    "k4_assign_multi_dev",
+    "k4_assign_multi_dev", "k4_align_reads_ext_batch", "k4_align_reads_ext_batch_dev", "k4_kalign_ext_batch",
+    "k4_kalign_ext_batch_dev", "k4_auto_trim_flanks_dev", "k4_remove_orphan_juncts_dev", "k4_format_sam_ext_dev",
 ]
 
 
@@ -165,6 +175,14 @@ def lib():
     L.k4_select_hits_dev.argtypes = [vp, i64, C.c_int32, vp, vp, vp, vp]
     L.k4_format_sam_dev.argtypes = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, C.POINTER(SamNames), C.POINTER(vp),
                                     C.POINTER(u64), C.POINTER(SamStats), vp, vp]
+    L.k4_align_reads_ext_batch.argtypes = [vp, C.POINTER(AlignParams), i64] + [vp] * 9
+    L.k4_align_reads_ext_batch_dev.argtypes = [vp, C.POINTER(AlignParams), i64, C.c_int32] + [vp] * 10
+    L.k4_kalign_ext_batch.argtypes = [vp, C.POINTER(KalignParams), i64] + [vp] * 6
+    L.k4_kalign_ext_batch_dev.argtypes = [vp, C.POINTER(KalignParams), i64, C.c_int32] + [vp] * 7
+    L.k4_auto_trim_flanks_dev.argtypes = [vp, C.c_int32, i32, i64, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_int64), vp]
+    L.k4_remove_orphan_juncts_dev.argtypes = [vp, u32, i64, C.c_int32, vp, vp, vp, C.POINTER(C.c_int64), vp]
+    L.k4_format_sam_ext_dev.argtypes = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(SamNames), C.POINTER(vp),
+                                        C.POINTER(u64), C.POINTER(SamStats), vp, vp]
     L.k4_free_device.argtypes = [vp]
     L.k4_free_device.restype = None
     L.k4_alloc_device.argtypes = [vp, u64, C.POINTER(vp)]
@@ -333,6 +351,37 @@ class SfxIndex:
                                             nxt.ctypes.data, hits.ctypes.data))
         return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits)
 
+    def align_reads_ext_batch(self, reads, tot_mm, core_len, core_delta, max_slides, min_core_len=0, mm_delta=1,
+                              strand=STRAND_BOTH, max_hits=1, min_chimeric_len=0, micro_indel_len=0, max_splice_junct_len=0):
+        """CSfxArray::AlignReads with MinChimericLen / microInDelLen / MaxSpliceJunctLen (SfxArray.cpp:7894-7930)."""
+        cat, offs, lens = _flatten(reads)
+        n = len(lens)
+        p = AlignParams(tot_mm, core_len, core_delta, max_slides, min_core_len, mm_delta, strand, max_hits,
+                        min_chimeric_len, micro_indel_len, max_splice_junct_len)
+        rslt = np.zeros(n, np.int32); inst = np.zeros(n, np.int32); low = np.zeros(n, np.int32)
+        nxt = np.zeros(n, np.int32)
+        hits = np.zeros((n, max_hits), dtype=HIT_DTYPE)
+        seg2 = np.zeros(n, dtype=SEG2_DTYPE)
+        self._ck(lib().k4_align_reads_ext_batch(self.h, C.byref(p), n, cat.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                                                rslt.ctypes.data, inst.ctypes.data, low.ctypes.data, nxt.ctypes.data,
+                                                hits.ctypes.data, seg2.ctypes.data))
+        return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits, seg2=seg2)
+
+    def kalign_ext_batch(self, reads, max_subs=5, min_edit_dist=1, max_ns=1, pmode=0, strand=STRAND_BOTH, max_ml=1,
+                         pe_mode=0, min_core_len=0, max_num_slides=0, min_chimeric_len=0, micro_indel_len=0,
+                         max_splice_junct_len=0):
+        """CKAligner::AlignRead with -c / -a / -A."""
+        cat, offs, lens = _flatten(reads)
+        n = len(lens)
+        p = KalignParams(max_subs, min_edit_dist, max_ns, pmode, strand, max_ml, pe_mode, min_core_len, max_num_slides,
+                         min_chimeric_len, micro_indel_len, max_splice_junct_len)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        hits = np.zeros((n, max(1, max_ml)), dtype=HIT_DTYPE)
+        seg2 = np.zeros(n, dtype=SEG2_DTYPE)
+        self._ck(lib().k4_kalign_ext_batch(self.h, C.byref(p), n, cat.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                                           out.ctypes.data, hits.ctypes.data, seg2.ctypes.data))
+        return dict(out=out, hits=hits, seg2=seg2)
+
     def best_matches_batch(self, reads, tot_mm, core_len, core_delta, max_core_slides, strand=STRAND_BOTH, max_hits=5):
         """CSfxArray::LocateBestMatches over a batch: rslt (the call's return value), inst, hits[n, max_hits]."""
         cat, offs, lens = _flatten(reads)
@@ -437,7 +486,7 @@ class SfxIndex:
         return {"reads": reads, "offs": d_offs[:tot], "lens": d_lens[:tot], "n_under": under.value, "n_over": over.value,
                 "max_len": ml.value, "n_units": n, "pe": pe}
 
-    def format_sam(self, prep, p1, p2=None, rr=None, hits=None, max_ml=1, pe_recs=None):
+    def format_sam(self, prep, p1, p2=None, rr=None, hits=None, max_ml=1, pe_recs=None, seg2=None):
         """SAM body (bytes), stats dict and per-chromosome hit flags for device-resident results."""
         import torch
 
@@ -450,10 +499,11 @@ class SfxIndex:
         d_sam, nbytes, stats = C.c_void_p(), C.c_uint64(), SamStats()
         ne = self.info()["n_entries"]
         chrom_hit = np.zeros(ne + 1, dtype=np.uint8)
-        self._ck(lib().k4_format_sam_dev(self.h, 1 if prep["pe"] else 0, prep["n_units"],
+        self._ck(lib().k4_format_sam_ext_dev(self.h, 1 if prep["pe"] else 0, prep["n_units"],
                                          rr.data_ptr() if rr is not None else None,
                                          hits.data_ptr() if hits is not None else None, max_ml,
-                                         pe_recs.data_ptr() if pe_recs is not None else None, prep["reads"].data_ptr(),
+                                         pe_recs.data_ptr() if pe_recs is not None else None,
+                                         seg2.data_ptr() if seg2 is not None else None, prep["reads"].data_ptr(),
                                          prep["offs"].data_ptr(), prep["lens"].data_ptr(), C.byref(names), C.byref(d_sam),
                                          C.byref(nbytes), C.byref(stats), chrom_hit.ctypes.data,
                                          torch.cuda.current_stream().cuda_stream))
@@ -464,6 +514,31 @@ class SfxIndex:
             body = buf.tobytes()
         lib().k4_free_device(d_sam)
         return body, {"nar": list(stats.nar), "plus": stats.plus, "minus": stats.minus, "n_lines": stats.n_lines}, chrom_hit
+
+    def post_stages(self, reads, out, hits, seg2, min_flank_exacts=0, orphan_splice=False, orphan_indel=False):
+        """AutoTrimFlanks / RemoveOrphanSpliceJuncts / RemoveOrphanMicroInDels (KAligner.cpp:653-686) over host arrays of SE
+        results, in the reference's order; returns (out, hits, counts)."""
+        import torch
+
+        dev = torch.device("cuda", self.info()["device"])
+        cat, offs, lens = _flatten(reads)
+        n, max_ml = hits.shape
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+        d_rr, d_hits, d_seg2 = t(out), t(hits), t(seg2)
+        d_reads = torch.from_numpy(np.concatenate([cat, np.zeros(16, np.uint8)])).to(dev)
+        d_offs, d_lens = t(offs), t(lens)
+        cnt = {}
+        c = C.c_int64(0)
+        if min_flank_exacts > 0:
+            self._ck(lib().k4_auto_trim_flanks_dev(self.h, min_flank_exacts, 0, n, max_ml, d_rr.data_ptr(), d_hits.data_ptr(),
+                                                   d_reads.data_ptr(), d_offs.data_ptr(), d_lens.data_ptr(), C.byref(c), 0))
+            cnt["trim"] = c.value
+        for on, which, key in ((orphan_splice, EXT_SPLICE, "splice"), (orphan_indel, EXT_INDEL, "indel")):
+            if on:
+                self._ck(lib().k4_remove_orphan_juncts_dev(self.h, which, n, max_ml, d_rr.data_ptr(), d_hits.data_ptr(),
+                                                           d_seg2.data_ptr(), C.byref(c), 0))
+                cnt[key] = c.value
+        return (d_rr.cpu().numpy().view(RESULT_DTYPE), d_hits.cpu().numpy().view(HIT_DTYPE).reshape(n, max_ml), cnt)
 
     # -- the hot path (device buffers; pointers are ints, e.g. torch.Tensor.data_ptr()) -------------------------
     def kalign_pe_batch_dev(self, params, pe_params, n_pairs, max_read_len, d_reads, d_offs, d_lens, d_out, stream=0):

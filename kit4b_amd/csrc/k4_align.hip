@@ -76,6 +76,9 @@ struct K4AlignArgs {
   int32_t* nxt;
   k4_read_result* rr;
   k4_hit* hits;
+  k4_seg2* seg2;      // second segments of microInDel / splice hits, one per read (null: those phases are off)
+  int32_t ext_on;     // any optional AlignReads phase requested (SfxArray.cpp:7894-7930): reads the standard phases leave
+                      // without a result go on to the general kernel instead of being finalised
   int32_t max_hits;
   uint32_t* slow_list;
   uint8_t* slow_step;  // phase ordinal at which the read left the fast path (its earlier phases are already tallied)
@@ -92,6 +95,7 @@ struct K4AlignArgs {
 
 struct K4ReadParams {
   int tot_mm, core_len, core_delta, max_slides, mm_delta, strand, max_hits;
+  int min_core_len, min_chimeric_len, micro_indel_len, max_splice_junct_len;  // the optional phases (k4_ext.h)
 };
 
 struct K4State {
@@ -105,6 +109,8 @@ K4_DEV K4ReadParams k4d_read_params(const K4AlignArgs& a, int len) {
     p.tot_mm = a.ap.tot_mm; p.core_len = a.ap.core_len; p.core_delta = a.ap.core_delta;
     p.max_slides = a.ap.max_core_slides; p.mm_delta = a.ap.mm_delta; p.strand = a.ap.strand;
     p.max_hits = a.ap.max_hits;
+    p.min_core_len = a.ap.min_core_len; p.min_chimeric_len = a.ap.min_chimeric_len;
+    p.micro_indel_len = a.ap.micro_indel_len; p.max_splice_junct_len = a.ap.max_splice_junct_len;
     return p;
   }
   int mm = a.kp.max_subs == 0 ? 0 : (int)(0.5 + (len * a.kp.max_subs) / 100.0);
@@ -118,15 +124,17 @@ K4_DEV K4ReadParams k4d_read_params(const K4AlignArgs& a, int len) {
   if (cd < cl) cd = cl;
   p.tot_mm = mm; p.core_len = cl; p.core_delta = cd; p.max_slides = sl;
   p.mm_delta = a.kp.min_edit_dist; p.strand = a.kp.strand; p.max_hits = a.kp.max_ml < 1 ? 1 : a.kp.max_ml;
+  p.min_core_len = a.kp.min_core_len; p.min_chimeric_len = a.kp.min_chimeric_len;
+  p.micro_indel_len = a.kp.micro_indel_len; p.max_splice_junct_len = a.kp.max_splice_junct_len;
   return p;
 }
 
-K4_DEV void k4d_store_hit(k4_hit* h, uint32_t chrom_id, uint32_t loci, int len, char strand, int mm) {
+K4_DEV void k4d_store_hit(k4_hit* h, uint32_t chrom_id, uint32_t loci, int len, char strand, int mm, uint32_t ext = 0) {
   uint4 v;
   v.x = chrom_id;
   v.y = loci;
   v.z = (uint32_t)(len & 0xFFFF) | ((uint32_t)(uint8_t)strand << 16) | ((uint32_t)(mm & 0xFF) << 24);
-  v.w = 0;
+  v.w = ext;
   *reinterpret_cast<uint4*>(h) = v;
 }
 
@@ -607,6 +615,7 @@ __global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : 
       if (!FIRST && (uint32_t)i == K4_NO_READ) active = false;
     }
     bool slow = false, survive = false;
+    int ext_from = -1;  // >= 0: every standard phase ran here without a result; the general kernel starts at the optional ones
     if (active) {
       const int len = (int)a.lens[i];
       const K4ReadParams rp = k4d_read_params(a, len);
@@ -680,11 +689,12 @@ __global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : 
           slow = true;
           n_lookup = c0; n_probe = c1; n_cand = c2;
         }
+        else if (rslt == 0 && step + 1 >= n_phases && a.ext_on) { slow = true; ext_from = n_phases; }  // :7894-7930
         else if (rslt != 0 || step + 1 >= n_phases) k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
         else survive = true;
       }
       if (slow) {
-        k4d_push_slow(a, i, step);
+        k4d_push_slow(a, i, ext_from >= 0 ? ext_from : step);
         n_slow++;
       }
     }
@@ -1002,11 +1012,18 @@ K4_DEV int64_t k4d_first_exact_wave(const K4DevIndex& ix, const K4Slow& sc, int 
   return found >= 0 ? found + 1 : 0;
 }
 
-template <int EL>
+#include "k4_ext.h"
+
+// CHIM: the chimeric branch (:6064-6189) -- every new in-bounds candidate is flank-trimmed by AdaptiveTrim (one lane each,
+// its mismatch vector in the lane's column of mk) instead of being counted out by the Hamming extension, and the fold ranks
+// by trimmed length first.  min_probe_chim = MinProbeChimericLen (:5880).
+template <int EL, bool CHIM>
 K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm, int cl, int core_delta,
                         const K4ReadParams& rp, int* p_inst, int* p_low, int* p_nxt, k4_hit* hits,
-                        uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand) {
+                        uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand, int min_probe_chim = 0,
+                        uint32_t* mk = nullptr) {
   const K4DevIndex& ix = a.ix;
+  int best_len = 0, best_mms = 0;  // BestChimericLen / BestMaxChimericMMs: one per call, not per strand (:5936-5940)
   if (*p_inst > rp.max_hits && *p_low == 0) return K4_HR_HITINSTS;
   if (*p_inst >= 1 && *p_low == 0 && (*p_nxt - *p_low) < rp.mm_delta) return K4_HR_MMDELTA;
   K4State st;
@@ -1131,10 +1148,19 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
         }
         run_over = hit_limit || ended;  // (ended is false when every sub-batch looked at was full of members)
         // 6. the Hamming extension (:6200-6261) for the candidates that are new in this strand pass
+        K4Trim trim[KB];
 #pragma unroll
         for (int k = 0; k < KB; k++) {
           mm[k] = 0;
           eos[k] = false;
+          trim[k].len = trim[k].t5 = trim[k].t3 = trim[k].mms = 0;
+          if (CHIM) {  // :6097 AdaptiveTrim(ProbeLen, probe, target, MinProbeChimericLen, MaxTotMM, 3 flank matches)
+            if ((newm[k] >> lane) & 1) {
+              k4d_build_mm_vector(ix, sc, len, pos[k] - (uint64_t)o, mk);
+              trim[k] = k4d_adaptive_trim(mk, len, min_probe_chim, allow_mm, 3);
+            }
+            continue;
+          }
           if ((newm[k] >> lane) & 1) {
             const uint64_t left = pos[k] - (uint64_t)o;
             if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
@@ -1152,11 +1178,38 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
 #pragma unroll
         for (int k = 0; k < KB; k++) {
           if (done_all) break;
-          unsigned long long todo = __ballot(((newm[k] >> lane) & 1) && !eos[k] && mm[k] <= allow_mm);
+          unsigned long long todo = CHIM ? __ballot(((newm[k] >> lane) & 1) && trim[k].len >= min_probe_chim && trim[k].len > 0)
+                                         : __ballot(((newm[k] >> lane) & 1) && !eos[k] && mm[k] <= allow_mm);
           int stop_lane = -1;
           while (todo) {
             const int c = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
+            if (CHIM) {  // the fold of :6106-6188
+              const int c_len = __shfl(trim[k].len, c, 64), c_mms = __shfl(trim[k].mms, c, 64);
+              const int t5 = __shfl(trim[k].t5, c, 64), t3 = __shfl(trim[k].t3, c, 64);
+              const int e_c = __shfl(e[k], c, 64);
+              const uint32_t loci_c = (uint32_t)__shfl((int)loci[k], c, 64);
+              const uint32_t tl = cur_strand == '+' ? (uint32_t)t5 : (uint32_t)t3, tr = cur_strand == '+' ? (uint32_t)t3 : (uint32_t)t5;
+              const uint32_t ext = K4_EXT_CHIMERIC | (tl & 0xFFFu) | ((tr & 0xFFFu) << 12);
+              if (c_len > best_len || (c_len == best_len && c_mms < best_mms)) {
+                if (best_len > 0 && c_len > best_len) st.low = c_mms + rp.mm_delta + 1;
+                best_len = c_len; best_mms = c_mms;
+                st.cur_hit = 0;
+                st.inst = 1;
+                st.nxt = st.low;
+                st.low = c_mms;
+                if (hits_w) k4d_store_hit(&hits_w[0], ix.ent_id[e_c], loci_c, len, cur_strand, c_mms, ext);
+              } else if (c_len == best_len && c_mms == best_mms) {
+                st.inst += 1;
+                if (st.cur_hit != -1 && st.inst <= rp.max_hits) {
+                  st.cur_hit += 1;
+                  if (hits_w && st.cur_hit < rp.max_hits) k4d_store_hit(&hits_w[st.cur_hit], ix.ent_id[e_c], loci_c, len, cur_strand, c_mms, ext);
+                }
+              } else if (c_len == best_len && c_mms < st.nxt)
+                st.nxt = c_mms;
+              if (c_len == len && st.inst > rp.max_hits && st.low == 0) { stop_lane = c; break; }  // :6187
+              continue;
+            }
             const int mm_c = __shfl(mm[k], c, 64);
             if (mm_c >= st.nxt) continue;
             const int e_c = __shfl(e[k], c, 64);
@@ -1319,10 +1372,51 @@ K4_DEV int k4d_best_slow(const K4AlignArgs& a, K4Slow& sc, int len, int max_tot_
   return sloughed ? inst + 1 : inst;
 }
 
+// The optional phases of AlignReads for a read the standard ones left without a result (SfxArray.cpp:7894-7930), in the
+// reference's order: microInDels, splice junctions (both with MaxHits 1, into hit slot 0 + the read's k4_seg2), then the
+// chimeric LocateCoreMultiples pass with its own core length.  Returns tHRslt, K4_NEED_SLOW or a negative error code.
+template <int EL>
+K4_DEV int k4d_ext_phases(const K4AlignArgs& a, K4Slow& sc, int len, const K4ReadParams& rp, int* inst, int* low, int* nxt,
+                          k4_hit* hits, k4_seg2* seg2, uint32_t* mk, uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand) {
+  int rslt = 0;
+  // no hit has been stored for this read so far; its slots start out zero (what the reference's caller would find in slots a
+  // phase counts but never writes is its own stale memory)
+  if (sc.lane == 0)
+    for (int q = 0; q < rp.max_hits; q++) *reinterpret_cast<uint4*>(&hits[q]) = make_uint4(0, 0, 0, 0);
+  if (rp.micro_indel_len > 0) {
+    rslt = k4d_two_seg<EL>(a, sc, false, rp.micro_indel_len, min(rp.tot_mm, 2), rp.core_len, rp.strand, len, inst, low, nxt, &hits[0],
+                           seg2, n_lookup, n_probe, n_cand);
+    if (rslt != 0) return rslt;
+  }
+  if (rp.max_splice_junct_len > 0) {
+    rslt = k4d_two_seg<EL>(a, sc, true, rp.max_splice_junct_len, min(rp.tot_mm, 2), rp.core_len, rp.strand, len, inst, low, nxt,
+                           &hits[0], seg2, n_lookup, n_probe, n_cand);
+    if (rslt != 0) return rslt;
+  }
+  if (rp.min_chimeric_len > 0) {
+    if (rp.max_slides <= 1) return K4_ERR_PARAMS;  // (the reference divides by MaxNumCoreSlides - 1, :7926)
+    const int cl = max(rp.min_core_len, len / (rp.tot_mm + 4));
+    const int cd = max(len / (rp.max_slides - 1), cl);
+    if (cl < 1) return K4_ERR_PARAMS;
+    if (rp.min_chimeric_len >= 15 && rp.min_chimeric_len <= 99)  // :5878-5883 any other value: the default branch
+      rslt = k4d_lcm_slow<EL, true>(a, sc, len, rp.tot_mm, cl, cd, rp, inst, low, nxt, hits, n_lookup, n_probe, n_cand,
+                                    max(cl, (rp.min_chimeric_len * len) / 100), mk);
+    else
+      rslt = k4d_lcm_slow<EL, false>(a, sc, len, rp.tot_mm, cl, cd, rp, inst, low, nxt, hits, n_lookup, n_probe, n_cand);
+    // a hit this pass stored cleared both segments of slot 0 (:6129); the second segment survives only with the two-segment
+    // record a microInDel / splice phase left there (it gave up over several equally good loci; its count was carried in)
+    if (seg2 && sc.lane == 0 && !(hits[0].ext & (K4_EXT_INDEL | K4_EXT_SPLICE))) *reinterpret_cast<uint4*>(seg2) = make_uint4(0, 0, 0, 0);
+    return rslt;
+  }
+  return 0;
+}
+
 // persistent waves pull read ids from their list until it is drained (every wave reaches the exit test).
 // pass 0: many waves with small dedupe tables (list = slow_list, ctl[0]/[1]); pass 1: few waves with tables sized for
 // the reference's own limits (list = huge_list, ctl[K4_CTL_HUGE]/[+1]).
-template <int EL>
+// EXT: the instantiation that also holds the optional phases (k4_ext.h); launched only when one of them is requested, so
+// that the standard path keeps the register budget (and with it the occupancy) of the lean one.
+template <int EL, bool EXT>
 __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_waves, int pass, uint64_t* hash_base,
                                                      uint32_t hash_cap, uint32_t* gen_base, int max_len) {
   // dynamic LDS, sized by the batch (k4_slow_lds_bytes): entry table copy | packed probe | probe bytes
@@ -1330,6 +1424,8 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
   uint64_t* ent_s = slow_lds;
   uint64_t* pk_s = slow_lds + (a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES : 0);
   uint8_t* probe_s = reinterpret_cast<uint8_t*>(pk_s + (max_len / 32 + 2));
+  // (chimeric phase only) one mismatch bit vector per lane behind the probe bytes, word w of lane l at mk_s[w * 64 + l]
+  uint32_t* mk_s = reinterpret_cast<uint32_t*>(probe_s + ((max_len + 64 + 7) & ~7)) + threadIdx.x;
   const uint32_t wave = blockIdx.x;
   const int lane = threadIdx.x;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0;
@@ -1398,22 +1494,36 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
         }
         continue;
       }
-      if (rp.tot_mm > 0) {
-        for (allow = 0; allow <= rp.tot_mm; allow++) {
-          int cl = len / (allow + rp.mm_delta);
-          if (cl <= rp.core_len) break;
+      // the standard phases -- unless the fast path ran all of them without a result and only the optional ones are left:
+      // then the In/Out state is what the last LocateCoreMultiples initialised it to (:5902-5907), no instance seen
+      int n_std = 0;
+      if (rp.tot_mm > 0)
+        for (; n_std <= rp.tot_mm; n_std++)
+          if (len / (n_std + rp.mm_delta) <= rp.core_len) break;
+      n_std += (rp.tot_mm > 0 ? n_std <= rp.tot_mm : true) ? 1 : 0;
+      const bool std_done = EXT && a.ext_on && from_phase >= n_std;
+      if (std_done) {
+        inst = 0; low = nxt = rp.tot_mm + rp.mm_delta + 1;
+      } else {
+        if (rp.tot_mm > 0) {
+          for (allow = 0; allow <= rp.tot_mm; allow++) {
+            int cl = len / (allow + rp.mm_delta);
+            if (cl <= rp.core_len) break;
+            t0 = n_lookup; t1 = n_probe; t2 = n_cand;
+            rslt = k4d_lcm_slow<EL, false>(a, sc, len, allow, cl, cl, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
+            if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }  // tallied by the fast path already
+            if (rslt != 0) break;
+          }
+        }
+        if (rslt == 0 && allow <= rp.tot_mm) {
           t0 = n_lookup; t1 = n_probe; t2 = n_cand;
-          rslt = k4d_lcm_slow<EL>(a, sc, len, allow, cl, cl, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
-          if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }  // tallied by the fast path already
-          if (rslt != 0) break;
+          rslt = k4d_lcm_slow<EL, false>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, &low, &nxt, hits,
+                                         n_lookup, n_probe, n_cand);
+          if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }
         }
       }
-      if (rslt == 0 && allow <= rp.tot_mm) {
-        t0 = n_lookup; t1 = n_probe; t2 = n_cand;
-        rslt = k4d_lcm_slow<EL>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, &low, &nxt, hits,
-                                n_lookup, n_probe, n_cand);
-        if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }
-      }
+      if (EXT && rslt == 0 && a.ext_on)  // SfxArray.cpp:7894-7930
+        rslt = k4d_ext_phases<EL>(a, sc, len, rp, &inst, &low, &nxt, hits, a.seg2 ? a.seg2 + i : nullptr, mk_s, n_lookup, n_probe, n_cand);
       if (rslt == K4_NEED_SLOW) {  // outgrew the small table: the big-table pass redoes the read (and tallies it)
         n_lookup = r0; n_probe = r1; n_cand = r2;
         if (lane == 0) {
@@ -1423,7 +1533,13 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
         }
         continue;
       }
-      if (lane == 0) k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
+      if (lane == 0) {
+        // a read without a reported hit has no second segment either (a two-segment phase may have left one behind)
+        if (EXT && a.seg2 && !(rslt == K4_HR_HITS || rslt == K4_HR_MMDELTA || rslt == K4_HR_HITINSTS))
+          *reinterpret_cast<uint4*>(a.seg2 + i) = make_uint4(0, 0, 0, 0);
+        if (rslt < 0) k4d_finalize(a, i, len, rp, a.mode == 0 ? rslt : K4_HR_FATAL, 0, 0, 0);
+        else k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
+      }
     }
     if (lane == 0) gen_base[wave] = sc.gen;
   }
@@ -1583,14 +1699,22 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
   }
   if (rc != K4_OK) return rc;
   const int slow_len = std::min(std::max(max_len, 1), K4_MAX_READ_LEN);
+  const bool chim = a.ext_on && (a.mode == 0 ? a.ap.min_chimeric_len : a.kp.min_chimeric_len) > 0;
   const size_t slow_lds = (size_t)(a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES : 0) * 8 + (size_t)(slow_len / 32 + 2) * 8 +
-                          (size_t)slow_len + 64;
+                          (size_t)((slow_len + 64 + 7) & ~7) + (chim ? (size_t)64 * 4 * ((slow_len + 31) / 32 + 1) : 0) + 16;
+  if (slow_lds > 48 * 1024) K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_slow<EL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slow_lds));
   // (no more waves than reads: a batch of one -- the facade's AlignReads -- should not pay for 8192 idle blocks)
   const uint32_t sw = (uint32_t)std::min<int64_t>(K4_SLOW_WAVES, std::max<int64_t>(a.n_reads, 1));
   const uint32_t hw = (uint32_t)std::min<int64_t>(K4_HUGE_WAVES, std::max<int64_t>(a.n_reads, 1));
-  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(sw), dim3(64), slow_lds, st, a, sw, 0, small_base, (uint32_t)K4_SMALL_HASH, gen_small,
-                     slow_len);
-  hipLaunchKernelGGL((k4k_align_slow<EL>), dim3(hw), dim3(64), slow_lds, st, a, hw, 1, big_base, w.slow_hash_cap, gen_big, slow_len);
+  if (a.ext_on) {
+    hipLaunchKernelGGL((k4k_align_slow<EL, true>), dim3(sw), dim3(64), slow_lds, st, a, sw, 0, small_base, (uint32_t)K4_SMALL_HASH,
+                       gen_small, slow_len);
+    hipLaunchKernelGGL((k4k_align_slow<EL, true>), dim3(hw), dim3(64), slow_lds, st, a, hw, 1, big_base, w.slow_hash_cap, gen_big, slow_len);
+  } else {
+    hipLaunchKernelGGL((k4k_align_slow<EL, false>), dim3(sw), dim3(64), slow_lds, st, a, sw, 0, small_base, (uint32_t)K4_SMALL_HASH,
+                       gen_small, slow_len);
+    hipLaunchKernelGGL((k4k_align_slow<EL, false>), dim3(hw), dim3(64), slow_lds, st, a, hw, 1, big_base, w.slow_hash_cap, gen_big, slow_len);
+  }
   K4_HIP(ix, hipGetLastError());
   return K4_OK;
 }
@@ -1603,6 +1727,19 @@ static int run_dev(k4_index* ix, K4AlignArgs& a, int max_len, void* stream) {
                    max_len, a.max_hits);
   a.ix = ix->d;
   hipStream_t st = (hipStream_t)stream;
+  {  // the optional phases (SfxArray.cpp:7894-7930): argument ranges as kalign enforces them (KAlignerCL.cpp:667-761)
+    const int mc = a.mode == 0 ? a.ap.min_chimeric_len : a.kp.min_chimeric_len;
+    const int mi = a.mode == 0 ? a.ap.micro_indel_len : a.kp.micro_indel_len;
+    const int ms = a.mode == 0 ? a.ap.max_splice_junct_len : a.kp.max_splice_junct_len;
+    if (mc < 0 || mi < 0 || mi > 20 || ms < 0 || (ms != 0 && (ms < 25 || ms > 100000)))
+      return k4_fail(ix, K4_ERR_PARAMS, "MinChimericLen / microInDelLen (0..20) / MaxSpliceJunctLen (0, 25..100000) out of range");
+    a.ext_on = (mc > 0 || mi > 0 || ms > 0) ? 1 : 0;
+    if ((mi > 0 || ms > 0) && !a.seg2)
+      return k4_fail(ix, K4_ERR_PARAMS, "microInDel / splice phases report two segments: use the *_ext entry points (k4_seg2 output)");
+    if (a.ext_on && (a.best || (a.mode == 1 && a.kp.pe_mode == 4)))
+      return k4_fail(ix, K4_ERR_PARAMS, "the optional AlignReads phases cannot be combined with LocateBestMatches (-N)");
+    if (a.seg2 && a.n_reads > 0) K4_HIP(ix, hipMemsetAsync(a.seg2, 0, (size_t)a.n_reads * sizeof(k4_seg2), st));
+  }
   // number of AlignReads phases any read can have: escalation 0..TotMM, or fewer plus the final phase (SfxArray.cpp:7867-7891)
   int tot_mm = a.ap.tot_mm;
   if (a.mode == 1) {
@@ -1625,6 +1762,11 @@ static int check_align_params(k4_index* ix, const k4_align_params* p) {
 extern "C" int k4_align_reads_batch_dev(k4_index* ix, const k4_align_params* p, int64_t n, int32_t max_len,
                                         const void* d_reads, const void* d_offs, const void* d_lens, void* d_rslt,
                                         void* d_inst, void* d_low, void* d_nxt, void* d_hits, void* stream) {
+  return k4_align_reads_ext_batch_dev(ix, p, n, max_len, d_reads, d_offs, d_lens, d_rslt, d_inst, d_low, d_nxt, d_hits, nullptr, stream);
+}
+extern "C" int k4_align_reads_ext_batch_dev(k4_index* ix, const k4_align_params* p, int64_t n, int32_t max_len,
+                                            const void* d_reads, const void* d_offs, const void* d_lens, void* d_rslt,
+                                            void* d_inst, void* d_low, void* d_nxt, void* d_hits, void* d_seg2, void* stream) {
   if (!ix) return K4_ERR_PARAMS;
   int rc = check_align_params(ix, p);
   if (rc != K4_OK) return rc;
@@ -1636,6 +1778,7 @@ extern "C" int k4_align_reads_batch_dev(k4_index* ix, const k4_align_params* p, 
   a.n_reads = n; a.mode = 0; a.ap = *p;
   a.rslt = (int32_t*)d_rslt; a.inst = (int32_t*)d_inst; a.low = (int32_t*)d_low; a.nxt = (int32_t*)d_nxt;
   a.hits = (k4_hit*)d_hits; a.max_hits = p->max_hits;
+  a.seg2 = (k4_seg2*)d_seg2;
   return run_dev(ix, a, max_len, stream);
 }
 
@@ -1678,8 +1821,19 @@ extern "C" int k4_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int6
                                    void* d_hits, void* stream) {
   return k4i_kalign_batch_dev(ix, p, n, max_len, d_reads, d_offs, d_lens, d_out, d_hits, stream, 0);
 }
+static int kalign_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len, const void* d_reads, const void* d_offs,
+                      const void* d_lens, void* d_out, void* d_hits, void* d_seg2, void* stream, int sparse_hits);
+extern "C" int k4_kalign_ext_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len, const void* d_reads,
+                                       const void* d_offs, const void* d_lens, void* d_out, void* d_hits, void* d_seg2,
+                                       void* stream) {
+  return kalign_dev(ix, p, n, max_len, d_reads, d_offs, d_lens, d_out, d_hits, d_seg2, stream, 0);
+}
 int k4i_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len, const void* d_reads,
                          const void* d_offs, const void* d_lens, void* d_out, void* d_hits, void* stream, int sparse_hits) {
+  return kalign_dev(ix, p, n, max_len, d_reads, d_offs, d_lens, d_out, d_hits, nullptr, stream, sparse_hits);
+}
+static int kalign_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int32_t max_len, const void* d_reads, const void* d_offs,
+                      const void* d_lens, void* d_out, void* d_hits, void* d_seg2, void* stream, int sparse_hits) {
   if (!ix) return K4_ERR_PARAMS;
   K4AlignArgs a;
   memset(&a, 0, sizeof(a));
@@ -1689,6 +1843,7 @@ int k4i_kalign_batch_dev(k4_index* ix, const k4_kalign_params* p, int64_t n, int
   a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
   a.n_reads = n; a.mode = 1;
   a.rr = (k4_read_result*)d_out; a.hits = (k4_hit*)d_hits; a.max_hits = a.kp.max_ml;
+  a.seg2 = (k4_seg2*)d_seg2;
   a.sparse_hits = sparse_hits;
   return run_dev(ix, a, max_len, stream);
 }
@@ -1770,9 +1925,26 @@ static int fetch_small(k4_index* ix, int64_t n, int max_hits, const int32_t** ou
   return K4_OK;
 }
 
+// second segments of a host-pointer batch: a temporary device array, copied down after the stream has drained
+struct Seg2Stage {
+  void* d = nullptr;
+  ~Seg2Stage() { if (d) hipFree(d); }
+  int alloc(k4_index* ix, int64_t n) { K4_HIP(ix, hipMalloc(&d, (size_t)std::max<int64_t>(n, 1) * sizeof(k4_seg2))); return K4_OK; }
+  int fetch(k4_index* ix, k4_seg2* out, int64_t n) {
+    K4_HIP(ix, hipMemcpyAsync(out, d, (size_t)n * sizeof(k4_seg2), hipMemcpyDeviceToHost, ix->stream));
+    K4_HIP(ix, hipStreamSynchronize(ix->stream));
+    return K4_OK;
+  }
+};
+
 extern "C" int k4_align_reads_batch(k4_index* ix, const k4_align_params* p, int64_t n, const uint8_t* reads,
                                     const uint64_t* offs, const uint32_t* lens, int32_t* rslt, int32_t* inst,
                                     int32_t* low, int32_t* nxt, k4_hit* hits) {
+  return k4_align_reads_ext_batch(ix, p, n, reads, offs, lens, rslt, inst, low, nxt, hits, nullptr);
+}
+extern "C" int k4_align_reads_ext_batch(k4_index* ix, const k4_align_params* p, int64_t n, const uint8_t* reads,
+                                        const uint64_t* offs, const uint32_t* lens, int32_t* rslt, int32_t* inst,
+                                        int32_t* low, int32_t* nxt, k4_hit* hits, k4_seg2* seg2) {
   if (!ix) return K4_ERR_PARAMS;
   int rc = check_align_params(ix, p);
   if (rc != K4_OK) return rc;
@@ -1785,9 +1957,12 @@ extern "C" int k4_align_reads_batch(k4_index* ix, const k4_align_params* p, int6
   if (rc != K4_OK) return rc;
   K4Workspace& w = ix->ws;
   int32_t* o = w.c_out;
-  rc = k4_align_reads_batch_dev(ix, p, n, max_len, w.c_reads, w.c_offs, w.c_lens, o, o + n, o + 2 * n, o + 3 * n,
-                                w.c_hits, ix->stream);
+  Seg2Stage s2;
+  if (seg2 && (rc = s2.alloc(ix, n)) != K4_OK) return rc;
+  rc = k4_align_reads_ext_batch_dev(ix, p, n, max_len, w.c_reads, w.c_offs, w.c_lens, o, o + n, o + 2 * n, o + 3 * n,
+                                    w.c_hits, s2.d, ix->stream);
   if (rc != K4_OK) return rc;
+  if (seg2 && (rc = s2.fetch(ix, seg2, n)) != K4_OK) return rc;
   if (w.c_small) {
     const int32_t* r;
     const k4_hit* h;
@@ -1840,6 +2015,10 @@ extern "C" int k4_best_matches_batch(k4_index* ix, const k4_align_params* p, int
 
 extern "C" int k4_kalign_batch(k4_index* ix, const k4_kalign_params* p, int64_t n, const uint8_t* reads,
                                const uint64_t* offs, const uint32_t* lens, k4_read_result* out, k4_hit* hits) {
+  return k4_kalign_ext_batch(ix, p, n, reads, offs, lens, out, hits, nullptr);
+}
+extern "C" int k4_kalign_ext_batch(k4_index* ix, const k4_kalign_params* p, int64_t n, const uint8_t* reads,
+                                   const uint64_t* offs, const uint32_t* lens, k4_read_result* out, k4_hit* hits, k4_seg2* seg2) {
   if (!ix || !p) return K4_ERR_PARAMS;
   if (n < 0 || (n > 0 && (!reads || !offs || !lens || !out || !hits))) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
   if (p->max_ml < 1) return k4_fail(ix, K4_ERR_PARAMS, "max_ml must be >= 1");
@@ -1849,8 +2028,11 @@ extern "C" int k4_kalign_batch(k4_index* ix, const k4_kalign_params* p, int64_t 
   int rc = stage_in(ix, n, reads, offs, lens, p->max_ml, &max_len, 24);
   if (rc != K4_OK) return rc;
   K4Workspace& w = ix->ws;
-  rc = k4_kalign_batch_dev(ix, p, n, max_len, w.c_reads, w.c_offs, w.c_lens, w.c_out, w.c_hits, ix->stream);
+  Seg2Stage s2;
+  if (seg2 && (rc = s2.alloc(ix, n)) != K4_OK) return rc;
+  rc = k4_kalign_ext_batch_dev(ix, p, n, max_len, w.c_reads, w.c_offs, w.c_lens, w.c_out, w.c_hits, s2.d, ix->stream);
   if (rc != K4_OK) return rc;
+  if (seg2 && (rc = s2.fetch(ix, seg2, n)) != K4_OK) return rc;
   if (w.c_small) {
     const int32_t* r;
     const k4_hit* h;

@@ -35,7 +35,7 @@ struct Buf {
 
 constexpr uint32_t kUniq = 0x8000u;  // cUniqueClustFlg and friends, KAligner.h:96-101
 constexpr uint32_t kOverlap = 10, kUScore = 5, kMScore = 1, kScale = 10, kMinScore = 50;
-// state of a locus in `reserved` of its k4_hit while this runs (cleared before returning)
+// state of a locus in `ext` of its k4_hit (these modes are not combined with the optional AlignReads phases) while this runs (cleared before returning)
 constexpr uint32_t kWon = 1u << 16, kWonAny = 1u << 17;
 
 struct Ent {  // a locus in SortMultiHits order
@@ -129,14 +129,14 @@ __global__ void k4k_mm_score(uint64_t m, int ml_mode, uint32_t max_reads_len, co
         sc = min(1 + (ov * kMScore) / kScale + (sc & ~kUniq), 0x3fffu);
       }
     }
-    hits[val[i]].reserved = sc;
+    hits[val[i]].ext = sc;
   }
 }
 
 // SortMultiHitReadIDs order among the loci of one read (:11058-11098): score descending, then chrom, len, mismatches,
 // start, strand
 K4_DEV bool k4d_mm_before(const k4_hit& a, const k4_hit& b) {
-  if (a.reserved != b.reserved) return a.reserved > b.reserved;
+  if (a.ext != b.ext) return a.ext > b.ext;
   if (a.chrom_id != b.chrom_id) return a.chrom_id < b.chrom_id;
   if (a.match_len != b.match_len) return a.match_len < b.match_len;
   if (a.mismatches != b.mismatches) return a.mismatches < b.mismatches;
@@ -155,11 +155,11 @@ __global__ void k4k_mm_winner(int64_t n, int32_t max_ml, const k4_read_result* _
       if (k4d_mm_before(h[q], h[b0])) { b1 = b0; b0 = q; }
       else if (b1 < 0 || k4d_mm_before(h[q], h[b1])) b1 = q;
     }
-    const uint32_t s0 = h[b0].reserved, s1 = h[b1].reserved;
+    const uint32_t s0 = h[b0].ext, s1 = h[b1].ext;
     const uint32_t best = s0 & ~kUniq;
     if (best < kMinScore) continue;
     if ((s0 & kUniq) == (s1 & kUniq) && best < 2u * (s1 & ~kUniq)) continue;
-    h[b0].reserved = s0 | kWon | ((s0 & kUniq) ? 0u : kWonAny);
+    h[b0].ext = s0 | kWon | ((s0 & kUniq) ? 0u : kWonAny);
   }
 }
 
@@ -170,7 +170,7 @@ __global__ void k4k_mm_state(uint64_t m, const Ent* __restrict__ ent, const uint
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
     uint8_t s = 1;
     if (ent[i].mh) {
-      const uint32_t r = hits[val[i]].reserved;
+      const uint32_t r = hits[val[i]].ext;
       s = !(r & kWon) ? 0 : (r & kWonAny) ? 2 : 1;
     }
     st0[i] = s;
@@ -221,11 +221,11 @@ __global__ void k4k_mm_assign(uint64_t m, int32_t max_ml, const Ent* __restrict_
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
     if (!ent[i].mh) continue;
     const uint64_t v = val[i];
-    const bool won = (hits[v].reserved & kWon) && st[i] == 1;
+    const bool won = (hits[v].ext & kWon) && st[i] == 1;
     if (!won) continue;
     const uint32_t r = ent[i].read;
     k4_hit h = hits[v];
-    h.reserved = (uint32_t)(v - (uint64_t)r * max_ml) | 0x80000000u;  // parked: slot 0 may still be read by its own thread
+    h.ext = (uint32_t)(v - (uint64_t)r * max_ml) | 0x80000000u;  // parked: slot 0 may still be read by its own thread
     hits[v] = h;
     rr[r].nar = K4_NAR_ACCEPTED;
     rr[r].num_hits = 1;
@@ -241,8 +241,8 @@ __global__ void k4k_mm_finish(int64_t n, int32_t max_ml, const uint32_t* __restr
     k4_hit* h = hits + i * max_ml;
     int win = -1;
     for (int q = 0; q < inst; q++) {
-      if (h[q].reserved & 0x80000000u) win = q;
-      h[q].reserved = 0;
+      if (h[q].ext & 0x80000000u) win = q;
+      h[q].ext = 0;
     }
     if (win > 0) h[0] = h[win];
   }

@@ -1,0 +1,644 @@
+// kit4b_amd/csrc/k4_ext.h -- the OPTIONAL phases of CSfxArray::AlignReads on gfx950; included by k4_align.hip
+// in front of the general kernel, whose wave-per-read frame (K4Slow: probe in LDS, 64-way seed search, run walk with one
+// suffix per lane) they run in.  A read gets here only when the standard phases found nothing (SfxArray.cpp:7894-7930):
+//   microInDels       CSfxArray::LocateInDels        SfxArray.cpp:7526-7832, ExploreInDelMatchRight/Left :9277-9735
+//   splice junctions  CSfxArray::LocateSpliceJuncts  SfxArray.cpp:7208-7523, ExploreSpliceRight/Left :8771-9265
+//   chimeric trimming CSfxArray::LocateCoreMultiples SfxArray.cpp:6064-6189 with CSfxArray::AdaptiveTrim :5561-5795
+// Division of labour: what is bound by memory latency -- the seed search, the suffix elements and core comparisons of a run,
+// the entry lookups -- is spread over the 64 lanes; each candidate locus is then explored by ONE lane with the reference's
+// own sequential rules (they are full of order-dependent early-outs), 64 candidates at a time; what the reference makes
+// depend on the order of the candidates (best score / tie counting, the chimeric fold) is replayed in suffix order.
+#pragma once
+
+// ---- exact target symbols for a lane that walks along the reference: one packed word per 16 bases, the exception bitmap
+// consulted once per 256-base block; beyond the block: a separator ---------------------------------------------------------
+struct K4Tb {
+  const K4DevIndex* ix;
+  int64_t cw, cblk;
+  uint32_t word;
+  bool flagged;
+  K4_DEV void init(const K4DevIndex& x) { ix = &x; cw = -1; cblk = -1; word = 0; flagged = false; }
+  K4_DEV uint32_t get(int64_t pos) {
+    if (pos < 0 || (uint64_t)pos >= ix->n) return 7u;
+    const int64_t blk = pos >> K4_EXC_SHIFT;
+    if (blk != cblk) { cblk = blk; flagged = (ix->excbm[blk >> 5] >> (blk & 31)) & 1; }
+    if (flagged) return k4d_ref_base(*ix, (uint64_t)pos);
+    const int64_t w = pos >> 4;
+    if (w != cw) { cw = w; word = ix->ref2[w]; }
+    return (word >> (30 - 2 * (uint32_t)(pos & 15))) & 3;
+  }
+};
+
+// ---- AdaptiveTrim (SfxArray.cpp:5561-5795) over a mismatch bit vector: bit j of word j >> 5 (LSB first) is set when read
+// base j differs from the target.  The vector of lane l sits at mk[w * 64 + l] (LDS).  The reference's regions are the runs
+// of equal bits; its two floating-point tests compare fractions whose cross products are small integers, so they are
+// evaluated exactly in integers ((M+1)/100 <= a/b  <=>  (M+1)*b <= 100*a: unequal fractions differ by >= 1/(100*2048)). ------
+struct K4Trim { int len, t5, t3, mms; };
+
+K4_DEV int k4d_mk_bit(const uint32_t* mk, int j) { return (int)((mk[(j >> 5) * 64] >> (j & 31)) & 1u); }
+K4_DEV int k4d_run_end(const uint32_t* mk, int L, int pos) {  // end (exclusive) of the run of equal bits that starts at pos
+  const uint32_t flip = k4d_mk_bit(mk, pos) ? 0xFFFFFFFFu : 0u;
+  int w = pos >> 5, b = pos & 31;
+  for (;;) {
+    const uint32_t d = ((mk[w * 64] ^ flip) >> b);
+    if (d) { const int e = (w << 5) + b + (__ffs((int)d) - 1); return e < L ? e : L; }
+    w++; b = 0;
+    if ((w << 5) >= L) return L;
+  }
+}
+
+K4_DEV K4Trim k4d_adaptive_trim(const uint32_t* mk, int L, int min_trim, int max_mm, int min_flank) {
+  K4Trim r = {0, 0, 0, 0};
+  if (L < 25 || L > 2048 || min_trim < 15 || min_trim > L || max_mm > ((15 * L + 99) / 100) || min_flank > 10) return r;  // :5601-5605
+  if (min_flank == 0) min_flank = 1;
+  if (min_trim == L) {  // :5612-5639 the mismatch total, none of them inside the flanks
+    const int allowed = (L * max_mm + 99) / 100;
+    int mms = 0;
+    for (int pos = 0; pos < L;) {
+      const int e = k4d_run_end(mk, L, pos);
+      if (k4d_mk_bit(mk, pos)) {
+        for (int j = pos; j < e; j++) {
+          if (++mms > allowed) return r;
+          if (j < min_flank || (L - j) < min_flank) return r;
+        }
+      }
+      pos = e;
+    }
+    r.len = L; r.mms = mms;
+    return r;
+  }
+  // :5641-5710 one pass over the runs: is there an exact run of cMinATExactLen, which runs may start / end the result
+  int n_min_exact = 0, first_start = -1, last_start = -1, last_end_end = -1;
+  const int mt16 = (int)(uint16_t)min_trim;
+  for (int pos = 0; pos < L;) {
+    const int e = k4d_run_end(mk, L, pos);
+    if (!k4d_mk_bit(mk, pos)) {
+      const int rl = e - pos;
+      if (rl >= 8) n_min_exact++;
+      if (rl >= min_flank) {
+        if (pos <= L - min_trim) { last_start = pos; if (first_start < 0) first_start = pos; }
+        if (e >= mt16) last_end_end = e;
+      }
+    }
+    pos = e;
+  }
+  if (!n_min_exact || first_start < 0 || last_end_end < 0) return r;
+  // :5712-5780 from every start run extend over the following runs while the mismatch rate allows
+  int best_len = 0, best_mm = 0, best_start = 0, best_end = 0;
+  for (int s = first_start; s <= last_start;) {
+    const int s_end = k4d_run_end(mk, L, s);
+    const bool trim5 = !k4d_mk_bit(mk, s) && (s_end - s) >= min_flank && s <= L - min_trim;
+    if (trim5) {
+      int cur_len = 0, cur_mm = 0;
+      for (int p = s; p < last_end_end;) {
+        const int e = k4d_run_end(mk, L, p);
+        const int rl = e - p;
+        const bool mm = k4d_mk_bit(mk, p) != 0;
+        const bool trim3 = !mm && rl >= min_flank && e >= mt16;
+        cur_len += rl;
+        p = e;
+        if (mm) {
+          if (max_mm == 0) break;
+          cur_mm += rl;
+          if ((max_mm + 1) * (L - s) <= 100 * cur_mm) break;
+        } else if (best_len == 0) {
+          best_start = s; best_end = L - (s + cur_len); best_len = cur_len; best_mm = 0;
+          continue;
+        }
+        if (cur_len < min_trim || !trim3) continue;
+        if ((max_mm + 1) * cur_len <= 100 * cur_mm) continue;
+        if (best_len < cur_len || (best_len == cur_len && (best_mm == 0 || cur_mm < best_mm))) {
+          best_start = s; best_end = L - (s + cur_len); best_len = cur_len; best_mm = cur_mm;
+        }
+      }
+    }
+    s = s_end;
+  }
+  if (best_len >= min_trim) { r.len = best_len; r.t5 = best_start; r.t3 = best_end; r.mms = best_mm; }
+  return r;
+}
+
+// 32 bases of a 2-bit XOR (MSB first, two bits per base) -> one bit per base, base 0 in bit 0
+K4_DEV uint32_t k4d_mm_bits(uint64_t x) {
+  uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
+  y = (y | (y >> 1)) & 0x3333333333333333ull;
+  y = (y | (y >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  y = (y | (y >> 4)) & 0x00FF00FF00FF00FFull;
+  y = (y | (y >> 8)) & 0x0000FFFF0000FFFFull;
+  y = (y | (y >> 16)) & 0x00000000FFFFFFFFull;
+  return __brev((uint32_t)y);
+}
+
+// the mismatch vector of the probe laid on [left, left+len) into this lane's column of mk (N == N is a match, :5618,5651)
+K4_DEV void k4d_build_mm_vector(const K4DevIndex& ix, const K4Slow& sc, int len, uint64_t left, uint32_t* mk) {
+  if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
+    for (int c = 0; 32 * c < len; c++)
+      mk[c * 64] = k4d_mm_bits((k4d_ref_chunk(ix, (int64_t)left + 32 * c) ^ k4d_probe_chunk(sc, 32 * c)) & k4d_range_mask(0, len - 32 * c));
+    return;
+  }
+  K4Tb t;
+  t.init(ix);
+  for (int c = 0; 32 * c < len; c++) {
+    uint32_t m = 0;
+    for (int q = 0; q < 32 && 32 * c + q < len; q++)
+      if ((sc.probe[32 * c + q] & 0x0f) != t.get((int64_t)left + 32 * c + q)) m |= 1u << q;
+    mk[c * 64] = m;
+  }
+}
+
+// ---- the two-segment explorations: one lane, the reference's sequential rules ------------------------------------------------
+#define K4X_MAX_OFSS 12  // mismatch offsets a lane records: max(MaxTotMM, 10) + 1 with MaxTotMM clamped to 2 by AlignReads
+struct K4XHit {
+  uint64_t l0, l1;          // Seg[0] / Seg[1].MatchLoci: concat offsets until the caller converts them
+  uint32_t len0, len1, ofs1, mm0, mm1, score, fl;  // fl: 1 FlgInDel, 2 FlgInsert, 4 FlgSplice, 8 found on the '-' strand
+};
+K4_DEV void k4x_zero(K4XHit& h) { h.l0 = h.l1 = 0; h.len0 = h.len1 = h.ofs1 = h.mm0 = h.mm1 = h.score = h.fl = 0; }
+K4_DEV void k4x_one_seg(K4XHit& h, int len, int64_t targ_ofs, int n_mm) {  // the "mismatches only" result, e.g. :9349-9356
+  k4x_zero(h);
+  h.len0 = (uint32_t)len; h.l0 = (uint64_t)targ_ofs; h.mm0 = (uint32_t)n_mm;
+  h.score = (uint32_t)(500 + len * 3 - n_mm * 5) & 0xFFFFu;
+}
+
+// ExploreInDelMatchRight, SfxArray.cpp:9277-9495
+K4_DEV int k4x_indel_right(K4Tb& t, const uint8_t* probe, int micro_indel_len, int max_tot_mm, int len, uint64_t e_start,
+                           uint64_t e_end, int64_t targ_ofs, K4XHit& hit) {
+  k4x_zero(hit);
+  if (targ_ofs < (int64_t)e_start || (targ_ofs + len - 1) > (int64_t)e_end) return 0;
+  const uint32_t targ_seq_len = (uint32_t)((e_end - e_start + 1) - ((uint64_t)targ_ofs - e_start));
+  int mm_ofs[K4X_MAX_OFSS];
+  int n_mm = 0;
+  uint32_t pb = 0, tv = 0;
+  const int lim = max(max_tot_mm, 7);
+  for (int idx = 0; idx < len && n_mm <= lim; idx++) {
+    pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
+    if (tv > 4 || pb > 4) return 0;
+    if (pb == tv && pb <= 3) continue;
+    mm_ofs[n_mm++] = idx;
+  }
+  if (n_mm < 7 || 7 > (len - mm_ofs[0])) {
+    if (n_mm > max_tot_mm) return 0;
+    k4x_one_seg(hit, len, targ_ofs, n_mm);
+    return 1;
+  }
+  const int tot_mm = min(max_tot_mm, n_mm);
+  K4XHit ins, del;
+  k4x_zero(ins); k4x_zero(del);
+  for (int pass = 0; pass < 2; pass++) {  // insertion into the probe :9363-9423, deletion from it :9426-9482
+    K4XHit& best = pass == 0 ? ins : del;
+    for (int m = 0; m <= tot_mm && 7 < (len - mm_ofs[m]); m++) {
+      for (int gl = 1; gl <= micro_indel_len; gl++) {
+        int score = 500 + len * 3 - ((gl - 1) + 20);
+        const int p0 = pass == 0 ? mm_ofs[m] + gl : mm_ofs[m];
+        const int t0 = pass == 0 ? mm_ofs[m] : mm_ofs[m] + gl;
+        const uint32_t tmp_probe_len = (uint32_t)(len - p0);
+        if (tmp_probe_len < 7) break;
+        if ((targ_seq_len - (uint32_t)t0) < tmp_probe_len) break;
+        int mms = 0;
+        uint32_t idx;
+        for (idx = 0; idx < tmp_probe_len && (m + mms) <= max_tot_mm; idx++) {
+          pb = probe[p0 + (int)idx] & 7; tv = t.get(targ_ofs + t0 + (int64_t)idx);
+          if (pb > 4 || tv > 4) break;
+          if (pb == tv && pb <= 3) continue;
+          mms += 1;
+          score -= 5;
+          if (tmp_probe_len < (uint32_t)(7 * mms)) break;
+        }
+        if (idx != tmp_probe_len) continue;
+        if (score > (int)best.score) {
+          best.len0 = (uint32_t)mm_ofs[m]; best.l0 = (uint64_t)targ_ofs; best.mm0 = (uint32_t)m;
+          best.len1 = tmp_probe_len & 0xFFFFu;
+          best.l1 = pass == 0 ? best.l0 + best.len0 : (uint64_t)targ_ofs + best.len0 + (uint64_t)gl;
+          best.mm1 = (uint32_t)mms;
+          best.ofs1 = pass == 0 ? best.len0 + (uint32_t)gl : best.len0;
+          best.score = (uint32_t)score & 0xFFFFu;
+          best.fl = pass == 0 ? 3u : 1u;
+        }
+      }
+    }
+  }
+  if (del.score == 0 && ins.score == 0) return 0;
+  if (del.score > ins.score) { hit = del; return 3; }
+  hit = ins;
+  return 2;
+}
+
+// ExploreInDelMatchLeft, SfxArray.cpp:9506-9735
+K4_DEV int k4x_indel_left(K4Tb& t, const uint8_t* probe, int micro_indel_len, int max_tot_mm, int len, uint64_t e_start,
+                          uint64_t e_end, int64_t targ_ofs, K4XHit& hit) {
+  k4x_zero(hit);
+  if (targ_ofs < (int64_t)e_start || (targ_ofs + len - 1) > (int64_t)e_end) return 0;
+  int mm_ofs[K4X_MAX_OFSS];
+  int n_mm = 0, idx;
+  uint32_t pb = 0, tv = 0;
+  const int lim = max(max_tot_mm, 7);
+  for (idx = len - 1; idx >= 0 && n_mm <= lim; idx--) {
+    pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
+    if (tv > 4 || pb > 4) return 0;
+    if (pb == tv && pb <= 3) continue;
+    mm_ofs[n_mm++] = idx;
+  }
+  if (n_mm < 7 || 7 > mm_ofs[0]) {
+    if (n_mm > max_tot_mm) return 0;
+    k4x_one_seg(hit, len, targ_ofs, n_mm);
+    return 1;
+  }
+  const int tot_mm = min(max_tot_mm, n_mm);
+  K4XHit ins, del;
+  k4x_zero(ins); k4x_zero(del);
+  for (int pass = 0; pass < 2; pass++) {  // insertion :9592-9658, deletion :9662-9722
+    K4XHit& best = pass == 0 ? ins : del;
+    for (int m = 0; m <= tot_mm && 7 < mm_ofs[m]; m++) {
+      for (int gl = 1; gl <= micro_indel_len; gl++) {
+        int score = 500 + len * 3 - ((gl - 1) + 20) - m * 5;
+        if (score < (int)best.score) break;
+        const int p0 = pass == 0 ? mm_ofs[m] - gl : mm_ofs[m];
+        const int t0 = pass == 0 ? mm_ofs[m] : mm_ofs[m] - gl;
+        const uint32_t tmp_probe_len = pass == 0 ? (uint32_t)(mm_ofs[m] - (gl - 1)) : (uint32_t)(mm_ofs[m] + 1);
+        if (tmp_probe_len < 7) break;
+        if (pass == 1 && (int64_t)gl > targ_ofs) break;
+        int mms = 0;
+        for (idx = 0; idx < (int)tmp_probe_len && (m + mms) <= max_tot_mm; idx++) {
+          pb = probe[p0 - idx] & 7; tv = t.get(targ_ofs + t0 - idx);
+          if (pb > 4 || tv > 4) break;
+          if (pb == tv && pb <= 3) continue;
+          mms += 1;
+          score -= 5;
+          if (tmp_probe_len < (uint32_t)(7 * mms)) break;
+        }
+        if (idx != (int)tmp_probe_len) continue;
+        if (score > (int)best.score) {
+          best.len0 = tmp_probe_len & 0xFFFFu;
+          best.l0 = pass == 0 ? (uint64_t)(uint32_t)(targ_ofs + gl) : (uint64_t)(uint32_t)(targ_ofs - gl);  // :9640 / :9705 32-bit casts
+          best.mm0 = (uint32_t)mms;
+          if (pass == 0) {
+            best.len1 = (uint32_t)(len - (int)(tmp_probe_len + (uint32_t)gl)) & 0xFFFFu;
+            best.l1 = best.l0 + best.len0;
+            best.ofs1 = best.len0 + (uint32_t)gl;
+          } else {
+            best.len1 = (uint32_t)(len - (int)tmp_probe_len) & 0xFFFFu;
+            best.l1 = best.l0 + tmp_probe_len + (uint64_t)gl;
+            best.ofs1 = tmp_probe_len & 0xFFFFu;
+          }
+          best.mm1 = (uint32_t)m;
+          best.score = (uint32_t)score & 0xFFFFu;
+          best.fl = pass == 0 ? 3u : 1u;
+        }
+      }
+    }
+  }
+  if (del.score == 0 && ins.score == 0) return 0;
+  if (del.score > ins.score) { hit = del; return 3; }
+  hit = ins;
+  return 2;
+}
+
+K4_DEV uint32_t k4x_splice_bonus(char cur_strand, uint32_t d0, uint32_t d1, uint32_t a0, uint32_t a1) {  // :8969-8984
+  const bool gt_ag = d0 == 2 && d1 == 3 && a0 == 2 && a1 == 0;
+  const bool ct_ac = d0 == 1 && d1 == 3 && a0 == 1 && a1 == 0;
+  if (cur_strand == '+') return gt_ag ? 50u : ct_ac ? 25u : 0u;
+  return ct_ac ? 50u : gt_ag ? 25u : 0u;
+}
+
+// ExploreSpliceRight, SfxArray.cpp:8771-9011
+K4_DEV int k4x_splice_right(K4Tb& t, const uint8_t* probe, char cur_strand, int max_junct_len, int max_tot_mm, int core_len,
+                            int len, int64_t targ_ofs, int64_t targ_len, K4XHit& hit) {
+  k4x_zero(hit);
+  if ((targ_ofs + len + 25) > targ_len) return 0;
+  if (max_tot_mm > 2) max_tot_mm = 2;
+  int mm_ofs[K4X_MAX_OFSS];
+  int n_mm = 0;
+  uint32_t pb = 0, tv = 0, idx;
+  const int lim = max(max_tot_mm, 10);
+  for (idx = (uint32_t)core_len; idx < (uint32_t)len && n_mm <= lim; idx++) {
+    pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
+    if (tv > 4 || pb > 4) return 0;
+    if (pb == tv && pb <= 3) continue;
+    mm_ofs[n_mm++] = (int)idx;
+  }
+  if (n_mm < 8 || 10 > (len - mm_ofs[0])) {
+    if (n_mm > max_tot_mm) return 0;
+    k4x_one_seg(hit, len, targ_ofs, n_mm);
+    return 1;
+  }
+  const int tot_mm = min(n_mm, max_tot_mm);
+  {  // :8868-8873 (with MaxTotMM 0 the reference indexes in front of its array; offset 0 stands in for that word)
+    const int64_t p0 = targ_ofs + (tot_mm >= 1 ? mm_ofs[tot_mm - 1] : 0);
+    for (idx = 0; idx < 35u; idx++)
+      if (t.get(p0 + idx) > 4) return 0;
+  }
+  K4XHit cur;
+  k4x_zero(cur);
+  for (int m = 0; m <= tot_mm && 10 < (len - mm_ofs[m]); m++) {
+    if (cur.score >= 1000) break;
+    const uint32_t max_seg_len = (uint32_t)(len - mm_ofs[m]);
+    const uint8_t* cur_p = probe + mm_ofs[m];
+    const int64_t donor = targ_ofs + mm_ofs[m];
+    int64_t t_start = donor + 25;
+    const int max_hash_diff = 4 * (max_tot_mm - m);
+    int probe_hash = 100000;
+    for (idx = 0; idx < max_seg_len; idx++) probe_hash += cur_p[idx] & 7;
+    const int min_hash = probe_hash - max_hash_diff, max_hash = probe_hash + max_hash_diff;
+    int targ_hash = 100000;
+    int64_t t_end = t_start;
+    for (idx = 0; idx < max_seg_len - 1; idx++) {
+      const uint32_t v = t.get(t_end);
+      if (v > 4) break;
+      targ_hash += (int)v;
+      t_end++;
+    }
+    if (idx < (max_seg_len - 1)) break;
+    // two readers: the window's leading and trailing ends move in step (each keeps its own cached word)
+    K4Tb ts = t;
+    for (int gap = 25; gap < max_junct_len - (int)max_seg_len; gap++, t_start++, t_end++) {
+      if ((tv = t.get(t_end)) > 4) break;
+      targ_hash += (int)tv;
+      const uint32_t out = ts.get(t_start);
+      if (targ_hash < min_hash || targ_hash > max_hash) { targ_hash -= (int)out; continue; }
+      targ_hash -= (int)out;
+      const uint32_t tmp_targ_len = (uint32_t)(targ_len - (targ_ofs + mm_ofs[m] + gap + 1));
+      if (tmp_targ_len < max_seg_len) break;
+      int mms = 0;
+      K4Tb tc = ts;
+      for (idx = 0; idx < max_seg_len && (m + mms) < max_tot_mm; idx++) {
+        pb = cur_p[idx] & 7; tv = tc.get(t_start + idx);
+        if (pb > 4 || tv > 4) break;
+        if (pb == tv && pb <= 3) continue;
+        mms += 1;
+      }
+      if (idx != max_seg_len) {
+        if (pb > 4 || tv > 4) break;
+        continue;
+      }
+      uint32_t score = (uint32_t)(500 + len * 3 - (((m + mms) * 5) + ((gap / 1000) * 10)));
+      score += k4x_splice_bonus(cur_strand, tc.get(donor), tc.get(donor + 1), tc.get(t_start - 1), tc.get(t_start - 2));
+      if (score > cur.score) {
+        cur.len0 = (uint32_t)mm_ofs[m]; cur.l0 = (uint64_t)targ_ofs; cur.mm0 = (uint32_t)m;
+        cur.len1 = (uint32_t)(len - mm_ofs[m]); cur.l1 = (uint64_t)(targ_ofs + mm_ofs[m] + gap); cur.mm1 = (uint32_t)mms;
+        cur.ofs1 = (uint32_t)mm_ofs[m];
+        cur.score = score & 0xFFFFu;
+        cur.fl = 4u;
+      }
+    }
+  }
+  if (cur.score == 0) return 0;
+  hit = cur;
+  return 3;
+}
+
+// ExploreSpliceLeft, SfxArray.cpp:9022-9265
+K4_DEV int k4x_splice_left(K4Tb& t, const uint8_t* probe, char cur_strand, int max_junct_len, int max_tot_mm, int core_len,
+                           int len, int64_t targ_ofs, K4XHit& hit) {
+  k4x_zero(hit);
+  if ((uint64_t)targ_ofs < 35u) return 0;
+  if (max_tot_mm > 2) max_tot_mm = 2;
+  const int64_t t3 = targ_ofs + len - 1;
+  const int p3 = len - 1;
+  int mm_ofs[K4X_MAX_OFSS];
+  int n_mm = 0;
+  uint32_t pb = 0, tv = 0, idx;
+  const int lim = max(max_tot_mm, 10);
+  for (idx = (uint32_t)core_len; idx < (uint32_t)len && n_mm <= lim; idx++) {
+    pb = probe[p3 - (int)idx] & 7; tv = t.get(t3 - idx);
+    if (tv > 4 || pb > 4) return 0;
+    if (pb == tv && pb <= 3) continue;
+    mm_ofs[n_mm++] = (int)idx;
+  }
+  if (n_mm < 8 || 10 > (len - mm_ofs[0])) {
+    if (n_mm > max_tot_mm) return 0;
+    k4x_one_seg(hit, len, targ_ofs, n_mm);
+    return 1;
+  }
+  const int tot_mm = min(n_mm, max_tot_mm);
+  for (idx = 0; idx < 35u; idx++)
+    if (t.get(t3 - mm_ofs[tot_mm] - idx) > 4) return 0;
+  K4XHit cur;
+  k4x_zero(cur);
+  for (int m = 0; m <= tot_mm && 10 < (len - mm_ofs[m]); m++) {
+    if (cur.score >= 1000) break;
+    const uint32_t max_seg_len = (uint32_t)(len - mm_ofs[m]);
+    const int cur_p = p3 - mm_ofs[m];
+    const int64_t donor = t3 - mm_ofs[m];
+    int64_t t_start = donor - 25;
+    const int max_hash_diff = 4 * (max_tot_mm - m);
+    int probe_hash = 100000;
+    for (idx = 0; idx < max_seg_len; idx++) probe_hash += probe[cur_p - (int)idx] & 7;
+    const int min_hash = probe_hash - max_hash_diff, max_hash = probe_hash + max_hash_diff;
+    int targ_hash = 100000;
+    int64_t t_end = t_start;
+    for (idx = 0; idx < max_seg_len - 1; idx++) {
+      const uint32_t v = t.get(t_end);
+      if (v > 4) break;
+      targ_hash += (int)v;
+      t_end--;
+    }
+    if (idx < (max_seg_len - 1)) break;
+    K4Tb ts = t;
+    for (int gap = 25; gap < max_junct_len - (int)max_seg_len; gap++, t_start--, t_end--) {
+      if ((tv = t.get(t_end)) > 4) break;
+      targ_hash += (int)tv;
+      const uint32_t out = ts.get(t_start);
+      if (targ_hash < min_hash || targ_hash > max_hash) { targ_hash -= (int)out; continue; }
+      targ_hash -= (int)out;
+      if ((uint32_t)(targ_ofs - gap) < 1u) break;
+      int mms = 0;
+      K4Tb tc = ts;
+      for (idx = 0; idx < max_seg_len && (m + mms) < max_tot_mm; idx++) {
+        pb = probe[cur_p - (int)idx] & 7; tv = tc.get(t_start - idx);
+        if (pb > 4 || tv > 4) break;
+        if (pb == tv && pb <= 3) continue;
+        mms += 1;
+      }
+      if (idx != max_seg_len) {
+        if (pb > 4 || tv > 4) break;
+        continue;
+      }
+      uint32_t score = (uint32_t)(500 + len * 3 - (((m + mms) * 5) + ((gap / 1000) * 10)));
+      score += k4x_splice_bonus(cur_strand, tc.get(t_start + 1), tc.get(t_start + 2), tc.get(donor), tc.get(donor - 1));
+      if (score > cur.score) {
+        cur.len0 = (uint32_t)(len - mm_ofs[m]); cur.l0 = (uint64_t)(targ_ofs - gap); cur.mm0 = (uint32_t)mms;
+        cur.len1 = (uint32_t)mm_ofs[m]; cur.l1 = cur.l0 + cur.len0 + (uint64_t)gap; cur.mm1 = (uint32_t)m;
+        cur.ofs1 = cur.len0;
+        cur.score = score & 0xFFFFu;
+        cur.fl = 4u;
+      }
+    }
+  }
+  if (cur.score == 0) return 0;
+  hit = cur;
+  return 3;
+}
+
+K4_DEV uint64_t k4x_shfl64(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+K4_DEV K4XHit k4x_from_lane(const K4XHit& x, int src) {
+  K4XHit r;
+  r.l0 = k4x_shfl64(x.l0, src); r.l1 = k4x_shfl64(x.l1, src);
+  r.len0 = (uint32_t)__shfl((int)x.len0, src, 64); r.len1 = (uint32_t)__shfl((int)x.len1, src, 64);
+  r.ofs1 = (uint32_t)__shfl((int)x.ofs1, src, 64); r.mm0 = (uint32_t)__shfl((int)x.mm0, src, 64);
+  r.mm1 = (uint32_t)__shfl((int)x.mm1, src, 64); r.score = (uint32_t)__shfl((int)x.score, src, 64);
+  r.fl = (uint32_t)__shfl((int)x.fl, src, 64);
+  return r;
+}
+
+// ---- LocateInDels (SfxArray.cpp:7526-7832) / LocateSpliceJuncts (:7208-7523): two cores per strand -- the read's first and
+// last core_len bases -- every suffix of the core's run explored to the right / to the left.  MaxHits is 1 in both calls
+// (:7903,7918): only pHits[0] is ever written, a tie in score only counts. --------------------------------------------------------
+template <int EL>
+K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_len, int max_tot_mm, int core_len, int strand,
+                       int len, int* p_inst, int* p_low, int* p_nxt, k4_hit* hit0, k4_seg2* seg2, uint32_t& n_lookup,
+                       uint32_t& n_probe, uint32_t& n_cand) {
+  const K4DevIndex& ix = a.ix;
+  const int64_t n = (int64_t)ix.n;
+  const int max_iter = ix.max_iter;
+  const int lane = sc.lane;
+  if (splice && max_tot_mm > 2) max_tot_mm = 2;
+  *p_inst = 0; *p_low = 0; *p_nxt = 0;
+  if (lane == 0) {  // memset(pHits, 0, sizeof(tsHitLoci)), :7280 / :7592
+    *reinterpret_cast<uint4*>(hit0) = make_uint4(0, 0, 0, 0);
+    if (seg2) *reinterpret_cast<uint4*>(seg2) = make_uint4(0, 0, 0, 0);
+  }
+  K4XHit best;
+  k4x_zero(best);
+  int best_inst = 0;
+  char cur_strand = '+';
+  if (strand == K4_STRAND_CRICK) { k4d_revcomp_wave(sc, len); cur_strand = '-'; }
+  do {
+    for (int phase = 0; phase < 2; phase++) {
+      const int ofs = phase == 0 ? 0 : len - core_len;
+      n_lookup++;
+      int64_t t = k4d_first_exact_wave<EL>(ix, sc, ofs, core_len, n_probe);
+      if (t == 0) continue;
+      t -= 1;
+      int iter = 0;
+      bool run_over = false;
+      for (int64_t base = t; !run_over; base += 64) {
+        const int64_t idx = base + lane;
+        const bool have = idx < n;
+        const uint64_t pos = have ? k4d_sa_at<EL>(ix, (uint64_t)idx) : 0;
+        bool fits = have;
+        if (have && idx != t) fits = splice ? !(((int64_t)pos + (phase == 0 ? len : core_len)) >= n) : !(((int64_t)pos + core_len) > n);
+        bool core_ok = have && idx == t;
+        if (!core_ok && fits) core_ok = k4d_lane_cmp(ix, sc, ofs, core_len, pos) == 0;
+        const unsigned long long bad = __ballot(!(fits && core_ok));
+        const int r = bad ? __ffsll((long long)bad) - 1 : 64;
+        n_probe += (uint32_t)(r < 64 ? r + 1 : 64);
+        // filters in front of the exploration, :7368-7383 / :7679-7693 (the entry is looked up at the CORE's position)
+        bool inb = lane < r && pos >= (uint64_t)ofs;
+        const int64_t left = (int64_t)pos - ofs;
+        uint64_t e_start = 0, e_end = 0;
+        if (inb) {
+          const int e = k4d_map_entry_slow(ix, sc.ent, pos, e_start, e_end);
+          if (splice) inb = (left + len) < n && e >= 0 && left >= (int64_t)e_start && (left + len) <= (int64_t)e_end;
+          else inb = e >= 0 && left >= (int64_t)e_start && (left + len - 1) <= (int64_t)e_end && (left + len) <= n;
+        }
+        unsigned long long inm = __ballot(inb);
+        bool hit_limit = false;
+        if (max_iter) {  // IterCnt counts the candidates that got this far; the walk ends with the MaxIter-th
+          const int rem = max_iter - iter;
+          if ((int)__popcll(inm) >= rem) {
+            unsigned long long keep = inm;
+            for (int q = 1; q < rem; q++) keep &= keep - 1;
+            const int last = __ffsll((long long)keep) - 1;
+            inm &= last >= 63 ? ~0ull : ((1ull << (last + 1)) - 1ull);
+            hit_limit = true;
+          }
+        }
+        const int took = (int)__popcll(inm);
+        iter += took;
+        n_cand += (uint32_t)took;
+        K4XHit x;
+        k4x_zero(x);
+        int xr = 0;
+        if ((inm >> lane) & 1) {
+          K4Tb tb;
+          tb.init(ix);
+          if (!splice)
+            xr = phase == 0 ? k4x_indel_right(tb, sc.probe, limit_len, max_tot_mm, len, e_start, e_end, left, x)
+                            : k4x_indel_left(tb, sc.probe, limit_len, max_tot_mm, len, e_start, e_end, left, x);
+          else if (phase == 0) {  // :7392-7426
+            int lim = (int)(n - left);
+            if (lim > 35) {
+              lim -= 35;
+              if (lim > limit_len) lim = limit_len;
+              xr = k4x_splice_right(tb, sc.probe, cur_strand, lim, max_tot_mm, core_len, len, left, n, x);
+            }
+          } else if ((uint64_t)left >= (uint32_t)(ofs + 10)) {  // :7429-7461
+            int lim = min((int32_t)left, (int32_t)limit_len);
+            if (lim >= 35) {
+              lim -= 10;
+              xr = k4x_splice_left(tb, sc.probe, cur_strand, lim, max_tot_mm, core_len, len, left, x);
+            }
+          }
+        }
+        if (xr > 0 && cur_strand == '-') x.fl |= 8u;
+        // replay in suffix order: `>=` the best score so far; an equal score at another locus only counts
+        unsigned long long todo = __ballot(xr > 0);
+        while (todo) {
+          const int c = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const uint32_t xs = (uint32_t)__shfl((int)x.score, c, 64);
+          if (xs < best.score) continue;
+          if (xs == best.score) {
+            if (best.l0 == k4x_shfl64(x.l0, c)) continue;
+            if (++best_inst > 1) continue;
+          } else
+            best_inst = 0;
+          best = k4x_from_lane(x, c);
+          best_inst++;
+        }
+        run_over = hit_limit || r < 64;
+      }
+      if (best_inst >= 1 && best.score >= 1000) { strand = 3; break; }
+    }
+    if (cur_strand == '+' && strand == K4_STRAND_BOTH) {
+      k4d_revcomp_wave(sc, len);
+      cur_strand = '-';
+      strand = K4_STRAND_CRICK;
+    } else
+      strand = 3;
+  } while (!(best_inst >= 1 && best.score >= 1000) && strand != 3);
+  if (cur_strand == '-') k4d_revcomp_wave(sc, len);
+  if (best_inst == 0) return K4_HR_NONE;
+  if (best.score > 1000) best.score = 1000;
+  // concat offsets -> chromosome + locus, :7501-7516 / :7800-7825
+  uint64_t s0 = 0, e0e = 0, s1 = 0, e1e = 0;
+  const int e0 = k4d_map_entry_slow(ix, sc.ent, best.l0, s0, e0e);
+  if (e0 < 0) return K4_HR_NONE;
+  uint32_t chrom1 = 0;
+  uint64_t l1 = best.l1;
+  if (!splice) {
+    const int e1 = k4d_map_entry_slow(ix, sc.ent, best.l1, s1, e1e);
+    if (e1 < 0 || e1 != e0) return K4_HR_NONE;  // (an InDel across two chromosomes, :7811-7814)
+    if (best.l1 > 0) { chrom1 = ix.ent_id[e1]; l1 -= s1; }
+  } else if (best.l1 > 0) {
+    const int e1 = k4d_map_entry_slow(ix, sc.ent, best.l1, s1, e1e);
+    if (e1 < 0) return K4_HR_NONE;
+    chrom1 = ix.ent_id[e1];
+    l1 -= s1;
+  }
+  // (with more than one instance the call returns eHRnone, but the slot and the counts stay as they are: a chimeric pass
+  // that follows sees them carried in, SfxArray.cpp:5890)
+  if (lane == 0) {
+    const uint32_t ext = ((best.fl & 1) ? K4_EXT_INDEL : 0u) | ((best.fl & 2) ? K4_EXT_INSERT : 0u) | ((best.fl & 4) ? K4_EXT_SPLICE : 0u);
+    uint4 v;
+    v.x = ix.ent_id[e0];
+    v.y = (uint32_t)(best.l0 - s0);
+    v.z = (best.len0 & 0xFFFFu) | ((uint32_t)(uint8_t)((best.fl & 8) ? '-' : '+') << 16) | ((best.mm0 & 0xFFu) << 24);
+    v.w = ext;
+    *reinterpret_cast<uint4*>(hit0) = v;
+    if (seg2 && (best.fl & 5)) {  // (a one-segment result leaves the record zero)
+      uint4 w;
+      w.x = chrom1;
+      w.y = (uint32_t)l1;
+      w.z = (best.len1 & 0xFFFFu) | ((best.ofs1 & 0xFFFFu) << 16);
+      w.w = (best.mm1 & 0xFFu) | ((best.score & 0xFFFFu) << 16);
+      *reinterpret_cast<uint4*>(seg2) = w;
+    }
+  }
+  *p_inst = splice ? best_inst : min(1, best_inst);
+  *p_low = (int)(best.mm0 + best.mm1);
+  *p_nxt = *p_low + 2;
+  return best_inst <= 1 ? K4_HR_HITS : K4_HR_NONE;
+}

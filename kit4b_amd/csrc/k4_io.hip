@@ -443,6 +443,7 @@ struct K4SamArgs {
   const k4_hit* hits;
   int max_ml;
   const k4_pe_read* pr;
+  const k4_seg2* seg2;          // SE: second segments of microInDel / splice hits, one per read, or null
   const uint8_t* reads;
   const uint64_t* offs;
   const uint32_t* lens;
@@ -468,18 +469,49 @@ K4_DEV bool k4d_sam_reported(const K4SamArgs& a, int64_t v) {
 }
 
 struct K4SamFields {
-  uint32_t flag, pos, mapq, len, pnext;
+  uint32_t flag, pos, mapq, pnext;
   int32_t tlen;
   bool mate_eq;
+  uint32_t n_ops;
+  uint32_t op_len[7];  // CIGAR, at most S M S  gap  S M S (ReportBAMread, KAligner.cpp:6148-6225)
+  char op[7];
 };
-// ReportBAMread (KAligner.cpp:6041-6146,6231): FLAG, MAPQ = max(1, 254 * hitlen / readlen), mate fields
+// CKAligner::AdjAlignStartLoci / AdjAlignHitLen / AdjStartLoci / AdjHitLen (KAligner.cpp:1633-1693) on the flat records
+K4_DEV uint32_t k4d_adj_start(const k4_hit& h) { return h.match_loci + (h.strand == '+' ? K4_HIT_TRIM_LEFT(h) : K4_HIT_TRIM_RIGHT(h)); }
+K4_DEV uint32_t k4d_adj_len0(const k4_hit& h) { return (uint32_t)h.match_len - K4_HIT_TRIM_LEFT(h) - K4_HIT_TRIM_RIGHT(h); }
+K4_DEV bool k4d_two_segs(const k4_hit& h) { return (h.ext & (K4_EXT_INDEL | K4_EXT_SPLICE)) != 0; }
+K4_DEV k4_seg2 k4d_sam_seg2(const K4SamArgs& a, int64_t i, const k4_hit& h) {
+  k4_seg2 z = {0, 0, 0, 0, 0, 0, 0};
+  return (!a.pe && a.seg2 && k4d_two_segs(h)) ? a.seg2[i] : z;
+}
+// ReportBAMread (KAligner.cpp:6041-6251): FLAG, POS, CIGAR, MAPQ = max(1, M * aligned / readlen) with M = 254, less 20 for
+// a splice junction and 10 for a microInDel, mate fields
 K4_DEV K4SamFields k4d_sam_fields(const K4SamArgs& a, int64_t v, const k4_hit& h) {
   const int64_t i = k4d_sam_read(a, v);
   K4SamFields f;
-  f.pos = h.match_loci + 1;
-  f.len = h.match_len;
   const uint32_t rl = a.lens[i];
-  int mq = (int)(254 * ((double)h.match_len / (double)rl));
+  const bool two = !a.pe && a.seg2 && k4d_two_segs(h);
+  const k4_seg2 s2 = k4d_sam_seg2(a, i, h);
+  const uint32_t tl = K4_HIT_TRIM_LEFT(h), tr = K4_HIT_TRIM_RIGHT(h);
+  const uint32_t len0 = k4d_adj_len0(h), len1 = two ? s2.match_len : 0u;
+  f.pos = k4d_adj_start(h) + 1;
+  f.n_ops = 0;
+  const uint32_t lead = h.strand == '+' ? tl : tr, trail = h.strand == '+' ? tr : tl;
+  if (lead) { f.op_len[f.n_ops] = lead; f.op[f.n_ops++] = 'S'; }
+  f.op_len[f.n_ops] = len0; f.op[f.n_ops++] = 'M';
+  if (trail) { f.op_len[f.n_ops] = trail; f.op[f.n_ops++] = 'S'; }
+  int mq0 = 254;
+  if (two) {
+    const int gap_t = (int)s2.match_loci - (int)(h.match_loci + h.match_len);
+    if (h.ext & K4_EXT_SPLICE) { mq0 -= 20; f.op_len[f.n_ops] = (uint32_t)gap_t; f.op[f.n_ops++] = 'N'; }
+    else {
+      mq0 -= 10;
+      if (h.ext & K4_EXT_INSERT) { f.op_len[f.n_ops] = rl - ((uint32_t)h.match_len + s2.match_len); f.op[f.n_ops++] = 'I'; }
+      else { f.op_len[f.n_ops] = (uint32_t)(gap_t < 0 ? -gap_t : gap_t); f.op[f.n_ops++] = 'D'; }
+    }
+    f.op_len[f.n_ops] = len1; f.op[f.n_ops++] = 'M';
+  }
+  int mq = (int)(mq0 * ((double)(len0 + len1) / (double)rl));
   mq = mq < 1 ? 1 : mq > 254 ? 254 : mq;
   f.mapq = (uint32_t)mq;
   f.pnext = 0;
@@ -494,9 +526,9 @@ K4_DEV K4SamFields k4d_sam_fields(const K4SamArgs& a, int64_t v, const k4_hit& h
   if (me.pe_aligned && mt.pe_aligned && mt.nar == K4_NAR_ACCEPTED) {
     if (mt.hit.strand != '+') f.flag |= 0x20u;
     f.mate_eq = true;
-    f.pnext = mt.hit.match_loci + 1;
-    const int64_t s = h.match_loci, e = mt.hit.match_loci;
-    f.tlen = (int32_t)(s <= e ? (e - s) + mt.hit.match_len : (s - e) + h.match_len);
+    f.pnext = k4d_adj_start(mt.hit) + 1;
+    const int64_t s = k4d_adj_start(h), e = k4d_adj_start(mt.hit);
+    f.tlen = (int32_t)(s <= e ? (e - s) + k4d_adj_len0(mt.hit) : (s - e) + len0);
   } else
     f.flag |= 0x8u;
   return f;
@@ -521,14 +553,18 @@ struct IsAccepted {
 __global__ void __launch_bounds__(256) k4k_sam_key_minor(K4SamArgs a, const uint32_t* __restrict__ idx, uint64_t m, uint32_t* __restrict__ key) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
-  const k4_hit h = k4d_sam_hit(a, idx[j]);
-  key[j] = ((uint32_t)h.match_len << 16) | ((uint32_t)h.strand << 8) | h.mismatches;
+  const int64_t v = idx[j];
+  const k4_hit h = k4d_sam_hit(a, v);
+  // AdjHitLen(Seg[0]), Strand, then the READ's LowMMCnt (both segments' mismatches for a two-segment hit)
+  const int64_t i = k4d_sam_read(a, v);
+  const uint32_t mm = a.pe ? h.mismatches : (k4d_two_segs(h) ? (uint32_t)a.rr[i].low_mm & 0xFFu : h.mismatches);
+  key[j] = (k4d_adj_len0(h) << 16) | ((uint32_t)h.strand << 8) | mm;
 }
 __global__ void __launch_bounds__(256) k4k_sam_key_major(K4SamArgs a, const uint32_t* __restrict__ idx, uint64_t m, uint64_t* __restrict__ key) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
   const k4_hit h = k4d_sam_hit(a, idx[j]);
-  key[j] = ((uint64_t)h.chrom_id << 32) | h.match_loci;
+  key[j] = ((uint64_t)h.chrom_id << 32) | k4d_adj_start(h);
 }
 
 // statistics over every read (ReportAlignStats, KAligner.cpp:3600-3830): NAR histogram [0..20), '+' [20], '-' [21]
@@ -562,7 +598,8 @@ K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t v) {
   const int w = a.pe ? (int)(i & 1) : 0;
   const int64_t rec = a.pe ? (i >> 1) : i;
   uint32_t n = a.name_len[w][rec] + 1 + k4d_udigits(f.flag) + 1 + a.cname_len[h.chrom_id - 1] + 1 + k4d_udigits(f.pos) + 1 +
-               k4d_udigits(f.mapq) + 1 + k4d_udigits(f.len) + 1 /*M*/ + 1 + 1 /*RNEXT*/ + 1 + k4d_udigits(f.pnext) + 1;
+               k4d_udigits(f.mapq) + 1 + 1 + 1 /*RNEXT*/ + 1 + k4d_udigits(f.pnext) + 1;
+  for (uint32_t q = 0; q < f.n_ops; q++) n += k4d_udigits(f.op_len[q]) + 1;
   n += (f.tlen < 0 ? 1 : 0) + k4d_udigits((uint32_t)(f.tlen < 0 ? -(int64_t)f.tlen : f.tlen)) + 1;
   n += a.lens[i] + 1 + 1 /* '*' */ + 1 /* '\n' */;
   return n;
@@ -607,7 +644,8 @@ K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int
     p += cl;
     *p++ = '\t'; p += k4d_put_uint(p, f.pos);
     *p++ = '\t'; p += k4d_put_uint(p, f.mapq);
-    *p++ = '\t'; p += k4d_put_uint(p, f.len); *p++ = 'M';
+    *p++ = '\t';
+    for (uint32_t q = 0; q < f.n_ops; q++) { p += k4d_put_uint(p, f.op_len[q]); *p++ = f.op[q]; }
     *p++ = '\t'; *p++ = f.mate_eq ? '=' : '*';
     *p++ = '\t'; p += k4d_put_uint(p, f.pnext);
     *p++ = '\t';
@@ -740,6 +778,13 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
                                  const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens,
                                  const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
                                  uint8_t* chrom_hit, void* stream) {
+  return k4_format_sam_ext_dev(ix, pe, n_units, d_rr, d_hits, max_ml, d_pe, nullptr, d_reads, d_offs, d_lens, names, d_sam, sam_bytes,
+                               stats, chrom_hit, stream);
+}
+extern "C" int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                                     const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
+                                     const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
+                                     k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
   if (!ix || !names || !d_sam || !sam_bytes) return K4_ERR_PARAMS;
   *d_sam = nullptr;
   *sam_bytes = 0;
@@ -774,7 +819,7 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
   K4SamArgs a;
   memset(&a, 0, sizeof(a));
   a.pe = pe ? 1 : 0; a.n_reads = n_reads; a.rr = (const k4_read_result*)d_rr; a.hits = (const k4_hit*)d_hits; a.max_ml = max_ml;
-  a.pr = (const k4_pe_read*)d_pe; a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
+  a.pr = (const k4_pe_read*)d_pe; a.seg2 = pe ? nullptr : (const k4_seg2*)d_seg2; a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
   for (int w = 0; w < 2; w++) {
     a.text[w] = (const uint8_t*)names->d_text[w]; a.name_off[w] = (const uint64_t*)names->d_name_off[w];
     a.name_len[w] = (const uint32_t*)names->d_name_len[w];

@@ -10,7 +10,7 @@
 //   statistics           CKAligner::ReportAlignStats :3600-3830 (NAR histogram, strand counts)
 //   SAM                  CKAligner::WriteBAMReadHits :5718-5914, ReportBAMread :5957-6320, SortHitMatch :10969,
 //                        CSAMfile::AddAlignment libkit4b/SAMfile.cpp:2194-2377 -> k4_format_sam_dev; header :1615,1667-1669,1799
-// Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R -X -N (plus -g <gpu>, -S <i/N> read slice).
+// Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R -X -N -c -a -A -x (plus -g <gpu>, -S <i/N> read slice).
 #include <zlib.h>
 #include <algorithm>
 #include <chrono>
@@ -33,6 +33,7 @@ struct Opts {
   int min_len = 50, max_len = 500;  // cDfltMinAcceptReadLen / cDfltMaxAcceptReadLen, KAligner.h:112-113
   int ml_mode = 0, max_multi = 0;   // -r / -R (etMLMode, KAligner.h:250-258)
   bool clamp = false, best = false; // -X / -N (KAlignerCL.cpp:278-280)
+  int min_chimeric = 0, micro_indel = 0, splice_junct = 0, min_flank_exacts = 0;  // -c / -a / -A / -x (KAlignerCL.cpp:237,245,246,267)
   double batch_mb = 0;              // -b <MB>: stream the input, this much text per file per batch (0: the whole input at once)
   int shard = 0, n_shards = 1;      // -S i/N: this process aligns the i-th of N contiguous slices of the reads (one process per GPU)
   int gpu = 0;
@@ -145,7 +146,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-S i/N] [-b MB per batch] [-g gpu=0]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-S i/N] [-b MB per batch] [-g gpu=0]\n");
 }
 
 }  // namespace
@@ -198,6 +199,10 @@ int main(int argc, char** argv) {
       case 'L': o.max_len = atoi(val().c_str()); break;
       case 'r': o.ml_mode = atoi(val().c_str()); break;
       case 'R': o.max_multi = atoi(val().c_str()); break;
+      case 'c': o.min_chimeric = atoi(val().c_str()); break;
+      case 'a': o.micro_indel = atoi(val().c_str()); break;
+      case 'A': o.splice_junct = atoi(val().c_str()); break;
+      case 'x': o.min_flank_exacts = atoi(val().c_str()); break;
       case 'X': o.clamp = true; break;
       case 'N': o.best = true; break;
       case 'S': { std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2) { usage(); return 1; } break; }
@@ -221,6 +226,19 @@ int main(int argc, char** argv) {
     const int lim = o.ml_mode == 5 ? 100000 : 500;  // cMaxAllHits / cMaxMultiHits
     if (max_ml < 2 || max_ml > lim) { fprintf(stderr, "k4align: -R%d outside of range 2..%d\n", max_ml, lim); return 1; }
   }
+  // the optional AlignReads phases and the stages they bring with them: the same argument rules as kalign (KAlignerCL.cpp:545-569,
+  // 667-761,823-830)
+  o.min_chimeric = abs(o.min_chimeric);
+  if (o.min_chimeric != 0 && (o.min_chimeric < 15 || o.min_chimeric > 99)) { fprintf(stderr, "k4align: minimum chimeric length percentage '-c%d' specified outside of range 15..99\n", o.min_chimeric); return 1; }
+  if (o.micro_indel < 0 || o.micro_indel > 20) { fprintf(stderr, "k4align: microInDel length maximum '-a%d' specified outside of range 0..20\n", o.micro_indel); return 1; }
+  if (o.splice_junct != 0 && (o.splice_junct < 25 || o.splice_junct > 100000)) { fprintf(stderr, "k4align: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000\n", o.splice_junct); return 1; }
+  if (o.min_flank_exacts < 0 || o.min_flank_exacts > 7) { fprintf(stderr, "k4align: max flank trimming '-x%d' specified outside of range 0..7\n", o.min_flank_exacts); return 1; }
+  if (pe && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDel '-a' / splice junction '-A' processing not supported in paired end processing\n"); return 1; }
+  if (pe && o.min_chimeric) { fprintf(stderr, "k4align: chimeric trimming '-c' is not supported in paired end processing yet (the mate rescue's trimmed branch, SfxArray.cpp:8616-8766)\n"); return 3; }
+  if (o.ml_mode == 5 && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDels / splice junctions not supported when reporting multiloci alignments '-r5'\n"); return 1; }
+  if (o.min_chimeric && (o.best || o.ml_mode == 3 || o.ml_mode == 4)) { fprintf(stderr, "k4align: chimeric read processing cannot be combined with -N / -r3 / -r4\n"); return 1; }
+  if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830
+  if (o.min_flank_exacts > 7) o.min_flank_exacts = 7;
   if (pe && o.pe_mode == 0) o.pe_mode = 1;  // kalign: -u without -U defaults to orphan recovery
   if (!pe) o.pe_mode = 0;
 
@@ -243,9 +261,14 @@ int main(int argc, char** argv) {
     return 1;
   }
   if (o.batch_mb > 0 && o.n_shards > 1) { fprintf(stderr, "k4align: -S slices the whole input; it cannot be combined with -b\n"); return 1; }
+  if ((o.micro_indel || o.splice_junct) && (o.batch_mb > 0 || o.n_shards > 1)) {
+    fprintf(stderr, "k4align: -a / -A drop junctions no second read of the RUN supports; they cannot be combined with -b or -S\n");
+    return 1;
+  }
   k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, max_ml,
                          o.ml_mode == 5 ? (o.best ? 4 : o.clamp ? 3 : 2) : o.ml_mode == 2 ? 2 : o.ml_mode != 0 ? 1 : 0,
-                         mcl, slides};
+                         mcl, slides, o.min_chimeric, o.micro_indel, o.splice_junct};
+  const bool two_seg = o.micro_indel > 0 || o.splice_junct > 0;
   k4_pe_params pp = {o.pe_mode, o.pair_min, o.pair_max, o.pair_strand};
   k4_sam_stats tot;
   memset(&tot, 0, sizeof(tot));
@@ -301,13 +324,14 @@ int main(int argc, char** argv) {
                             &under, &over, &max_len, nullptr));
     auto tb = now();
     // ---- align (ProcCoredApprox / ProcessPairedEnds) ---------------------------------------------------------------
-    void *d_rr = nullptr, *d_hits = nullptr, *d_pe = nullptr;
+    void *d_rr = nullptr, *d_hits = nullptr, *d_pe = nullptr, *d_seg2 = nullptr;
     if (n > 0 && max_len > 0) {
       if (!pe) {
         CK(k4_alloc_device(ix, (uint64_t)n * sizeof(k4_read_result), &d_rr));
         CK(k4_alloc_device(ix, (uint64_t)n * max_ml * sizeof(k4_hit), &d_hits));
+        if (two_seg) CK(k4_alloc_device(ix, (uint64_t)n * sizeof(k4_seg2), &d_seg2));
         CK(k4_reserve(ix, n, (int32_t)max_len, max_ml));
-        CK(k4_kalign_batch_dev(ix, &kp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_rr, d_hits, nullptr));
+        CK(k4_kalign_ext_batch_dev(ix, &kp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_rr, d_hits, d_seg2, nullptr));
         if (o.ml_mode == 3 || o.ml_mode == 4) {  // AssignMultiMatches (KAligner.cpp:5092): clusters over all reads of the run
           int64_t n_assigned = 0;
           CK(k4_assign_multi_dev(ix, o.ml_mode, (int32_t)max_len, n, max_ml, d_rr, d_hits, &n_assigned, nullptr));
@@ -332,6 +356,21 @@ int main(int argc, char** argv) {
         CK(k4_alloc_device(ix, (uint64_t)2 * n * sizeof(k4_pe_read), &d_pe));
         CK(k4_kalign_pe_batch_dev(ix, &kp, &pp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_pe, nullptr));
       }
+      // the filters between alignment and report, in CKAligner::Align's order (KAligner.cpp:653-686)
+      int64_t cnt = 0;
+      if (o.min_flank_exacts > 0) {
+        CK(k4_auto_trim_flanks_dev(ix, o.min_flank_exacts, pe ? 1 : 0, pe ? 2 * n : n, max_ml, pe ? d_pe : d_rr, d_hits, d_reads, d_offs,
+                                   d_lens, &cnt, nullptr));
+        fprintf(stderr, "k4align: flank autotrim to %d exact bases: %lld aligned reads removed\n", o.min_flank_exacts, (long long)cnt);
+      }
+      if (!pe && o.splice_junct > 0) {
+        CK(k4_remove_orphan_juncts_dev(ix, K4_EXT_SPLICE, n, max_ml, d_rr, d_hits, d_seg2, &cnt, nullptr));
+        fprintf(stderr, "k4align: %lld orphan splice junction reads removed\n", (long long)cnt);
+      }
+      if (!pe && o.micro_indel > 0) {
+        CK(k4_remove_orphan_juncts_dev(ix, K4_EXT_INDEL, n, max_ml, d_rr, d_hits, d_seg2, &cnt, nullptr));
+        fprintf(stderr, "k4align: %lld orphan microInDel reads removed\n", (long long)cnt);
+      }
     }
     // ---- SAM body on the device (k4_format_sam_dev) ------------------------------------------------------------------
     k4_sam_names nm;
@@ -344,8 +383,8 @@ int main(int argc, char** argv) {
     memset(&stt, 0, sizeof(stt));
     std::vector<uint8_t> hc(info.n_entries + 1, 0);
     if (n > 0 && max_len > 0)
-      CK(k4_format_sam_dev(ix, pe ? 1 : 0, n, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, &nm, &d_sam, &sam_bytes, &stt,
-                           hc.data(), nullptr));
+      CK(k4_format_sam_ext_dev(ix, pe ? 1 : 0, n, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, &nm, &d_sam, &sam_bytes,
+                               &stt, hc.data(), nullptr));
     auto tc = now();
     for (int k = 0; k < 20; k++) tot.nar[k] += stt.nar[k];
     tot.plus += stt.plus; tot.minus += stt.minus; tot.n_lines += stt.n_lines;
@@ -363,7 +402,7 @@ int main(int argc, char** argv) {
       keep_sam = d_sam;
       keep_bytes = sam_bytes;
     }
-    for (void* q : {d_reads, d_offs, d_lens, d_rr, d_hits, d_pe, a1.d_text, a1.d_offs, a1.d_lens, a1.d_noff, a1.d_nlen, a2.d_text,
+    for (void* q : {d_reads, d_offs, d_lens, d_rr, d_hits, d_pe, d_seg2, a1.d_text, a1.d_offs, a1.d_lens, a1.d_noff, a1.d_nlen, a2.d_text,
                     a2.d_offs, a2.d_lens, a2.d_noff, a2.d_nlen})
       k4_free_device(q);
     auto td = now();

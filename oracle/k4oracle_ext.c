@@ -837,13 +837,17 @@ int k4o_align_reads_ext(const k4o_index* ix, const k4o_ext_params* ext, int tot_
     if (rslt != 0) return rslt;
   }
   if (ext->min_chimeric_len > 0) { /* :7923-7930 */
-    /* whatever the two phases above left in slot 0 is no hit of this read (they returned eHRnone) */
-    memset(seg2, 0, sizeof(*seg2));
     if (max_slides <= 1) return ERR_PARAMS; /* the reference divides by MaxNumCoreSlides-1 */
     const int cl = IMAX(min_core_len, probe_len / (tot_mm + 4));
     const int cd = IMAX(probe_len / (max_slides - 1), cl);
-    return k4o_locate_core_multiples_chimeric(ix, ext->min_chimeric_len, tot_mm, cl, cd, max_slides, mm_delta, strand, inst, low,
+    rslt = k4o_locate_core_multiples_chimeric(ix, ext->min_chimeric_len, tot_mm, cl, cd, max_slides, mm_delta, strand, inst, low,
                                               nxt, probe, probe_len, max_hits, hits, ctr);
+    /* Slot 0 may still hold what the last two-segment phase left there when it gave up over too many equally good loci:
+     * that phase's instance count is carried in, and with more than MaxHits exact instances this pass returns
+     * eHRHitInsts at once (:5890) without touching the slot.  Whenever the pass does store a hit it clears both segments
+     * first (:6129), so the second segment is gone unless slot 0 still is that two-segment record. */
+    if (!(hits[0].ext & (K4O_EXT_INDEL | K4O_EXT_SPLICE))) memset(seg2, 0, sizeof(*seg2));
+    return rslt;
   }
   return 0;
 }

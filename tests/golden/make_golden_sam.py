@@ -16,6 +16,7 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
 import synth  # noqa: E402
 
 NGS = os.path.join(ROOT, "oracle", "_ref", "ngskit4b")
@@ -39,6 +40,23 @@ CASES = {
 CLUSTER_CASES = {
     "se_r3_R8": ["-s2", "-r3", "-R8"],
     "se_r4_R8": ["-s2", "-r4", "-R8"],
+}
+# the optional AlignReads phases and the stages kalign runs with them, on the g3 genome of make_golden_ext.py
+# (planted introns): -c chimeric trimming (soft clips), -a microInDels (I / D, orphan filter), -A splice junctions (N, flank
+# autotrim to -s exact bases, orphan filter), -x flank autotrim alone
+EXT_CASES = {
+    "se_c50": (["-s2", "-c50"], lambda ch, sites: synth.make_reads(ch, 500, 100, seed=5001, n_prob=0.02, edge_frac=0.05)[0]
+               + synth.make_ext_reads(ch, 900, 100, "chimeric", seed=5002, max_subs=2)),
+    "se_a12": (["-s2", "-a12"], lambda ch, sites: synth.make_reads(ch, 500, 100, seed=5003, n_prob=0.02)[0]
+               + synth.make_variant_reads(ch, 60, 8, 100, "indel", seed=5004) + synth.make_ext_reads(ch, 150, 100, "indel", seed=5005)),
+    "se_A3000": (["-s2", "-A3000"], lambda ch, sites: synth.make_reads(ch, 500, 100, seed=5006, n_prob=0.02, sub_lambda=1.5)[0]
+                 + synth.make_variant_reads(ch, 45, 8, 100, "splice", seed=5007, sites=sites)
+                 + synth.make_ext_reads(ch, 100, 100, "splice", seed=5008, sites=sites[45:])),
+    "se_all_120": (["-s3", "-c60", "-a10", "-A2500"], lambda ch, sites: synth.make_reads(ch, 300, 120, seed=5009)[0]
+                   + synth.make_ext_reads(ch, 400, 120, "chimeric", seed=5010, max_subs=3)
+                   + synth.make_variant_reads(ch, 40, 6, 120, "indel", seed=5011)
+                   + synth.make_variant_reads(ch, 40, 6, 120, "splice", seed=5012, sites=sites)),
+    "se_x4": (["-s4", "-x4"], lambda ch, sites: synth.make_reads(ch, 1500, 100, seed=5013, sub_lambda=3.0, n_prob=0.02, edge_frac=0.05)[0]),
 }
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # case names: regenerate just these (others keep their files)
 PE_CASES = {
@@ -93,6 +111,23 @@ def main():
             for name, args in CLUSTER_CASES.items():
                 hist = run(tmp, name, args, ["-i", fa], sfx=g2)
                 meta[name] = dict(args=args, nar=hist, index="g2", reads="sam_se_cluster.fa.xz")
+                print(name, hist)
+        if not ONLY or any(c in ONLY for c in EXT_CASES):
+            import make_golden_ext
+
+            names3, chroms3, sites3, _ = make_golden_ext.genome()
+            g3 = os.path.join(tmp, "g3.sfx")
+            with lzma.open(os.path.join(HERE, "g3.sfx.xz"), "rb") as f, open(g3, "wb") as g:
+                g.write(f.read())
+            for name, (args, gen) in EXT_CASES.items():
+                if ONLY and name not in ONLY:
+                    continue
+                fa = os.path.join(tmp, name + ".fa")
+                synth.write_fasta(fa, gen(chroms3, sites3))
+                hist = run(tmp, name, args, ["-i", fa], sfx=g3)
+                with open(fa, "rb") as f, lzma.open(os.path.join(HERE, "sam_%s.fa.xz" % name), "wb", preset=9) as g:
+                    g.write(f.read())
+                meta[name] = dict(args=args, nar=hist, index="g3")
                 print(name, hist)
         for name, (args, kw) in PE_CASES.items():
             if ONLY and name not in ONLY:

@@ -245,3 +245,32 @@ def make_ext_reads(chroms, n_reads, read_len, kind, seed=91, sites=None, max_sub
             r = revcomp(r)
         reads.append(r.astype(np.uint8))
     return reads
+
+
+def make_variant_reads(chroms, n_events, reads_per_event, read_len, kind, seed=191, sites=None, max_subs=1):
+    """Several reads over the SAME microInDel ('indel': a donor genome that lacks 1..20 reference bases or carries 1..20 extra
+    ones at n_events positions) or the same intron ('splice': the first n_events of `sites`), at random offsets, strands and
+    with 0..max_subs substitutions -- what survives kalign's orphan-junction filters."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for ev in range(n_events):
+        if kind == "splice":
+            c, d, gap = sites[ev % len(sites)]
+            ins = None
+        else:
+            c = int(rng.integers(0, len(chroms)))
+            d = int(rng.integers(read_len + 30, len(chroms[c]) - read_len - 60))
+            gap = int(rng.integers(1, 21))
+            ins = rng.integers(0, 4, gap).astype(np.uint8) if rng.random() < 0.5 else None
+        g = chroms[c]
+        for _ in range(reads_per_event):
+            left = int(rng.integers(12, read_len - 12 - (gap if ins is not None else 0)))
+            if ins is not None:
+                r = np.concatenate([g[d - left:d], ins, g[d:d + read_len - left - gap]])
+            else:
+                r = np.concatenate([g[d - left:d], g[d + gap:d + gap + read_len - left]])
+            if len(r) != read_len or (r > 3).any():
+                continue
+            r = _mutate(r.copy(), rng, int(rng.integers(0, max_subs + 1)))
+            reads.append(revcomp(r) if rng.random() < 0.5 else r.astype(np.uint8))
+    return reads

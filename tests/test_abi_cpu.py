@@ -24,12 +24,13 @@ def test_header_symbols_all_exported(L):
     assert declared == set(kit4b_amd.ABI_SYMBOLS), declared ^ set(kit4b_amd.ABI_SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.k4_abi_version() == 1
+    assert L.k4_abi_version() == 2
 
 
 def test_struct_sizes_match_header():
-    assert C.sizeof(kit4b_amd.AlignParams) == 32
-    assert C.sizeof(kit4b_amd.KalignParams) == 36
+    assert C.sizeof(kit4b_amd.AlignParams) == 44  # ABI 2: + MinChimericLen, microInDelLen, MaxSpliceJunctLen
+    assert C.sizeof(kit4b_amd.KalignParams) == 48
+    assert kit4b_amd.SEG2_DTYPE.itemsize == 16
     assert kit4b_amd.HIT_DTYPE.itemsize == 16
     assert kit4b_amd.RESULT_DTYPE.itemsize == 24
     assert C.sizeof(kit4b_amd.Counters) == 48
