@@ -340,13 +340,13 @@ def _unxz(src, dst):
 
 
 @pytest.mark.parametrize("case", sorted(SAM_CASES))
-def test_k4align_writes_the_reference_sam(k4, golden_dir, g2_path, tmp_path, case):
+def test_k4align_writes_the_reference_sam(k4, golden_dir, g2_path, g3_path, tmp_path, case):
     """`k4align` (C++ over the C ABI) against the SAM `ngskit4b kalign` wrote for the same reads, index and options:
     identical header (but @PG) and identical records (the reference's order among equal keys is unspecified)."""
     exe = os.path.join(ROOT, "kit4b_amd", "k4align")
     assert os.path.exists(exe)
     out = str(tmp_path / "out.sam")
-    sfx = g2_path if SAM_CASES[case].get("index") == "g2" else os.path.join(golden_dir, "g1.sfx")
+    sfx = {"g2": g2_path, "g3": g3_path}.get(SAM_CASES[case].get("index"), os.path.join(golden_dir, "g1.sfx"))
     cmd = [exe, "-I", sfx, "-o", out] + SAM_CASES[case]["args"]
     if case.startswith("se_"):
         cmd += ["-i", _unxz(os.path.join(golden_dir, SAM_CASES[case].get("reads", "sam_%s.fa.xz" % case)), str(tmp_path / "r.fa"))]

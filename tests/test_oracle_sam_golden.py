@@ -11,7 +11,8 @@ from oracle_bindings import oracle_kalign_pe
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = json.load(open(os.path.join(GOLDEN, "sam_cases.json")))
-NAR_CODE = {"AA": 1, "EN": 2, "NL": 3, "MH": 4, "ML": 5, "UI": 13, "OI": 14, "UP": 15, "IS": 16, "IT": 17, "NP": 18}
+NAR_CODE = {"AA": 1, "EN": 2, "NL": 3, "MH": 4, "ML": 5, "ET": 6, "OJ": 7, "OM": 8, "UI": 13, "OI": 14, "UP": 15, "IS": 16, "IT": 17,
+            "NP": 18}
 CHROMS = ["chr1", "chr2", "chr3", "chr4", "chr5"]
 
 
@@ -31,7 +32,32 @@ def kalign_args(args):
         elif a in ("-r3", "-r4"): kw["pe_mode"] = 1                     # eMLuniq / eMLmulti: multi-aligned reads keep their loci
         elif a == "-X": kw["pe_mode"] = max(kw.get("pe_mode", 0), 3)   # ... reads over the -R limit clamped to it
         elif a == "-N": kw["pe_mode"] = 4                               # ... through LocateBestMatches
+        elif a.startswith("-c"): kw["min_chimeric_len"] = int(a[2:])    # the optional AlignReads phases
+        elif a.startswith("-a"): kw["micro_indel_len"] = int(a[2:])
+        elif a.startswith("-A"): kw["max_splice_junct_len"] = int(a[2:])
+        elif a.startswith("-x"): pe["min_flank_exacts"] = int(a[2:])
+    # `-A` without `-c` / `-x` forces the flank autotrim to -s exact bases (KAlignerCL.cpp:829-830)
+    if kw.get("max_splice_junct_len") and not kw.get("min_chimeric_len") and not pe.get("min_flank_exacts"):
+        pe["min_flank_exacts"] = kw["max_subs"]
     return kw, pe
+
+
+def ext_case(args):
+    return any(a[:2] in ("-c", "-a", "-A", "-x") for a in args)
+
+
+def oracle_se_ext(oracle, h, reads, kw, post):
+    """CKAligner::AlignRead with -c / -a / -A, then the filters of CKAligner::Align (KAligner.cpp:653-686)"""
+    from oracle_bindings import EXT_INDEL, EXT_SPLICE
+
+    r = oracle.kalign_ext_batch(h, reads, **kw)
+    if post.get("min_flank_exacts"):
+        oracle.auto_trim_flanks(h, reads, r["out"], r["hits"], r["seg2"], post["min_flank_exacts"])
+    if kw.get("max_splice_junct_len"):
+        oracle.remove_orphan_juncts(EXT_SPLICE, r["out"], r["hits"], r["seg2"])
+    if kw.get("micro_indel_len"):
+        oracle.remove_orphan_juncts(EXT_INDEL, r["out"], r["hits"], r["seg2"])
+    return r
 
 
 def pick_rand_hits(out, hits):
@@ -64,7 +90,29 @@ def check_hist(nars, expect):
         assert got[code] == expect.get(name, 0), (name, got[code], expect.get(name, 0))
 
 
-@pytest.mark.parametrize("case", sorted(c for c in CASES if c.startswith("se_")))
+@pytest.mark.parametrize("case", sorted(c for c in CASES if c.startswith("se_") and ext_case(CASES[c]["args"])))
+def test_se_ext_matches_reference_sam(oracle, golden_dir, g3_path, case):
+    """kalign -c / -a / -A / -x: soft-clipped, I / D / N CIGARs, scaled MAPQ, orphan filters, flank autotrim"""
+    kw, post = kalign_args(CASES[case]["args"])
+    names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % case))
+    h = oracle.open(g3_path)
+    oracle.set_max_iter(h, 5000)
+    r = oracle_se_ext(oracle, h, reads, kw, post)
+    check_hist(r["out"]["nar"], CASES[case]["nar"])
+    res = [dict(nar=int(o["nar"]), hit=hh[0], pe_aligned=0, seg2=s2) for o, hh, s2 in zip(r["out"], r["hits"], r["seg2"])]
+    _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    assert sorted(samutil.sam_records(names, reads, res, ["chr1", "chr2", "chr3"])) == sorted(recs)
+    cig = [l.split("\t")[5] for l in recs]
+    if kw.get("min_chimeric_len"):
+        assert sum("S" in c for c in cig) > 50
+    if kw.get("micro_indel_len"):
+        assert sum("I" in c for c in cig) > 20 and sum("D" in c for c in cig) > 20
+    if kw.get("max_splice_junct_len"):
+        assert sum("N" in c for c in cig) > 50
+    oracle.close(h)
+
+
+@pytest.mark.parametrize("case", sorted(c for c in CASES if c.startswith("se_") and not ext_case(CASES[c]["args"])))
 def test_se_matches_reference_sam(oracle, golden_dir, g2_path, case):
     kw, _ = kalign_args(CASES[case]["args"])
     names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, CASES[case].get("reads", "sam_%s.fa.xz" % case)))
