@@ -88,6 +88,7 @@ class CSfxArray {
     uint32_t len;
     int32_t rslt, inst, low, nxt, rc;
     std::vector<k4_hit> hits;
+    k4_seg2 seg2;  // the second segment of a microInDel / splice-junction hit (slot 0)
     bool done;
   };
   std::mutex m_QMtx;
@@ -109,15 +110,17 @@ class CSfxArray {
     const int mh = g[0]->p.max_hits;
     std::vector<int32_t> r(4 * n);
     std::vector<k4_hit> h(n * (size_t)mh);
+    std::vector<k4_seg2> s2(n);
     int rc;
     {
       std::lock_guard<std::mutex> dev(m_Mtx);
-      rc = k4_align_reads_batch(m_pIdx, &g[0]->p, (int64_t)n, cat.data(), offs.data(), lens.data(), r.data(), r.data() + n,
-                                r.data() + 2 * n, r.data() + 3 * n, h.data());
+      rc = k4_align_reads_ext_batch(m_pIdx, &g[0]->p, (int64_t)n, cat.data(), offs.data(), lens.data(), r.data(), r.data() + n,
+                                    r.data() + 2 * n, r.data() + 3 * n, h.data(), s2.data());
       if (rc != K4_OK) Fail(rc);
     }
     for (size_t i = 0; i < n; i++) {
       Req* q = g[i];
+      q->seg2 = s2[i];
       q->rc = rc; q->rslt = r[i]; q->inst = r[n + i]; q->low = r[2 * n + i]; q->nxt = r[3 * n + i];
       q->hits.assign(h.begin() + (ptrdiff_t)(i * mh), h.begin() + (ptrdiff_t)((i + 1) * mh));
     }
@@ -169,15 +172,34 @@ class CSfxArray {
     m_Errs.push_back(m ? m : "");
     return rc;
   }
-  static void Expand(const k4_hit& h, tsHitLoci* p) {  // what LocateCoreMultiples stores, SfxArray.cpp:6264-6307
+  // the flat records -> tsHitLoci as LocateCoreMultiples (SfxArray.cpp:6264-6307, chimeric :6123-6146), LocateInDels
+  // (:7800-7825) and LocateSpliceJuncts (:7501-7516) leave it
+  static void Expand(const k4_hit& h, tsHitLoci* p, const k4_seg2* s2 = nullptr) {
     std::memset(p, 0, sizeof(*p));
     p->BisBase = eBaseN;
+    p->FlgChimeric = (h.ext & K4_EXT_CHIMERIC) ? 1 : 0;
+    p->FlgInDel = (h.ext & K4_EXT_INDEL) ? 1 : 0;
+    p->FlgInsert = (h.ext & K4_EXT_INSERT) ? 1 : 0;
+    p->FlgSplice = (h.ext & K4_EXT_SPLICE) ? 1 : 0;
+    p->FlgNonOrphan = (h.ext & K4_EXT_NONORPHAN) ? 1 : 0;
     p->Seg[0].Strand = h.strand;
     p->Seg[0].ChromID = h.chrom_id;
     p->Seg[0].MatchLoci = h.match_loci;
     p->Seg[0].MatchLen = h.match_len;
     p->Seg[0].Mismatches = h.mismatches;
     p->Seg[0].TrimMismatches = h.mismatches;
+    p->Seg[0].TrimLeft = (uint16_t)K4_HIT_TRIM_LEFT(h);
+    p->Seg[0].TrimRight = (uint16_t)K4_HIT_TRIM_RIGHT(h);
+    if (s2 && (h.ext & (K4_EXT_INDEL | K4_EXT_SPLICE))) {
+      p->Score = s2->score;
+      p->Seg[1].ReadOfs = s2->read_ofs;
+      p->Seg[1].Strand = h.strand;
+      p->Seg[1].ChromID = s2->chrom_id;
+      p->Seg[1].MatchLoci = s2->match_loci;
+      p->Seg[1].MatchLen = s2->match_len;
+      p->Seg[1].Mismatches = s2->mismatches;
+      p->Seg[1].TrimMismatches = s2->mismatches;
+    }
   }
 
  public:
@@ -296,10 +318,6 @@ class CSfxArray {
                  int ProbeLen, int MaxHits, tsHitLoci* pHits, int NumAllocdIdentNodes, tsIdentNode* pAllocsIdentNodes) {
     (void)ExtdProcFlags; (void)ReadID; (void)NumAllocdIdentNodes; (void)pAllocsIdentNodes;
     if (!m_pIdx) return K4_ERR_INTERNAL;
-    if (MinChimericLen > 0 || microInDelLen > 0 || MaxSpliceJunctLen > 0) {
-      m_Errs.push_back("CSfxArray::AlignReads: chimeric / microInDel / splice phases are outside the accelerated path");
-      return K4_ERR_UNSUPPORTED;
-    }
     if (*pLowHitInstances > 0) {  // carried-in hits (never passed by CKAligner::AlignRead, KAligner.cpp:9609-9611)
       m_Errs.push_back("CSfxArray::AlignReads: carried-in LowHitInstances > 0 is not supported");
       return K4_ERR_UNSUPPORTED;
@@ -307,14 +325,18 @@ class CSfxArray {
     if (Align2Strand == eALSnone) return eHRnone;
     if (ProbeLen < 1 || MaxHits < 1) return K4_ERR_PARAMS;
     Req rq;
-    rq.p = k4_align_params{TotMM, CoreLen, CoreDelta, MaxNumCoreSlides, MinCoreLen, MMDelta, (int32_t)Align2Strand, MaxHits};
+    // MinChimericLen outside 15..99 means "no trimming" to LocateCoreMultiples (:5878-5883) but still runs its extra pass
+    rq.p = k4_align_params{TotMM, CoreLen, CoreDelta, MaxNumCoreSlides, MinCoreLen, MMDelta, (int32_t)Align2Strand, MaxHits,
+                           MinChimericLen > 0 ? MinChimericLen : 0, microInDelLen > 0 ? microInDelLen : 0,
+                           MaxSpliceJunctLen > 0 ? MaxSpliceJunctLen : 0};
+    std::memset(&rq.seg2, 0, sizeof(rq.seg2));
     rq.probe = pProbeSeq; rq.len = (uint32_t)ProbeLen;
     rq.rslt = rq.inst = rq.low = rq.nxt = 0; rq.rc = K4_OK; rq.done = false;
     Submit(rq);  // alone: a batch of one; with other threads calling at the same time: one batch for all of them
     if (rq.rc != K4_OK) return rq.rc;
     *pLowHitInstances = rq.inst; *pLowMMCnt = rq.low; *pNxtLowMMCnt = rq.nxt;
     int nvalid = (rq.rslt >= eHRhits && rq.rslt <= eHRHitInsts) ? (rq.inst < MaxHits ? rq.inst : MaxHits) : 0;
-    for (int i = 0; i < nvalid; i++) Expand(rq.hits[(size_t)i], &pHits[i]);
+    for (int i = 0; i < nvalid; i++) Expand(rq.hits[(size_t)i], &pHits[i], i == 0 ? &rq.seg2 : nullptr);
     return rq.rslt;
   }
 

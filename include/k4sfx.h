@@ -364,6 +364,45 @@ int k4_select_hits_dev(k4_index* ix, int64_t n_reads, int32_t max_ml, void* d_rr
  * max_reads_len: the longest read loaded (m_MaxReadsLen).  Waits for `stream`. */
 int k4_assign_multi_dev(k4_index* ix, int ml_mode, int32_t max_reads_len, int64_t n_reads, int32_t max_ml, void* d_rr,
                         void* d_hits, int64_t* n_assigned, void* stream);
+/* ---- the overlapped host <-> device pipeline (kit4b_amd/csrc/k4_pipeline.hip) ---------------------------
+ * <- the reference's loader thread running beside its aligner threads (CKAligner::InitiateLoadingReads / ProcLoadReadFiles,
+ *    KAligner.cpp:4786-4866,11323-11496; ThreadedIterReads :10370-10438) and its writer (WriteBAMReadHits :5718).
+ * Three HIP streams: the caller's reader thread(s) fill pinned ring buffers (k4_pipeline_acquire / _submit) whose contents go
+ * up on the copy stream while a worker thread of the library parses, filters and aligns the chunks that have already arrived
+ * on the compute stream; k4_pipeline_format then makes ONE coordinate-sorted SAM body over everything (identical to a single
+ * batch), which k4_pipeline_next_sam hands out piece by piece from a second pinned ring while the next pieces come down.
+ * One acquire, then one submit, per end at a time; `final` marks the last chunk of an end (bytes may be 0). */
+typedef struct k4_pipeline k4_pipeline;
+typedef struct {
+  int32_t paired;               /* 0: one input (SE), 1: two inputs, record i of end 0 pairs with record i of end 1 */
+  k4_kalign_params kp;          /* as for k4_kalign_ext_batch_dev / k4_kalign_pe_batch_dev (PE: max_ml 10, pe_mode 1) */
+  k4_pe_params pe;
+  int32_t min_len, max_len;     /* the length filter of LoadRawReads (k4_prepare_reads_dev) */
+  uint32_t n_buffers;           /* pinned buffers per end (0: 3) */
+  uint32_t min_batch_units;     /* reads / pairs that must have arrived before an alignment batch is launched (0: 2^20) */
+  uint64_t chunk_bytes;         /* size of one pinned buffer = one upload (0: 256 MiB) */
+  uint64_t expect_text_bytes[2];/* text per end, if known (file sizes): the HBM arena is sized once */
+} k4_pipeline_params;
+typedef struct {                /* where the aligned batch lives in HBM (for the global stages between alignment and report:
+                                 * k4_assign_multi_dev, k4_select_hits_dev, k4_auto_trim_flanks_dev, k4_remove_orphan_juncts_dev) */
+  int64_t n_units, n_reads;     /* reads (SE) / pairs (PE); reads through the SE pass */
+  uint32_t max_read_len;
+  int32_t max_ml;
+  uint64_t n_under, n_over;     /* sloughed by the length filter */
+  void *d_rr, *d_hits, *d_seg2, *d_pe, *d_reads, *d_offs, *d_lens;
+  k4_sam_names names;
+} k4_pipeline_view;
+int k4_pipeline_open(k4_index* ix, const k4_pipeline_params* p, k4_pipeline** out);
+int k4_pipeline_acquire(k4_pipeline* pl, int end, void** buf, uint64_t* cap); /* blocks while every buffer is on its way up */
+int k4_pipeline_submit(k4_pipeline* pl, int end, uint64_t bytes, int final_chunk);
+/* text in the caller's own memory (pinned for the full PCIe rate); it must stay valid until k4_pipeline_wait_aligned returns */
+int k4_pipeline_submit_host(k4_pipeline* pl, int end, const void* text, uint64_t bytes, int final_chunk);
+int k4_pipeline_wait_aligned(k4_pipeline* pl, k4_pipeline_view* view); /* after the final chunks: every read is aligned */
+int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit /* host, n_entries + 1, or NULL */, uint64_t* sam_bytes);
+int k4_pipeline_next_sam(k4_pipeline* pl, const void** ptr, uint64_t* bytes); /* valid until the next call; 0 bytes: done */
+int k4_pipeline_read_sam(k4_pipeline* pl, void* dst, uint64_t cap, uint64_t* bytes); /* the whole body into caller memory */
+void k4_pipeline_close(k4_pipeline* pl);
+
 void k4_free_device(void* p);
 /* device memory for host programs that use the *_dev entry points without a HIP runtime of their own */
 int k4_alloc_device(k4_index* ix, uint64_t bytes, void** d_ptr);

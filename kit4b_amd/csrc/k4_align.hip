@@ -1576,12 +1576,14 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
   if (max_reads >= 0xFFFFFFF0ll) return k4_fail(ix, K4_ERR_PARAMS, "at most 2^32-16 reads per batch");
   K4_HIP(ix, hipSetDevice(ix->device));
   K4Workspace& w = ix->ws;
+  bool touched = false;  // something was (re)allocated or filled on the null stream
   int fast_len = std::min<int>(max_read_len, K4_MAX_FAST_READ_LEN);
   if (max_reads > w.cap_reads || fast_len > w.cap_len) {
     int64_t cap = std::max<int64_t>(max_reads, w.cap_reads);
     cap = (cap + 255) / 256 * 256;
     int len = std::max(fast_len, w.cap_len);
     int nch = nch_for(len);
+    touched = true;
     // the capacities say what the pointers below can hold: zero while they are being replaced, so that a failed
     // allocation leaves a workspace every *_dev call refuses (K4_ERR_PARAMS) instead of one with null buffers
     w.cap_reads = 0;
@@ -1609,6 +1611,7 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
     w.cap_len = len;
   }
   if (!w.ctl) {
+    touched = true;
     K4_HIP(ix, hipMalloc(&w.ctl, K4_CTL_WORDS * 4));
     K4_HIP(ix, hipMemset(w.ctl, 0, K4_CTL_WORDS * 4));
   }
@@ -1617,6 +1620,7 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
   uint64_t nodes = ix->d.max_iter ? std::min<uint64_t>((uint64_t)ix->d.max_iter * 48, K4_MAX_IDENT_NODES) : K4_MAX_IDENT_NODES;
   uint32_t hcap = next_pow2(std::max<uint64_t>(2 * nodes + 2, 1024));
   if (!w.slow_hash || hcap > w.slow_hash_cap) {
+    touched = true;
     if (w.slow_hash) hipFree(w.slow_hash);
     w.slow_hash = nullptr;
     const size_t words = (size_t)K4_SLOW_WAVES * K4_SMALL_HASH + (size_t)K4_HUGE_WAVES * hcap;
@@ -1627,6 +1631,8 @@ extern "C" int k4_reserve(k4_index* ix, int64_t max_reads, int32_t max_read_len,
     w.slow_lanes = K4_SLOW_WAVES;
   }
   w.cap_hits = std::max(w.cap_hits, max_hits);
+  // (the fills above ran on the null stream: callers launch on streams of their own, possibly non-blocking ones)
+  if (touched) K4_HIP(ix, hipDeviceSynchronize());
   return K4_OK;
 }
 

@@ -43,11 +43,22 @@ int main(int argc, char** argv) {
       printf("\n");
     }
   }
-  // unsupported arguments are reported, not silently ignored
+  // the optional phases through the reference's own argument list (MinChimericLen 50 %): a read whose first 30 bases are
+  // foreign is placed with its 5' flank trimmed; a carried-in instance count is refused, not silently ignored
   int Inst = 0, Low = 0, Nxt = 0;
   tsHitLoci Hit;
-  Rslt = pSfx->AlignReads(0, 1, 50, 2, 33, 33, 8, 8, 1, eALSboth, 0, 0, &Inst, &Low, &Nxt, Probe.data(), 100, 1, &Hit, 16, Nodes);
-  printf("chimeric rslt %d msgs %d\n", Rslt, pSfx->NumErrMsgs());
+  {
+    if (pSfx->GetSeq(2, 5000, Probe.data(), 100) != 100) return 4;
+    std::vector<etSeqBase> P = Probe;
+    for (int q = 0; q < 30; q++) P[q] = (etSeqBase)((P[q] + 1 + q % 3) % 4);
+    Rslt = pSfx->AlignReads(0, 1, 50, 2, 33, 33, 8, 8, 1, eALSboth, 0, 0, &Inst, &Low, &Nxt, P.data(), 100, 1, &Hit, 16, Nodes);
+    printf("chimeric rslt %d inst %d flg %d loci %llu trimleft %u trimright %u msgs %d\n", Rslt, Inst, (int)Hit.FlgChimeric,
+           (unsigned long long)Hit.Seg[0].MatchLoci, (unsigned)Hit.Seg[0].TrimLeft, (unsigned)Hit.Seg[0].TrimRight, pSfx->NumErrMsgs());
+    Inst = 1;
+    Rslt = pSfx->AlignReads(0, 1, 0, 2, 33, 33, 8, 8, 1, eALSboth, 0, 0, &Inst, &Low, &Nxt, P.data(), 100, 1, &Hit, 16, Nodes);
+    printf("carried-in rslt %d msgs %d\n", Rslt, pSfx->NumErrMsgs());
+    Inst = Low = Nxt = 0;
+  }
   while (pSfx->NumErrMsgs()) pSfx->GetErrMsg();
   // LocateBestMatches (CKAligner's -N, KAligner.cpp:9779) and AlignPairedRead (mate rescue, :3372) keep their signatures
   {

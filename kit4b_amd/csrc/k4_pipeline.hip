@@ -1,0 +1,482 @@
+// kit4b_amd/csrc/k4_pipeline.hip -- the overlapped host <-> device pipeline around the hot path.
+//
+// The reference loads reads on a background thread while its workers align (CKAligner::InitiateLoadingReads /
+// ProcLoadReadFiles, ngskit4b/KAligner.cpp:4786-4866,11323-11496; ThreadedIterReads :10370-10438) and writes the sorted
+// result at the end (WriteBAMReadHits :5718).  Here the same three stages run on three HIP streams:
+//
+//   reader thread(s) of the caller -> pinned ring buffers --copy stream--> text arena in HBM       (k4_pipeline_acquire/submit)
+//   worker thread of this library:   parse -> length filter -> align, chunk by chunk, on the compute stream, while the
+//                                    next chunk is still on its way up; results accumulate in HBM arenas
+//   k4_pipeline_format:              ONE global coordinate sort + SAM text over all chunks (the output is identical to a
+//                                    single batch by construction)
+//   k4_pipeline_next_sam:            SAM text --copy-out stream--> pinned ring -> the caller's writer, piece k+1 coming
+//                                    down while piece k is written
+// Nothing here computes: every kernel is launched through the *_dev entry points of this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "k4_internal.h"
+
+namespace {
+
+struct Arena {  // grow-only device array; only the worker thread touches it while the pipeline runs
+  uint8_t* p = nullptr;
+  size_t cap = 0, used = 0;
+  int reserve(k4_index* ix, size_t need, size_t slack_div = 2) {
+    if (need <= cap) return K4_OK;
+    size_t ncap = std::max(need + need / slack_div + 4096, cap * 2);
+    uint8_t* np = nullptr;
+    K4_HIP(ix, hipDeviceSynchronize());  // no copy or kernel may still use the old block
+    K4_HIP(ix, hipMalloc(&np, ncap + 64));
+    if (used) K4_HIP(ix, hipMemcpy(np, p, used, hipMemcpyDeviceToDevice));
+    if (p) hipFree(p);
+    p = np; cap = ncap;
+    return K4_OK;
+  }
+  void release() { if (p) hipFree(p); p = nullptr; cap = used = 0; }
+};
+
+struct PinBuf {
+  uint8_t* h = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;  // recorded behind the copy that uses the buffer
+  bool in_flight = false;   // handed to submit(), copy not yet known complete
+  bool lent = false;        // handed out by acquire(), not yet submitted
+};
+
+struct Job {
+  int end;
+  int buf;            // ring index, or -1 for caller memory
+  const void* src;    // caller memory (buf == -1)
+  uint64_t bytes;
+  int final_chunk;
+};
+
+struct End {
+  Arena text;                 // every byte of the file(s) of this end, in order
+  uint64_t parsed = 0;        // bytes that belong to complete records already parsed
+  uint64_t uploaded = 0;      // bytes whose copy has been enqueued
+  hipEvent_t up_ev = nullptr; // behind the last enqueued copy
+  Arena offs, lens, noff, nlen;  // per record: 8 / 4 / 8 / 4 bytes
+  int64_t n_rec = 0;
+  int fmt = 0;
+  bool final_seen = false;
+  std::vector<PinBuf> ring;
+};
+
+}  // namespace
+
+struct k4_pipeline {
+  k4_index* ix = nullptr;
+  k4_pipeline_params prm{};
+  hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+  End end[2];
+  Arena reads;           // etSeqBase bytes of both ends
+  Arena c_offs, c_lens;  // per aligned read (PE: interleaved), 8 / 4 bytes
+  Arena rr, hits, seg2, pe;
+  int64_t units_done = 0;
+  uint32_t max_read_len = 0;
+  uint64_t n_under = 0, n_over = 0;
+  int n_ends = 1;
+  // worker
+  std::thread worker;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Job> jobs;
+  bool closing = false, worker_done = false;
+  int err = K4_OK;
+  // output
+  void* d_sam = nullptr;
+  uint64_t sam_bytes = 0, sam_next = 0, sam_given = 0;
+  std::vector<PinBuf> out_ring;
+  std::deque<std::pair<int, uint64_t>> out_q;  // (ring index, bytes) of pieces on their way down, oldest first
+  int out_held = -1;
+};
+
+namespace {
+
+int pin_alloc(k4_index* ix, PinBuf& b, size_t cap) {
+  K4_HIP(ix, hipHostMalloc((void**)&b.h, cap, hipHostMallocDefault));
+  K4_HIP(ix, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+  b.cap = cap;
+  return K4_OK;
+}
+
+// parse whatever complete records the uploaded text of `e` holds beyond `parsed` (chunks of < 4 GiB per call)
+int parse_more(k4_pipeline* pl, int e) {
+  k4_index* ix = pl->ix;
+  End& E = pl->end[e];
+  // the compute stream may only read what the copy stream has delivered
+  if (E.up_ev) K4_HIP(ix, hipStreamWaitEvent(pl->s_comp, E.up_ev, 0));
+  const uint64_t piece = 3ull << 30;
+  while (E.parsed < E.uploaded) {
+    const uint64_t len = std::min(piece, E.uploaded - E.parsed);
+    const int final_chunk = E.final_seen && E.parsed + len == E.uploaded;
+    // room: a record takes at least ~ 2 lines; 1 per 24 bytes is generous for real reads, a shortfall only costs another round
+    const int64_t cap_rec = (int64_t)(len / 24 + 1024);
+    int rc;
+    if ((rc = E.offs.reserve(ix, (size_t)(E.n_rec + cap_rec) * 8)) != K4_OK) return rc;
+    if ((rc = E.lens.reserve(ix, (size_t)(E.n_rec + cap_rec) * 4)) != K4_OK) return rc;
+    if ((rc = E.noff.reserve(ix, (size_t)(E.n_rec + cap_rec) * 8)) != K4_OK) return rc;
+    if ((rc = E.nlen.reserve(ix, (size_t)(E.n_rec + cap_rec) * 4)) != K4_OK) return rc;
+    if ((rc = pl->reads.reserve(ix, pl->reads.used + len + 64)) != K4_OK) return rc;
+    k4_parse_info info;
+    rc = k4_parse_fastx_dev(ix, E.text.p + E.parsed, len, E.parsed, final_chunk, E.fmt, cap_rec, pl->reads.p, pl->reads.used,
+                            E.offs.p + 8 * E.n_rec, E.lens.p + 4 * E.n_rec, E.noff.p + 8 * E.n_rec, E.nlen.p + 4 * E.n_rec, &info,
+                            pl->s_comp);
+    if (rc != K4_OK) return rc;
+    if (info.format) E.fmt = (int)info.format;
+    if (info.consumed == 0) {
+      if (len == E.uploaded - E.parsed) break;  // an incomplete record: more text needed
+      return k4_fail(ix, K4_ERR_PARAMS, "a record longer than 3 GiB");
+    }
+    E.n_rec += (int64_t)info.n_records;
+    E.offs.used = (size_t)E.n_rec * 8; E.lens.used = (size_t)E.n_rec * 4; E.noff.used = (size_t)E.n_rec * 8; E.nlen.used = (size_t)E.n_rec * 4;
+    pl->reads.used += info.n_bases;
+    E.parsed += info.consumed;
+  }
+  return K4_OK;
+}
+
+// align the units (reads / pairs) both ends have delivered and nobody has aligned yet
+int align_more(k4_pipeline* pl, bool flush) {
+  k4_index* ix = pl->ix;
+  const bool pe = pl->n_ends == 2;
+  const int64_t avail = pe ? std::min(pl->end[0].n_rec, pl->end[1].n_rec) : pl->end[0].n_rec;
+  const int64_t n = avail - pl->units_done;
+  if (n <= 0 || (!flush && n < (int64_t)pl->prm.min_batch_units)) return K4_OK;
+  const int64_t r0 = pe ? 2 * pl->units_done : pl->units_done, nr = pe ? 2 * n : n;
+  const int max_ml = std::max(pl->prm.kp.max_ml, 1);
+  int rc;
+  if ((rc = pl->c_offs.reserve(ix, (size_t)(r0 + nr + 1) * 8)) != K4_OK) return rc;
+  if ((rc = pl->c_lens.reserve(ix, (size_t)(r0 + nr + 1) * 4)) != K4_OK) return rc;
+  uint64_t under = 0, over = 0;
+  uint32_t max_len = 0;
+  const int64_t d = pl->units_done;
+  rc = k4_prepare_reads_dev(ix, pe ? 1 : 0, n, pl->prm.min_len, pl->prm.max_len, pl->end[0].offs.p + 8 * d, pl->end[0].lens.p + 4 * d,
+                            pe ? pl->end[1].offs.p + 8 * d : nullptr, pe ? pl->end[1].lens.p + 4 * d : nullptr, 0,
+                            pl->c_offs.p + 8 * r0, pl->c_lens.p + 4 * r0, &under, &over, &max_len, pl->s_comp);
+  if (rc != K4_OK) return rc;
+  pl->c_offs.used = (size_t)(r0 + nr) * 8; pl->c_lens.used = (size_t)(r0 + nr) * 4;
+  pl->n_under += under; pl->n_over += over;
+  pl->max_read_len = std::max(pl->max_read_len, max_len);
+  if (pe) {
+    if ((rc = pl->pe.reserve(ix, (size_t)(r0 + nr) * sizeof(k4_pe_read))) != K4_OK) return rc;
+    pl->pe.used = (size_t)(r0 + nr) * sizeof(k4_pe_read);
+    if (max_len > 0)
+      rc = k4_kalign_pe_batch_dev(ix, &pl->prm.kp, &pl->prm.pe, n, (int32_t)max_len, pl->reads.p, pl->c_offs.p + 8 * r0, pl->c_lens.p + 4 * r0,
+                                  pl->pe.p + (size_t)r0 * sizeof(k4_pe_read), pl->s_comp);
+    else
+      rc = k4_check_hip(ix, hipMemsetAsync(pl->pe.p + (size_t)r0 * sizeof(k4_pe_read), 0, (size_t)nr * sizeof(k4_pe_read), pl->s_comp), "memset");
+  } else {
+    const bool two = pl->prm.kp.micro_indel_len > 0 || pl->prm.kp.max_splice_junct_len > 0;
+    if ((rc = pl->rr.reserve(ix, (size_t)(r0 + nr) * sizeof(k4_read_result))) != K4_OK) return rc;
+    if ((rc = pl->hits.reserve(ix, (size_t)(r0 + nr) * max_ml * sizeof(k4_hit))) != K4_OK) return rc;
+    if (two && (rc = pl->seg2.reserve(ix, (size_t)(r0 + nr) * sizeof(k4_seg2))) != K4_OK) return rc;
+    pl->rr.used = (size_t)(r0 + nr) * sizeof(k4_read_result);
+    pl->hits.used = (size_t)(r0 + nr) * max_ml * sizeof(k4_hit);
+    if (two) pl->seg2.used = (size_t)(r0 + nr) * sizeof(k4_seg2);
+    if (max_len > 0) {
+      if ((rc = k4_reserve(ix, n, (int32_t)max_len, max_ml)) != K4_OK) return rc;
+      rc = k4_kalign_ext_batch_dev(ix, &pl->prm.kp, n, (int32_t)max_len, pl->reads.p, pl->c_offs.p + 8 * r0, pl->c_lens.p + 4 * r0,
+                                   pl->rr.p + (size_t)r0 * sizeof(k4_read_result), pl->hits.p + (size_t)r0 * max_ml * sizeof(k4_hit),
+                                   two ? pl->seg2.p + (size_t)r0 * sizeof(k4_seg2) : nullptr, pl->s_comp);
+    } else {
+      K4_HIP(ix, hipMemsetAsync(pl->rr.p + (size_t)r0 * sizeof(k4_read_result), 0, (size_t)nr * sizeof(k4_read_result), pl->s_comp));
+      K4_HIP(ix, hipMemsetAsync(pl->hits.p + (size_t)r0 * max_ml * sizeof(k4_hit), 0, (size_t)nr * max_ml * sizeof(k4_hit), pl->s_comp));
+    }
+  }
+  if (rc != K4_OK) return rc;
+  pl->units_done = avail;
+  return K4_OK;
+}
+
+void worker_main(k4_pipeline* pl) {
+  k4_index* ix = pl->ix;
+  hipSetDevice(ix->device);
+  int rc = K4_OK;
+  for (;;) {
+    Job j;
+    {
+      std::unique_lock<std::mutex> lk(pl->m);
+      pl->cv.wait(lk, [&] { return !pl->jobs.empty() || pl->closing; });
+      if (pl->jobs.empty()) break;
+      j = pl->jobs.front();
+      pl->jobs.pop_front();
+    }
+    if (rc != K4_OK) {  // drain: buffers must still be released
+      if (j.buf >= 0) { std::lock_guard<std::mutex> lk(pl->m); pl->end[j.end].ring[(size_t)j.buf].in_flight = false; pl->cv.notify_all(); }
+      continue;
+    }
+    End& E = pl->end[j.end];
+    // 1. this chunk starts its way up ...
+    if (j.bytes) {
+      rc = E.text.reserve(ix, E.text.used + j.bytes + 64, 4);
+      if (rc == K4_OK) {
+        const void* src = j.buf >= 0 ? (const void*)E.ring[(size_t)j.buf].h : j.src;
+        rc = k4_check_hip(ix, hipMemcpyAsync(E.text.p + E.text.used, src, j.bytes, hipMemcpyHostToDevice, pl->s_in), "upload");
+      }
+      if (rc == K4_OK) {
+        E.text.used += j.bytes;
+        if (j.buf >= 0) rc = k4_check_hip(ix, hipEventRecord(E.ring[(size_t)j.buf].ev, pl->s_in), "event");
+      }
+    }
+    if (j.final_chunk) E.final_seen = true;
+    // 2. ... while everything that had arrived before it is parsed and aligned (the copy stream runs on its own)
+    if (rc == K4_OK) rc = parse_more(pl, j.end);
+    bool all_final = true;
+    for (int e = 0; e < pl->n_ends; e++) all_final &= pl->end[e].final_seen;
+    if (rc == K4_OK) rc = align_more(pl, false);
+    // 3. the chunk just sent becomes parseable: everything up to here is behind up_ev
+    if (rc == K4_OK && j.bytes) {
+      if (!E.up_ev) rc = k4_check_hip(ix, hipEventCreateWithFlags(&E.up_ev, hipEventDisableTiming), "event");
+      if (rc == K4_OK) rc = k4_check_hip(ix, hipEventRecord(E.up_ev, pl->s_in), "event");
+      E.uploaded = E.text.used;
+    }
+    if (j.buf >= 0) {  // the ring buffer is free once its copy has completed: acquire() waits on the event
+      std::lock_guard<std::mutex> lk(pl->m);
+      E.ring[(size_t)j.buf].in_flight = false;
+      pl->cv.notify_all();
+    }
+    if (rc == K4_OK && all_final) {
+      bool empty;
+      { std::lock_guard<std::mutex> lk(pl->m); empty = pl->jobs.empty(); }
+      if (empty) {  // the last chunks: parse and align what is left
+        for (int e = 0; e < pl->n_ends && rc == K4_OK; e++) rc = parse_more(pl, e);
+        if (rc == K4_OK) rc = align_more(pl, true);
+      }
+    }
+  }
+  if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(pl->s_comp), "pipeline");
+  std::lock_guard<std::mutex> lk(pl->m);
+  pl->err = rc;
+  pl->worker_done = true;
+  pl->cv.notify_all();
+}
+
+int join_worker(k4_pipeline* pl) {
+  {
+    std::lock_guard<std::mutex> lk(pl->m);
+    pl->closing = true;
+    pl->cv.notify_all();
+  }
+  if (pl->worker.joinable()) pl->worker.join();
+  return pl->err;
+}
+
+}  // namespace
+
+extern "C" int k4_pipeline_open(k4_index* ix, const k4_pipeline_params* p, k4_pipeline** out) {
+  if (!ix || !p || !out) return K4_ERR_PARAMS;
+  *out = nullptr;
+  if (p->kp.max_ml < 1) return k4_fail(ix, K4_ERR_PARAMS, "max_ml must be >= 1");
+  K4_HIP(ix, hipSetDevice(ix->device));
+  k4_pipeline* pl = new k4_pipeline;
+  pl->ix = ix;
+  pl->prm = *p;
+  pl->n_ends = p->paired ? 2 : 1;
+  if (pl->prm.chunk_bytes == 0) pl->prm.chunk_bytes = 256ull << 20;
+  pl->prm.chunk_bytes = std::min<uint64_t>(std::max<uint64_t>(pl->prm.chunk_bytes, 1ull << 20), 2ull << 30);
+  if (pl->prm.min_batch_units == 0) pl->prm.min_batch_units = 1u << 20;
+  if (pl->prm.n_buffers < 2) pl->prm.n_buffers = 3;
+  int rc = K4_OK;
+  auto ck = [&](hipError_t e, const char* what) { if (rc == K4_OK) rc = k4_check_hip(ix, e, what); };
+  ck(hipStreamCreateWithFlags(&pl->s_in, hipStreamNonBlocking), "stream");
+  ck(hipStreamCreateWithFlags(&pl->s_comp, hipStreamNonBlocking), "stream");
+  ck(hipStreamCreateWithFlags(&pl->s_out, hipStreamNonBlocking), "stream");
+  for (int e = 0; e < pl->n_ends && rc == K4_OK; e++) {
+    pl->end[e].ring.resize((size_t)pl->prm.n_buffers);
+    if (p->expect_text_bytes[e]) rc = pl->end[e].text.reserve(ix, (size_t)p->expect_text_bytes[e] + 64, 64);
+  }
+  if (rc != K4_OK) { k4_pipeline_close(pl); return rc; }
+  pl->worker = std::thread(worker_main, pl);
+  *out = pl;
+  return K4_OK;
+}
+
+// a pinned buffer of the ring of `end` for the caller to fill; blocks while all of them are on their way up
+extern "C" int k4_pipeline_acquire(k4_pipeline* pl, int end, void** buf, uint64_t* cap) {
+  if (!pl || end < 0 || end >= pl->n_ends || !buf || !cap) return K4_ERR_PARAMS;
+  k4_index* ix = pl->ix;
+  End& E = pl->end[end];
+  for (;;) {
+    int pick = -1;
+    {
+      std::unique_lock<std::mutex> lk(pl->m);
+      if (pl->err != K4_OK) return pl->err;
+      for (size_t b = 0; b < E.ring.size(); b++)
+        if (!E.ring[b].in_flight && !E.ring[b].lent) { pick = (int)b; break; }
+      if (pick < 0) { pl->cv.wait(lk); continue; }
+      E.ring[(size_t)pick].lent = true;
+    }
+    PinBuf& B = E.ring[(size_t)pick];
+    if (!B.h) {
+      K4_HIP(ix, hipSetDevice(ix->device));
+      int rc = pin_alloc(ix, B, (size_t)pl->prm.chunk_bytes);
+      if (rc != K4_OK) return rc;
+    } else
+      K4_HIP(ix, hipEventSynchronize(B.ev));  // its previous copy has left the buffer
+    *buf = B.h;
+    *cap = B.cap;
+    return K4_OK;
+  }
+}
+
+static int push_job(k4_pipeline* pl, const Job& j) {
+  std::lock_guard<std::mutex> lk(pl->m);
+  if (pl->err != K4_OK) return pl->err;
+  if (pl->closing) return K4_ERR_PARAMS;
+  pl->jobs.push_back(j);
+  pl->cv.notify_all();
+  return K4_OK;
+}
+
+extern "C" int k4_pipeline_submit(k4_pipeline* pl, int end, uint64_t bytes, int final_chunk) {
+  if (!pl || end < 0 || end >= pl->n_ends) return K4_ERR_PARAMS;
+  End& E = pl->end[end];
+  int pick = -1;
+  {
+    std::lock_guard<std::mutex> lk(pl->m);
+    for (size_t b = 0; b < E.ring.size(); b++)
+      if (E.ring[b].lent) { pick = (int)b; break; }
+    if (pick < 0) {
+      if (bytes) return K4_ERR_PARAMS;  // nothing acquired
+    } else {
+      if (bytes > E.ring[(size_t)pick].cap) return K4_ERR_PARAMS;
+      E.ring[(size_t)pick].lent = false;
+      E.ring[(size_t)pick].in_flight = bytes != 0;
+    }
+  }
+  Job j = {end, bytes ? pick : -1, nullptr, bytes, final_chunk};
+  return push_job(pl, j);
+}
+
+// text in the caller's own memory (pinned for the full PCIe rate); it must stay valid until k4_pipeline_wait_aligned returns
+extern "C" int k4_pipeline_submit_host(k4_pipeline* pl, int end, const void* text, uint64_t bytes, int final_chunk) {
+  if (!pl || end < 0 || end >= pl->n_ends || (bytes && !text)) return K4_ERR_PARAMS;
+  const uint64_t piece = pl->prm.chunk_bytes;
+  uint64_t pos = 0;
+  do {
+    const uint64_t len = std::min(piece, bytes - pos);
+    Job j = {end, -1, (const uint8_t*)text + pos, len, final_chunk && pos + len == bytes};
+    int rc = push_job(pl, j);
+    if (rc != K4_OK) return rc;
+    pos += len;
+  } while (pos < bytes);
+  return K4_OK;
+}
+
+extern "C" int k4_pipeline_wait_aligned(k4_pipeline* pl, k4_pipeline_view* v) {
+  if (!pl) return K4_ERR_PARAMS;
+  int rc = join_worker(pl);
+  if (rc != K4_OK) return rc;
+  k4_index* ix = pl->ix;
+  for (int e = 0; e < pl->n_ends; e++)
+    if (!pl->end[e].final_seen) return k4_fail(ix, K4_ERR_PARAMS, "k4_pipeline_wait_aligned before the final chunk of end %d", e);
+  if (pl->n_ends == 2 && pl->end[0].n_rec != pl->end[1].n_rec) return k4_fail(ix, K4_ERR_PARAMS, "the PE1 and PE2 inputs hold different numbers of reads (%lld, %lld)", (long long)pl->end[0].n_rec, (long long)pl->end[1].n_rec);
+  for (int e = 0; e < pl->n_ends; e++)
+    if (pl->end[e].parsed != pl->end[e].uploaded) return k4_fail(ix, K4_ERR_NOT_FASTA, "input %d ends inside a record", e);
+  if (v) {
+    memset(v, 0, sizeof(*v));
+    v->n_units = pl->units_done;
+    v->n_reads = pl->n_ends == 2 ? 2 * pl->units_done : pl->units_done;
+    v->max_read_len = pl->max_read_len;
+    v->n_under = pl->n_under; v->n_over = pl->n_over;
+    v->max_ml = std::max(pl->prm.kp.max_ml, 1);
+    v->d_rr = pl->rr.p; v->d_hits = pl->hits.p; v->d_seg2 = pl->seg2.p; v->d_pe = pl->pe.p;
+    v->d_reads = pl->reads.p; v->d_offs = pl->c_offs.p; v->d_lens = pl->c_lens.p;
+    for (int e = 0; e < pl->n_ends; e++) {
+      v->names.d_text[e] = pl->end[e].text.p; v->names.d_name_off[e] = pl->end[e].noff.p; v->names.d_name_len[e] = pl->end[e].nlen.p;
+    }
+  }
+  return K4_OK;
+}
+
+extern "C" int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* sam_bytes) {
+  if (!pl) return K4_ERR_PARAMS;
+  k4_pipeline_view v;
+  int rc = k4_pipeline_wait_aligned(pl, &v);
+  if (rc != K4_OK) return rc;
+  if (pl->d_sam) { hipFree(pl->d_sam); pl->d_sam = nullptr; }
+  pl->sam_bytes = pl->sam_next = pl->sam_given = 0;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (v.n_units > 0 && v.max_read_len > 0)
+    rc = k4_format_sam_ext_dev(pl->ix, pl->n_ends == 2 ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_seg2, v.d_reads, v.d_offs,
+                               v.d_lens, &v.names, &pl->d_sam, &pl->sam_bytes, stats, chrom_hit, pl->s_comp);
+  if (sam_bytes) *sam_bytes = pl->sam_bytes;
+  return rc;
+}
+
+// the next piece of the SAM body in a pinned buffer that stays valid until the following call; *bytes == 0 at the end.
+// Two further pieces are already on their way down while the caller consumes this one.
+extern "C" int k4_pipeline_next_sam(k4_pipeline* pl, const void** ptr, uint64_t* bytes) {
+  if (!pl || !ptr || !bytes) return K4_ERR_PARAMS;
+  k4_index* ix = pl->ix;
+  *ptr = nullptr;
+  *bytes = 0;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  if (pl->out_ring.empty()) {
+    pl->out_ring.resize(3);
+    const size_t cap = (size_t)std::min<uint64_t>(std::max<uint64_t>(pl->prm.chunk_bytes, 8ull << 20), 256ull << 20);
+    for (PinBuf& b : pl->out_ring) {
+      int rc = pin_alloc(ix, b, cap);
+      if (rc != K4_OK) return rc;
+    }
+  }
+  if (pl->out_held >= 0) { pl->out_ring[(size_t)pl->out_held].in_flight = false; pl->out_held = -1; }
+  // keep the copy-out stream busy: every free buffer gets the next piece
+  for (size_t b = 0; b < pl->out_ring.size() && pl->sam_next < pl->sam_bytes; b++) {
+    PinBuf& B = pl->out_ring[b];
+    if (B.in_flight) continue;
+    const uint64_t len = std::min<uint64_t>(B.cap, pl->sam_bytes - pl->sam_next);
+    K4_HIP(ix, hipMemcpyAsync(B.h, (const uint8_t*)pl->d_sam + pl->sam_next, len, hipMemcpyDeviceToHost, pl->s_out));
+    K4_HIP(ix, hipEventRecord(B.ev, pl->s_out));
+    B.in_flight = true;
+    pl->out_q.push_back({(int)b, len});
+    pl->sam_next += len;
+  }
+  if (pl->out_q.empty()) return K4_OK;
+  const std::pair<int, uint64_t> f = pl->out_q.front();
+  pl->out_q.pop_front();
+  K4_HIP(ix, hipEventSynchronize(pl->out_ring[(size_t)f.first].ev));
+  pl->out_held = f.first;
+  *ptr = pl->out_ring[(size_t)f.first].h;
+  *bytes = f.second;
+  return K4_OK;
+}
+
+// the whole SAM body into the caller's memory (pinned for the full PCIe rate)
+extern "C" int k4_pipeline_read_sam(k4_pipeline* pl, void* dst, uint64_t cap, uint64_t* bytes) {
+  if (!pl || !bytes) return K4_ERR_PARAMS;
+  *bytes = pl->sam_bytes;
+  if (pl->sam_bytes == 0) return K4_OK;
+  if (!dst || cap < pl->sam_bytes) return k4_fail(pl->ix, K4_ERR_PARAMS, "the SAM body takes %llu bytes", (unsigned long long)pl->sam_bytes);
+  K4_HIP(pl->ix, hipSetDevice(pl->ix->device));
+  K4_HIP(pl->ix, hipMemcpyAsync(dst, pl->d_sam, pl->sam_bytes, hipMemcpyDeviceToHost, pl->s_out));
+  K4_HIP(pl->ix, hipStreamSynchronize(pl->s_out));
+  return K4_OK;
+}
+
+extern "C" void k4_pipeline_close(k4_pipeline* pl) {
+  if (!pl) return;
+  join_worker(pl);
+  hipSetDevice(pl->ix->device);
+  hipDeviceSynchronize();
+  for (int e = 0; e < 2; e++) {
+    End& E = pl->end[e];
+    for (PinBuf& b : E.ring) { if (b.h) hipHostFree(b.h); if (b.ev) hipEventDestroy(b.ev); }
+    if (E.up_ev) hipEventDestroy(E.up_ev);
+    for (Arena* a : {&E.text, &E.offs, &E.lens, &E.noff, &E.nlen}) a->release();
+  }
+  for (PinBuf& b : pl->out_ring) { if (b.h) hipHostFree(b.h); if (b.ev) hipEventDestroy(b.ev); }
+  for (Arena* a : {&pl->reads, &pl->c_offs, &pl->c_lens, &pl->rr, &pl->hits, &pl->seg2, &pl->pe}) a->release();
+  if (pl->d_sam) hipFree(pl->d_sam);
+  for (hipStream_t s : {pl->s_in, pl->s_comp, pl->s_out}) if (s) hipStreamDestroy(s);
+  delete pl;
+}

@@ -11,8 +11,13 @@
 //   SAM                  CKAligner::WriteBAMReadHits :5718-5914, ReportBAMread :5957-6320, SortHitMatch :10969,
 //                        CSAMfile::AddAlignment libkit4b/SAMfile.cpp:2194-2377 -> k4_format_sam_dev; header :1615,1667-1669,1799
 // Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R -X -N -c -a -A -x (plus -g <gpu>, -S <i/N> read slice).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +42,9 @@ struct Opts {
   double batch_mb = 0;              // -b <MB>: stream the input, this much text per file per batch (0: the whole input at once)
   int shard = 0, n_shards = 1;      // -S i/N: this process aligns the i-th of N contiguous slices of the reads (one process per GPU)
   int gpu = 0;
+  bool legacy = false;              // -Z: the serial whole-input path of round 1 (one batch, no overlap), kept for comparison
+  int chunk_mb = 256;               // -B <MB>: size of one pinned upload buffer of the pipeline
+  int io_threads = 4;               // -t <n>: concurrent pread / pwrite calls per buffer
 };
 
 struct Parsed {  // one reads file after k4_parse_fastx_dev: everything lives in HBM
@@ -141,12 +149,120 @@ struct Stream {
   void close() { if (f) gzclose(f); f = nullptr; }
 };
 
+// ---- the pipelined (default) mode: one reader thread per end fills the library's pinned ring buffers ----------------------
+bool is_gzip(const std::string& path) {
+  unsigned char m[2] = {0, 0};
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  const size_t got = fread(m, 1, 2, f);
+  fclose(f);
+  return got == 2 && m[0] == 0x1f && m[1] == 0x8b;
+}
+uint64_t file_size(const std::string& path) {
+  struct stat st;
+  return stat(path.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
+}
+// plain files: the range [off, off+len) by `nt` concurrent pread()s (tmpfs / page cache deliver more than one thread can take)
+bool pread_parallel(int fd, uint64_t off, uint8_t* dst, uint64_t len, int nt) {
+  if (len < (8u << 20) || nt <= 1) {
+    uint64_t done = 0;
+    while (done < len) {
+      const ssize_t g = pread(fd, dst + done, len - done, (off_t)(off + done));
+      if (g <= 0) return false;
+      done += (uint64_t)g;
+    }
+    return true;
+  }
+  std::atomic<bool> ok(true);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([&, t] {
+      const uint64_t a = len * t / nt, b = len * (t + 1) / nt;
+      uint64_t done = a;
+      while (done < b) {
+        const ssize_t g = pread(fd, dst + done, b - done, (off_t)(off + done));
+        if (g <= 0) { ok = false; return; }
+        done += (uint64_t)g;
+      }
+    });
+  for (std::thread& x : th) x.join();
+  return ok;
+}
+// every file of one end, in order, into the pipeline; a file that lacks its last newline gets one (as Stream does)
+int feed_end(k4_pipeline* pl, int end, const std::vector<std::string>& files, int io_threads, double* secs_read) {
+  void* buf = nullptr;
+  uint64_t cap = 0, used = 0;
+  uint8_t last = '\n';
+  auto t0 = std::chrono::steady_clock::now();
+  double busy = 0;
+  auto flush = [&](int fin) -> int {
+    busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int rc = k4_pipeline_submit(pl, end, used, fin);
+    buf = nullptr; used = 0;
+    t0 = std::chrono::steady_clock::now();
+    return rc;
+  };
+  for (size_t f = 0; f < files.size(); f++) {
+    const bool gz = is_gzip(files[f]);
+    gzFile g = nullptr;
+    int fd = -1;
+    uint64_t fsz = 0, fpos = 0;
+    if (gz) {
+      g = gzopen(files[f].c_str(), "rb");
+      if (!g) return K4_ERR_OPEN_FILE;
+      gzbuffer(g, 4u << 20);
+    } else {
+      fd = open(files[f].c_str(), O_RDONLY);
+      if (fd < 0) return K4_ERR_OPEN_FILE;
+      fsz = file_size(files[f]);
+    }
+    for (;;) {
+      if (!buf) {
+        busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        int rc = k4_pipeline_acquire(pl, end, &buf, &cap);  // (waiting for a free buffer is not reading time)
+        t0 = std::chrono::steady_clock::now();
+        if (rc != K4_OK) return rc;
+        used = 0;
+      }
+      uint64_t got = 0;
+      if (gz) {
+        const int r = gzread(g, (uint8_t*)buf + used, (unsigned)std::min<uint64_t>(cap - used, 1u << 30));
+        if (r < 0) return K4_ERR_FILE_ACCESS;
+        got = (uint64_t)r;
+      } else {
+        got = std::min<uint64_t>(cap - used, fsz - fpos);
+        if (got && !pread_parallel(fd, fpos, (uint8_t*)buf + used, got, io_threads)) return K4_ERR_FILE_ACCESS;
+        fpos += got;
+      }
+      if (got == 0) break;  // end of this file
+      used += got;
+      last = ((uint8_t*)buf)[used - 1];
+      if (used == cap) { int rc = flush(0); if (rc != K4_OK) return rc; }
+    }
+    if (gz) gzclose(g); else close(fd);
+    if (last != '\n' && f + 1 < files.size()) {  // the next file starts on a line of its own
+      if (!buf) { int rc = k4_pipeline_acquire(pl, end, &buf, &cap); if (rc != K4_OK) return rc; used = 0; }
+      ((uint8_t*)buf)[used++] = '\n';
+      last = '\n';
+      if (used == cap) { int rc = flush(0); if (rc != K4_OK) return rc; }
+    }
+  }
+  if (!buf) {  // the final (possibly empty) chunk still has to be announced
+    int rc = k4_pipeline_acquire(pl, end, &buf, &cap);
+    if (rc != K4_OK) return rc;
+    used = 0;
+  }
+  int rc = flush(1);
+  if (secs_read) *secs_read = busy;
+  return rc;
+}
+
 const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"};
 
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-S i/N] [-b MB per batch] [-g gpu=0]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=4] [-Z] [-g gpu=0]\n");
 }
 
 }  // namespace
@@ -208,6 +324,9 @@ int main(int argc, char** argv) {
       case 'S': { std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2) { usage(); return 1; } break; }
       case 'g': o.gpu = atoi(val().c_str()); break;
       case 'b': o.batch_mb = atof(val().c_str()); break;
+      case 'B': o.chunk_mb = std::max(1, atoi(val().c_str())); break;
+      case 't': o.io_threads = std::max(1, atoi(val().c_str())); break;
+      case 'Z': o.legacy = true; break;
       case 'T': case 'F': (void)val(); break;  // accepted and ignored (threads, log file)
       default: usage(); return 1;
     }
@@ -280,6 +399,50 @@ int main(int argc, char** argv) {
     return std::chrono::duration<double>(b - a).count();
   };
 
+  // the stages between alignment and report, over ALL reads of the run (CKAligner::Align, KAligner.cpp:615-686)
+  auto global_stages = [&](int64_t n, uint32_t max_len, void* d_rr, void* d_hits, void* d_seg2, void* d_pe, void* d_reads, void* d_offs,
+                           void* d_lens) -> int {
+    if (n <= 0 || max_len == 0) return K4_OK;
+    if (!pe) {
+      if (o.ml_mode == 3 || o.ml_mode == 4) {  // AssignMultiMatches (KAligner.cpp:5092): clusters over all reads of the run
+        int64_t n_assigned = 0;
+        CK(k4_assign_multi_dev(ix, o.ml_mode, (int32_t)max_len, n, max_ml, d_rr, d_hits, &n_assigned, nullptr));
+        fprintf(stderr, "k4align: %lld multi-aligned reads assigned to one locus by clustering\n", (long long)n_assigned);
+      }
+      if (o.ml_mode == 2) {
+        // eMLrand (KAligner.cpp:9945-9962): rand() once per read within the instance limit, in load order -- what the
+        // reference does when it runs one thread (with more its draws depend on thread timing).  The draws are a private
+        // restatement of the C library's generator: other code in this process (the HIP runtime) may call rand() too
+        std::vector<k4_read_result> rr((size_t)n);
+        std::vector<uint32_t> choice((size_t)n, 0);
+        CK(k4_copy_to_host(ix, rr.data(), d_rr, (uint64_t)n * sizeof(k4_read_result)));
+        for (int64_t i = 0; i < n; i++)
+          if (rr[i].nar == K4_NAR_ACCEPTED && rr[i].num_hits >= 1) choice[i] = (uint32_t)(draws.next() % rr[i].num_hits);
+        void* d_choice = nullptr;
+        CK(k4_alloc_device(ix, (uint64_t)n * 4, &d_choice));
+        CK(k4_copy_to_device(ix, d_choice, choice.data(), (uint64_t)n * 4));
+        CK(k4_select_hits_dev(ix, n, max_ml, d_rr, d_hits, d_choice, nullptr));
+        k4_free_device(d_choice);
+      }
+    }
+    // the filters, in CKAligner::Align's order (KAligner.cpp:653-686)
+    int64_t cnt = 0;
+    if (o.min_flank_exacts > 0) {
+      CK(k4_auto_trim_flanks_dev(ix, o.min_flank_exacts, pe ? 1 : 0, pe ? 2 * n : n, max_ml, pe ? d_pe : d_rr, d_hits, d_reads, d_offs,
+                                 d_lens, &cnt, nullptr));
+      fprintf(stderr, "k4align: flank autotrim to %d exact bases: %lld aligned reads removed\n", o.min_flank_exacts, (long long)cnt);
+    }
+    if (!pe && o.splice_junct > 0) {
+      CK(k4_remove_orphan_juncts_dev(ix, K4_EXT_SPLICE, n, max_ml, d_rr, d_hits, d_seg2, &cnt, nullptr));
+      fprintf(stderr, "k4align: %lld orphan splice junction reads removed\n", (long long)cnt);
+    }
+    if (!pe && o.micro_indel > 0) {
+      CK(k4_remove_orphan_juncts_dev(ix, K4_EXT_INDEL, n, max_ml, d_rr, d_hits, d_seg2, &cnt, nullptr));
+      fprintf(stderr, "k4align: %lld orphan microInDel reads removed\n", (long long)cnt);
+    }
+    return K4_OK;
+  };
+
   // One batch: text holding whole records (the last one possibly cut when more text follows) -> records -> alignments ->
   // SAM body.  The body goes to `body` (a part file) or, for the single batch of the whole-input mode, stays on the device.
   void* keep_sam = nullptr;
@@ -332,45 +495,11 @@ int main(int argc, char** argv) {
         if (two_seg) CK(k4_alloc_device(ix, (uint64_t)n * sizeof(k4_seg2), &d_seg2));
         CK(k4_reserve(ix, n, (int32_t)max_len, max_ml));
         CK(k4_kalign_ext_batch_dev(ix, &kp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_rr, d_hits, d_seg2, nullptr));
-        if (o.ml_mode == 3 || o.ml_mode == 4) {  // AssignMultiMatches (KAligner.cpp:5092): clusters over all reads of the run
-          int64_t n_assigned = 0;
-          CK(k4_assign_multi_dev(ix, o.ml_mode, (int32_t)max_len, n, max_ml, d_rr, d_hits, &n_assigned, nullptr));
-          fprintf(stderr, "k4align: %lld multi-aligned reads assigned to one locus by clustering\n", (long long)n_assigned);
-        }
-        if (o.ml_mode == 2) {
-          // eMLrand (KAligner.cpp:9945-9962): rand() once per read within the instance limit, in load order -- what the
-          // reference does when it runs one thread (with more its draws depend on thread timing).  The draws are a private
-          // restatement of the C library's generator: other code in this process (the HIP runtime) may call rand() too
-          std::vector<k4_read_result> rr((size_t)n);
-          std::vector<uint32_t> choice((size_t)n, 0);
-          CK(k4_copy_to_host(ix, rr.data(), d_rr, (uint64_t)n * sizeof(k4_read_result)));
-          for (int64_t i = 0; i < n; i++)
-            if (rr[i].nar == K4_NAR_ACCEPTED && rr[i].num_hits >= 1) choice[i] = (uint32_t)(draws.next() % rr[i].num_hits);
-          void* d_choice = nullptr;
-          CK(k4_alloc_device(ix, (uint64_t)n * 4, &d_choice));
-          CK(k4_copy_to_device(ix, d_choice, choice.data(), (uint64_t)n * 4));
-          CK(k4_select_hits_dev(ix, n, max_ml, d_rr, d_hits, d_choice, nullptr));
-          k4_free_device(d_choice);
-        }
       } else {
         CK(k4_alloc_device(ix, (uint64_t)2 * n * sizeof(k4_pe_read), &d_pe));
         CK(k4_kalign_pe_batch_dev(ix, &kp, &pp, n, (int32_t)max_len, d_reads, d_offs, d_lens, d_pe, nullptr));
       }
-      // the filters between alignment and report, in CKAligner::Align's order (KAligner.cpp:653-686)
-      int64_t cnt = 0;
-      if (o.min_flank_exacts > 0) {
-        CK(k4_auto_trim_flanks_dev(ix, o.min_flank_exacts, pe ? 1 : 0, pe ? 2 * n : n, max_ml, pe ? d_pe : d_rr, d_hits, d_reads, d_offs,
-                                   d_lens, &cnt, nullptr));
-        fprintf(stderr, "k4align: flank autotrim to %d exact bases: %lld aligned reads removed\n", o.min_flank_exacts, (long long)cnt);
-      }
-      if (!pe && o.splice_junct > 0) {
-        CK(k4_remove_orphan_juncts_dev(ix, K4_EXT_SPLICE, n, max_ml, d_rr, d_hits, d_seg2, &cnt, nullptr));
-        fprintf(stderr, "k4align: %lld orphan splice junction reads removed\n", (long long)cnt);
-      }
-      if (!pe && o.micro_indel > 0) {
-        CK(k4_remove_orphan_juncts_dev(ix, K4_EXT_INDEL, n, max_ml, d_rr, d_hits, d_seg2, &cnt, nullptr));
-        fprintf(stderr, "k4align: %lld orphan microInDel reads removed\n", (long long)cnt);
-      }
+      CK(global_stages(n, max_len, d_rr, d_hits, d_seg2, d_pe, d_reads, d_offs, d_lens));
     }
     // ---- SAM body on the device (k4_format_sam_dev) ------------------------------------------------------------------
     k4_sam_names nm;
@@ -410,13 +539,56 @@ int main(int argc, char** argv) {
     return K4_OK;
   };
 
-  // ---- the input: all at once (one batch, its SAM body stays on the device until the header is out) or streamed ----------
+  // ---- the input ---------------------------------------------------------------------------------------------------------------
+  // default: the overlapped pipeline (k4_pipeline_*): reader threads -> pinned ring -> copy stream || parse + align on the
+  // compute stream; one global sort + SAM body at the end, handed out while its next pieces come down.
+  // -b <MB>: bounded memory, coordinate-sorted parts merged on the host; -S i/N: one slice of the reads (one process per GPU)
+  k4_pipeline* pl = nullptr;
+  uint64_t pl_sam_bytes = 0;
+  const bool pipelined = o.batch_mb <= 0 && o.n_shards == 1 && !o.legacy;
+  if (pipelined) {
+    for (const std::vector<std::string>* fs : {&o.in1, &o.in2})
+      for (const std::string& q : *fs) {
+        FILE* t = fopen(q.c_str(), "rb");
+        if (!t) { fprintf(stderr, "k4align: unable to open '%s'\n", q.c_str()); return 2; }
+        fclose(t);
+      }
+    k4_pipeline_params pp2;
+    memset(&pp2, 0, sizeof(pp2));
+    pp2.paired = pe ? 1 : 0; pp2.kp = kp; pp2.pe = pp; pp2.min_len = o.min_len; pp2.max_len = o.max_len;
+    pp2.chunk_bytes = (uint64_t)o.chunk_mb << 20;
+    for (int e = 0; e < (pe ? 2 : 1); e++) {
+      bool plain = true;
+      uint64_t tot_sz = 0;
+      for (const std::string& q : e ? o.in2 : o.in1) { plain &= !is_gzip(q); tot_sz += file_size(q) + 1; }
+      pp2.expect_text_bytes[e] = plain ? tot_sz : 0;
+    }
+    CK(k4_pipeline_open(ix, &pp2, &pl));
+    auto tr = now();
+    int rc_end[2] = {K4_OK, K4_OK};
+    double rd[2] = {0, 0};
+    std::thread t2;
+    if (pe) t2 = std::thread([&] { rc_end[1] = feed_end(pl, 1, o.in2, o.io_threads, &rd[1]); });
+    rc_end[0] = feed_end(pl, 0, o.in1, o.io_threads, &rd[0]);
+    if (pe) t2.join();
+    s_read = std::max(rd[0], rd[1]);
+    for (int e = 0; e < 2; e++)
+      if (rc_end[e] != K4_OK) { fprintf(stderr, "k4align: error reading the input (%d): %s\n", rc_end[e], k4_last_error(ix)); return 2; }
+    k4_pipeline_view v;
+    CK(k4_pipeline_wait_aligned(pl, &v));
+    s_parse = secs(tr, now()) - s_read;  // what the device side added behind the reading
+    auto tg = now();
+    CK(global_stages(v.n_units, v.max_read_len, v.d_rr, v.d_hits, v.d_seg2, v.d_pe, v.d_reads, v.d_offs, v.d_lens));
+    CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
+    s_align = secs(tg, now());
+    n_under = v.n_under; n_over = v.n_over; n_units = (uint64_t)v.n_units;
+  }
   Stream f1, f2;
-  if (!f1.open(o.in1) || (pe && !f2.open(o.in2))) { fprintf(stderr, "k4align: unable to open reads\n"); return 2; }
+  if (!pipelined && (!f1.open(o.in1) || (pe && !f2.open(o.in2)))) { fprintf(stderr, "k4align: unable to open reads\n"); return 2; }
   std::vector<std::string> parts;
   const uint64_t want0 = o.batch_mb > 0 ? std::max<uint64_t>((uint64_t)(o.batch_mb * 1048576.0), 4096) : UINT64_MAX;
   uint64_t want = want0;
-  for (;;) {
+  for (; !pipelined;) {
     auto tr = now();
     if (!f1.fill(want) || (pe && !f2.fill(want))) { fprintf(stderr, "k4align: error reading the input\n"); return 2; }
     s_read += secs(tr, now());
@@ -471,7 +643,36 @@ int main(int argc, char** argv) {
     if (all_chroms || hit_chrom[c]) fprintf(fp, "@SQ\tAS:%s\tSN:%s\tLN:%u\n", info.dataset, e.name, e.seq_len);
   }
   fprintf(fp, "@PG\tID:k4align\tVN:1.0\n");
-  if (keep_sam) {
+  if (pl) {  // the body comes down piece by piece while the previous piece is written
+    fflush(fp);
+    const int fd = fileno(fp);
+    uint64_t fpos = (uint64_t)ftello(fp);
+    for (;;) {
+      const void* ptr = nullptr;
+      uint64_t len = 0;
+      CK(k4_pipeline_next_sam(pl, &ptr, &len));
+      if (len == 0) break;
+      // (several pwrite()s side by side: one thread does not saturate tmpfs / the page cache)
+      const int nt = len >= (8u << 20) ? std::max(o.io_threads, 1) : 1;
+      std::atomic<bool> ok(true);
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+          const uint64_t a = len * t / nt, b = len * (t + 1) / nt;
+          uint64_t done = a;
+          while (done < b) {
+            const ssize_t g = pwrite(fd, (const char*)ptr + done, b - done, (off_t)(fpos + done));
+            if (g <= 0) { ok = false; return; }
+            done += (uint64_t)g;
+          }
+        });
+      for (std::thread& x : th) x.join();
+      if (!ok) { fprintf(stderr, "k4align: write to %s failed\n", o.out.c_str()); return 5; }
+      fpos += len;
+    }
+    fseeko(fp, (off_t)fpos, SEEK_SET);
+    k4_pipeline_close(pl);
+  } else if (keep_sam) {
     std::vector<char> piece((size_t)std::min<uint64_t>(keep_bytes, 256ull << 20));
     for (uint64_t off = 0; off < keep_bytes; off += piece.size()) {
       const uint64_t len = std::min<uint64_t>(piece.size(), keep_bytes - off);

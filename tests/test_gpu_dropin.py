@@ -17,7 +17,7 @@ CASES = json.load(open(os.path.join(G, "sam_cases.json")))
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/ngskit4b_k4 not built (make -C oracle ngskit4b_k4 needs /root/reference)")
-@pytest.mark.parametrize("case", ["se_s2", "pe_u1", "se_r5_R8_N"])
+@pytest.mark.parametrize("case", ["se_s2", "pe_u1", "se_r5_R8_N", "se_c50", "se_a12", "se_A3000", "se_all_120"])
 def test_reference_front_end_on_the_gpu_library(tmp_path, case):
     def unxz(name):
         dst = str(tmp_path / name[:-3])
@@ -27,7 +27,10 @@ def test_reference_front_end_on_the_gpu_library(tmp_path, case):
     files = ["-i", unxz("sam_%s.fa.xz" % case)] if case.startswith("se_") else \
         ["-i", unxz("sam_%s_1.fa.xz" % case), "-u", unxz("sam_%s_2.fa.xz" % case)]
     sam = str(tmp_path / "o.sam")
-    p = subprocess.run([EXE, "kalign", "-I", os.path.join(G, "g1.sfx"), "-o", sam, "-T", "4", "-F", str(tmp_path / "log")]
+    sfx = os.path.join(G, "g1.sfx")
+    if CASES[case].get("index") == "g3":  # the optional AlignReads phases: the reference's own trimming / orphan filters / CIGAR
+        sfx = unxz("g3.sfx.xz")           # code on top of the facade's AlignReads(MinChimericLen, microInDelLen, MaxSpliceJunctLen)
+    p = subprocess.run([EXE, "kalign", "-I", sfx, "-o", sam, "-T", "4", "-F", str(tmp_path / "log")]
                        + CASES[case]["args"] + files, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     got = [l for l in open(sam).read().splitlines() if not l.startswith("@PG")]

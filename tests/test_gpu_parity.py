@@ -243,7 +243,27 @@ def _pick_rand_on_device(ix, out, hits):
     return out2, hits2
 
 
-@pytest.mark.parametrize("case", sorted(SAM_CASES))
+@pytest.mark.parametrize("case", sorted(c for c in SAM_CASES if SAM_CASES[c].get("index") == "g3"))
+def test_reference_sam_end_to_end_optional_phases(k4, golden_dir, g3_path, case):
+    """`kalign -c / -a / -A / -x`: the records and the NAR tallies the reference wrote, from the GPU's
+    AlignRead-level results + the device post stages (flank autotrim, orphan-junction filters)."""
+    from test_oracle_sam_golden import check_hist, kalign_args
+
+    kw, post = kalign_args(SAM_CASES[case]["args"])
+    ix = k4.SfxIndex.open(g3_path)
+    ix.set_max_iter(5000)
+    names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % case))
+    r = ix.kalign_ext_batch(reads, **kw)
+    out, hits, _ = ix.post_stages(reads, r["out"], r["hits"], r["seg2"], min_flank_exacts=post.get("min_flank_exacts", 0),
+                                  orphan_splice=bool(kw.get("max_splice_junct_len")), orphan_indel=bool(kw.get("micro_indel_len")))
+    check_hist(out["nar"], SAM_CASES[case]["nar"])
+    res = [dict(nar=int(o["nar"]), hit=hh[0], pe_aligned=0, seg2=s2) for o, hh, s2 in zip(out, hits, r["seg2"])]
+    _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    assert sorted(samutil.sam_records(names, reads, res, ["chr1", "chr2", "chr3"])) == sorted(recs)
+    ix.close()
+
+
+@pytest.mark.parametrize("case", sorted(c for c in SAM_CASES if SAM_CASES[c].get("index") != "g3"))
 def test_reference_sam_end_to_end(k4, golden_dir, g2_path, case):
     """The records `ngskit4b kalign` wrote (SE and PE incl. mate rescue) are reproduced from the GPU results."""
     kw, pe = _kalign_args(SAM_CASES[case]["args"])
@@ -392,7 +412,10 @@ def test_csfxarray_facade_program(k4, golden_dir):
                 assert ("chrom 2 loci %d strand + mm %d len 100" % (loci, subs)) in l, l
             n += 1
     assert n == 16
-    assert "chimeric rslt -3 msgs 1" in lines
+    chim = [l for l in lines if l.startswith("chimeric rslt")][0].split()
+    assert chim[2] == "1" and chim[4] == "1" and chim[6] == "1" and chim[8] == "5000" and chim[12] == "0" and chim[14] == "0"
+    assert 28 <= int(chim[10]) <= 33  # TrimLeft: the foreign flank (a chance match may shorten / the 3-base rule lengthen it)
+    assert "carried-in rslt -3 msgs 1" in lines
     assert "best rslt 1 inst 1 chrom 2 loci 1200 strand + mm 1" in lines      # LocateBestMatches, same signature
     assert "pair rslt 1 chrom 2 loci 1200 strand - mm 0" in lines              # AlignPairedRead, same signature
     th = [l for l in lines if l.startswith("threads 8 probes 480 hits ")]
