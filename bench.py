@@ -487,6 +487,58 @@ class GpuEngine:
             return out, self.out_pe[:, 6:10].contiguous(), self.out_pe
         return self.out, self.hits, None
 
+    def e2e(self, reads, n, L, max_subs, log_fn):
+        """FASTQ text in (pinned) host memory -> SAM text in (pinned) host memory through the overlapped pipeline
+        (k4_pipeline_*: chunks go up on the copy stream while earlier chunks are parsed and aligned; one global coordinate
+        sort; the body comes down at the end).  PCIe-inclusive; never `value`.  Beside it: the time the same bytes take
+        over PCIe alone -- up, then down: a coordinate-sorted output cannot start before the last read has arrived."""
+        dev = reads.device
+        n = min(n, reads.shape[0])
+        W = 12 + L + 3 + L + 1  # "@r%09d\n" + bases + "\n+\n" + quals + "\n"
+        t0 = time.time()
+        text = torch.empty((n, W), dtype=torch.uint8, device=dev)
+        text[:, 0] = ord("@"); text[:, 1] = ord("r")
+        idx = torch.arange(n, device=dev)
+        for d in range(9):
+            text[:, 2 + d] = ((idx // (10 ** (8 - d))) % 10 + 48).to(torch.uint8)
+        text[:, 11] = 10
+        lut = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)
+        text[:, 12:12 + L] = lut[reads[:n].long().clamp_(max=4)]
+        text[:, 12 + L] = 10; text[:, 13 + L] = ord("+"); text[:, 14 + L] = 10
+        text[:, 15 + L:15 + 2 * L] = ord("I")
+        text[:, W - 1] = 10
+        T = n * W
+        h_text = torch.empty(T, dtype=torch.uint8, pin_memory=True)
+        h_text.copy_(text.reshape(-1))
+        cap_out = n * (L + 80)
+        h_sam = torch.empty(cap_out, dtype=torch.uint8, pin_memory=True)
+        del text, idx
+        torch.cuda.synchronize()
+        log_fn("e2e: %d FASTQ records (%.2f GB) in pinned host memory in %.1fs" % (n, T / 1e9, time.time() - t0))
+        kp = k4.KalignParams(max_subs, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+        best = None
+        for rep in range(3):
+            t0 = time.perf_counter()
+            got, st, _ = self.ix.pipeline_sam([h_text], kp, min_len=50, max_len=500, out=h_sam)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, got, st)
+        dt, got, st = best
+        # the same bytes over PCIe alone, pinned both ways
+        d_buf = torch.empty(max(T, got), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); d_buf[:T].copy_(h_text, non_blocking=True); torch.cuda.synchronize(); t_up = time.perf_counter() - t0
+        t0 = time.perf_counter(); h_sam[:got].copy_(d_buf[:got], non_blocking=True); torch.cuda.synchronize(); t_dn = time.perf_counter() - t0
+        lines = int((h_sam[:got] == 10).sum().item()) if got < (4 << 30) else None
+        del d_buf
+        return {"host_text_to_host_sam_Mreads_s": n / dt / 1e6, "reads": n, "seconds": dt, "text_in_GB": T / 1e9, "sam_out_GB": got / 1e9,
+                "pcie_h2d_GBps": T / t_up / 1e9, "pcie_d2h_GBps": got / t_dn / 1e9,
+                "pcie_bound_Mreads_s": n / (t_up + t_dn) / 1e6, "pcie_bound_frac": (t_up + t_dn) / dt,
+                "sam_lines": st["n_lines"], "sam_lines_counted": lines, "accepted_reads": st["nar"][1],
+                "note": "FASTQ (216 B/record) in pinned host memory -> coordinate-sorted SAM body in pinned host memory; best of 3; "
+                        "pcie_bound = the same bytes up then down with nothing else (the sort needs every read before the first "
+                        "output byte)"}
+
     def close(self):
         self.ix.close()
 

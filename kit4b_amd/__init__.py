@@ -94,6 +94,19 @@ class SamStats(C.Structure):
 FASTA, FASTQ = 1, 2
 
 
+class PipelineParams(C.Structure):
+    _fields_ = [("paired", C.c_int32), ("kp", KalignParams), ("pe", PeParams), ("min_len", C.c_int32), ("max_len", C.c_int32),
+                ("n_buffers", C.c_uint32), ("min_batch_units", C.c_uint32), ("chunk_bytes", C.c_uint64),
+                ("expect_text_bytes", C.c_uint64 * 2)]
+
+
+class PipelineView(C.Structure):
+    _fields_ = [("n_units", C.c_int64), ("n_reads", C.c_int64), ("max_read_len", C.c_uint32), ("max_ml", C.c_int32),
+                ("n_under", C.c_uint64), ("n_over", C.c_uint64), ("d_rr", C.c_void_p), ("d_hits", C.c_void_p),
+                ("d_seg2", C.c_void_p), ("d_pe", C.c_void_p), ("d_reads", C.c_void_p), ("d_offs", C.c_void_p),
+                ("d_lens", C.c_void_p), ("names", SamNames)]
+
+
 class Counters(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_lookup", C.c_uint64), ("n_probe", C.c_uint64), ("n_cand", C.c_uint64),
                 ("n_slow", C.c_uint64), ("n_bases", C.c_uint64)]
@@ -113,6 +126,8 @@ ABI_SYMBOLS = [
     "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",
     "k4_assign_multi_dev", "k4_align_reads_ext_batch", "k4_align_reads_ext_batch_dev", "k4_kalign_ext_batch",
     "k4_kalign_ext_batch_dev", "k4_auto_trim_flanks_dev", "k4_remove_orphan_juncts_dev", "k4_format_sam_ext_dev",
+    "k4_pipeline_open", "k4_pipeline_acquire", "k4_pipeline_submit", "k4_pipeline_submit_host", "k4_pipeline_wait_aligned",
+    "k4_pipeline_format", "k4_pipeline_next_sam", "k4_pipeline_read_sam", "k4_pipeline_close",
 ]
 
 
@@ -183,6 +198,16 @@ def lib():
     L.k4_remove_orphan_juncts_dev.argtypes = [vp, u32, i64, C.c_int32, vp, vp, vp, C.POINTER(C.c_int64), vp]
     L.k4_format_sam_ext_dev.argtypes = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(SamNames), C.POINTER(vp),
                                         C.POINTER(u64), C.POINTER(SamStats), vp, vp]
+    L.k4_pipeline_open.argtypes = [vp, C.POINTER(PipelineParams), C.POINTER(vp)]
+    L.k4_pipeline_acquire.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u64)]
+    L.k4_pipeline_submit.argtypes = [vp, i32, u64, i32]
+    L.k4_pipeline_submit_host.argtypes = [vp, i32, vp, u64, i32]
+    L.k4_pipeline_wait_aligned.argtypes = [vp, C.POINTER(PipelineView)]
+    L.k4_pipeline_format.argtypes = [vp, C.POINTER(SamStats), vp, C.POINTER(u64)]
+    L.k4_pipeline_next_sam.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.k4_pipeline_read_sam.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.k4_pipeline_close.argtypes = [vp]
+    L.k4_pipeline_close.restype = None
     L.k4_free_device.argtypes = [vp]
     L.k4_free_device.restype = None
     L.k4_alloc_device.argtypes = [vp, u64, C.POINTER(vp)]
@@ -539,6 +564,66 @@ class SfxIndex:
                                                            d_seg2.data_ptr(), C.byref(c), 0))
                 cnt[key] = c.value
         return (d_rr.cpu().numpy().view(RESULT_DTYPE), d_hits.cpu().numpy().view(HIT_DTYPE).reshape(n, max_ml), cnt)
+
+    def pipeline_sam(self, texts, kp, pe=None, min_len=50, max_len=500, chunk_bytes=0, ring=False, out=None):
+        """host text (bytes-like / pinned tensors: one for SE, two for PE) -> SAM body through the overlapped pipeline.
+        ring=True feeds through acquire / submit (what k4align's reader threads do), else submit_host.  Returns (body or
+        number of bytes written into `out`, stats dict, view)."""
+        L = lib()
+        prm = PipelineParams()
+        prm.paired = 1 if len(texts) == 2 else 0
+        prm.kp = kp
+        if pe is not None:
+            prm.pe = pe
+        prm.min_len, prm.max_len, prm.chunk_bytes = min_len, max_len, chunk_bytes
+        bufs = []
+        for e, t in enumerate(texts):
+            if hasattr(t, "data_ptr"):
+                bufs.append((t.data_ptr(), t.numel(), t))
+            else:
+                a = np.frombuffer(bytes(t), dtype=np.uint8)
+                bufs.append((a.ctypes.data, len(a), a))
+            prm.expect_text_bytes[e] = bufs[-1][1]
+        pl = C.c_void_p()
+        self._ck(L.k4_pipeline_open(self.h, C.byref(prm), C.byref(pl)))
+        try:
+            if ring:
+                pos = [0] * len(bufs)
+                done = [False] * len(bufs)
+                while not all(done):
+                    for e, (ptr, n, _) in enumerate(bufs):
+                        if done[e]:
+                            continue
+                        b, cap = C.c_void_p(), C.c_uint64()
+                        self._ck(L.k4_pipeline_acquire(pl, e, C.byref(b), C.byref(cap)))
+                        ln = min(cap.value, n - pos[e])
+                        C.memmove(b.value, ptr + pos[e], ln)
+                        pos[e] += ln
+                        done[e] = pos[e] == n
+                        self._ck(L.k4_pipeline_submit(pl, e, ln, 1 if done[e] else 0))
+            else:
+                for e, (ptr, n, _) in enumerate(bufs):
+                    self._ck(L.k4_pipeline_submit_host(pl, e, ptr, n, 1))
+            view = PipelineView()
+            self._ck(L.k4_pipeline_wait_aligned(pl, C.byref(view)))
+            stats, nbytes = SamStats(), C.c_uint64()
+            self._ck(L.k4_pipeline_format(pl, C.byref(stats), None, C.byref(nbytes)))
+            st = {"nar": list(stats.nar), "plus": stats.plus, "minus": stats.minus, "n_lines": stats.n_lines,
+                  "n_units": view.n_units, "n_under": view.n_under, "n_over": view.n_over, "sam_bytes": nbytes.value}
+            if out is not None:
+                got = C.c_uint64()
+                self._ck(L.k4_pipeline_read_sam(pl, out.data_ptr(), out.numel(), C.byref(got)))
+                return got.value, st, None
+            parts = []
+            while True:
+                p, n = C.c_void_p(), C.c_uint64()
+                self._ck(L.k4_pipeline_next_sam(pl, C.byref(p), C.byref(n)))
+                if n.value == 0:
+                    break
+                parts.append(C.string_at(p.value, n.value))
+            return b"".join(parts), st, None
+        finally:
+            L.k4_pipeline_close(pl)
 
     # -- the hot path (device buffers; pointers are ints, e.g. torch.Tensor.data_ptr()) -------------------------
     def kalign_pe_batch_dev(self, params, pe_params, n_pairs, max_read_len, d_reads, d_offs, d_lens, d_out, stream=0):

@@ -227,11 +227,8 @@ void worker_main(k4_pipeline* pl) {
         if (j.buf >= 0) rc = k4_check_hip(ix, hipEventRecord(E.ring[(size_t)j.buf].ev, pl->s_in), "event");
       }
     }
-    if (j.final_chunk) E.final_seen = true;
     // 2. ... while everything that had arrived before it is parsed and aligned (the copy stream runs on its own)
     if (rc == K4_OK) rc = parse_more(pl, j.end);
-    bool all_final = true;
-    for (int e = 0; e < pl->n_ends; e++) all_final &= pl->end[e].final_seen;
     if (rc == K4_OK) rc = align_more(pl, false);
     // 3. the chunk just sent becomes parseable: everything up to here is behind up_ev
     if (rc == K4_OK && j.bytes) {
@@ -239,6 +236,9 @@ void worker_main(k4_pipeline* pl) {
       if (rc == K4_OK) rc = k4_check_hip(ix, hipEventRecord(E.up_ev, pl->s_in), "event");
       E.uploaded = E.text.used;
     }
+    if (j.final_chunk) E.final_seen = true;  // (only now: the text parsed above was not the end of the input yet)
+    bool all_final = true;
+    for (int e = 0; e < pl->n_ends; e++) all_final &= pl->end[e].final_seen;
     if (j.buf >= 0) {  // the ring buffer is free once its copy has completed: acquire() waits on the event
       std::lock_guard<std::mutex> lk(pl->m);
       E.ring[(size_t)j.buf].in_flight = false;
