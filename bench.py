@@ -524,12 +524,12 @@ class GpuEngine:
             if best is None or dt < best[0]:
                 best = (dt, got, st)
         dt, got, st = best
+        lines = int((h_sam[:got] == 10).sum().item()) if got < (4 << 30) else None
         # the same bytes over PCIe alone, pinned both ways
         d_buf = torch.empty(max(T, got), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter(); d_buf[:T].copy_(h_text, non_blocking=True); torch.cuda.synchronize(); t_up = time.perf_counter() - t0
         t0 = time.perf_counter(); h_sam[:got].copy_(d_buf[:got], non_blocking=True); torch.cuda.synchronize(); t_dn = time.perf_counter() - t0
-        lines = int((h_sam[:got] == 10).sum().item()) if got < (4 << 30) else None
         del d_buf
         return {"host_text_to_host_sam_Mreads_s": n / dt / 1e6, "reads": n, "seconds": dt, "text_in_GB": T / 1e9, "sam_out_GB": got / 1e9,
                 "pcie_h2d_GBps": T / t_up / 1e9, "pcie_d2h_GBps": got / t_dn / 1e9,

@@ -176,6 +176,20 @@ int k4_open_device(uint64_t concat_len, uint32_t sfx_el_size, const void* d_seq,
                    uint32_t n_entries, const k4_entry* entries, const char* dataset, int device, int kmer_k,
                    k4_index** out);
 void k4_close(k4_index* ix);
+/* k4_sfx_map / k4_sfx_unmap <- CSfxArray::Disk2Hdr / Disk2Entries (SfxArray.cpp:629-825): the .sfx file mapped read-only with
+ * its tables decoded, for callers that place the index themselves (k4_open_host, or libk4comm's broadcast over xGMI) */
+typedef struct {
+  const void* map; size_t map_len;      /* the mapping (owned; k4_sfx_unmap releases it and `entries`) */
+  uint64_t concat_len; uint32_t sfx_el_size, n_entries;
+  k4_entry* entries;
+  const uint8_t* seq;                   /* concat_len bytes, one etSeqBase per base, EOS separators */
+  const uint8_t* sa;                    /* concat_len * sfx_el_size bytes */
+  const uint8_t* header;                /* tsSfxHeaderV3, 1224 bytes */
+  char dataset[81];
+} k4_sfx_file;
+int k4_sfx_map(const char* sfx_path, k4_sfx_file* out);
+void k4_sfx_unmap(k4_sfx_file* f);
+int k4_set_raw_header(k4_index* ix, const void* hdr_1224); /* the header an index opened from parts reports / writes */
 const char* k4_last_error(const k4_index* ix);            /* <- CErrorCodes::GetErrMsg, ErrorCodes.h:99-113 */
 const char* k4_global_error(void);                        /* error text when no index handle exists yet */
 int k4_info(const k4_index* ix, k4_info_t* out);          /* <- GetNumEntries/GetTotSeqsLen/GetSfxHeader */

@@ -127,7 +127,8 @@ ABI_SYMBOLS = [
     "k4_assign_multi_dev", "k4_align_reads_ext_batch", "k4_align_reads_ext_batch_dev", "k4_kalign_ext_batch",
     "k4_kalign_ext_batch_dev", "k4_auto_trim_flanks_dev", "k4_remove_orphan_juncts_dev", "k4_format_sam_ext_dev",
     "k4_pipeline_open", "k4_pipeline_acquire", "k4_pipeline_submit", "k4_pipeline_submit_host", "k4_pipeline_wait_aligned",
-    "k4_pipeline_format", "k4_pipeline_next_sam", "k4_pipeline_read_sam", "k4_pipeline_close",
+    "k4_pipeline_format", "k4_pipeline_next_sam", "k4_pipeline_read_sam", "k4_pipeline_close", "k4_sfx_map", "k4_sfx_unmap",
+    "k4_set_raw_header",
 ]
 
 

@@ -468,9 +468,10 @@ static T rd(const uint8_t* p) {
   return v;
 }
 
-extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out) {
-  if (!path || !*path || !out) return K4_ERR_PARAMS;
-  *out = nullptr;
+// the .sfx container mapped read-only, its tables decoded (CSfxArray::Disk2Hdr / Disk2Entries, SfxArray.cpp:629-825)
+extern "C" int k4_sfx_map(const char* path, k4_sfx_file* o) {
+  if (!path || !*path || !o) return K4_ERR_PARAMS;
+  memset(o, 0, sizeof(*o));
   int fd = open(path, O_RDONLY);
   if (fd < 0) {
     k4_set_global_error("unable to open %s", path);
@@ -516,9 +517,8 @@ extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out)
     k4_set_global_error("%s: inconsistent header (blocks=%u)", path, n_blocks);
     return done(K4_ERR_FILE_ACCESS);
   }
-  char dataset[81];
-  memcpy(dataset, f + 52, 80);
-  dataset[80] = 0;
+  memcpy(o->dataset, f + 52, 80);
+  o->dataset[80] = 0;
   const uint8_t* b = f + block_ofs;
   uint64_t n = rd<uint64_t>(b + 8);
   uint32_t el = rd<uint32_t>(b + 16);
@@ -532,11 +532,11 @@ extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out)
     k4_set_global_error("%s: entries block truncated", path);
     return done(K4_ERR_FILE_ACCESS);
   }
-  std::vector<k4_entry> ents(ne);
+  k4_entry* ents = (k4_entry*)calloc(ne ? ne : 1, sizeof(k4_entry));
+  if (!ents) return done(K4_ERR_MEM);
   for (uint32_t i = 0; i < ne; i++) {
     const uint8_t* p = e + 8 + (size_t)i * 111;
     k4_entry& d = ents[i];
-    memset(&d, 0, sizeof(d));
     d.entry_id = rd<uint32_t>(p);
     d.fblock_id = rd<uint32_t>(p + 4);
     memcpy(d.name, p + 8, 80);
@@ -545,9 +545,34 @@ extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out)
     d.start_ofs = rd<uint64_t>(p + 95);
     d.end_ofs = rd<uint64_t>(p + 103);
   }
-  int rc = k4_open_host(n, el, b + 20, b + 20 + n, ne, ents.data(), dataset, device, kmer_k, out);
-  if (rc == K4_OK && *out) (*out)->raw_header.assign(f, f + 1224);
-  return done(rc);
+  o->map = f; o->map_len = len; o->concat_len = n; o->sfx_el_size = el; o->n_entries = ne; o->entries = ents;
+  o->seq = b + 20; o->sa = b + 20 + n; o->header = f;
+  return K4_OK;
+}
+extern "C" void k4_sfx_unmap(k4_sfx_file* o) {
+  if (!o) return;
+  if (o->map) munmap((void*)o->map, o->map_len);
+  free(o->entries);
+  memset(o, 0, sizeof(*o));
+}
+
+extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out) {
+  if (!out) return K4_ERR_PARAMS;
+  *out = nullptr;
+  k4_sfx_file m;
+  int rc = k4_sfx_map(path, &m);
+  if (rc != K4_OK) return rc;
+  rc = k4_open_host(m.concat_len, m.sfx_el_size, m.seq, m.sa, m.n_entries, m.entries, m.dataset, device, kmer_k, out);
+  if (rc == K4_OK && *out) (*out)->raw_header.assign(m.header, m.header + 1224);
+  k4_sfx_unmap(&m);
+  return rc;
+}
+
+// the header text an index built from parts reports and writes (GetSfxHeader / k4_write_sfx): the file's own 1224 bytes
+extern "C" int k4_set_raw_header(k4_index* ix, const void* hdr_1224) {
+  if (!ix || !hdr_1224) return K4_ERR_PARAMS;
+  ix->raw_header.assign((const uint8_t*)hdr_1224, (const uint8_t*)hdr_1224 + 1224);
+  return K4_OK;
 }
 
 extern "C" void k4_close(k4_index* ix) {

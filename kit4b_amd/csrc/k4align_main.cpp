@@ -27,7 +27,11 @@
 #include <queue>
 #include <string>
 #include <vector>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include "../../include/k4comm.h"
 #include "../../include/k4sfx.h"
+#include "k4_merge.h"
 
 namespace {
 
@@ -42,9 +46,13 @@ struct Opts {
   double batch_mb = 0;              // -b <MB>: stream the input, this much text per file per batch (0: the whole input at once)
   int shard = 0, n_shards = 1;      // -S i/N: this process aligns the i-th of N contiguous slices of the reads (one process per GPU)
   int gpu = 0;
+  std::vector<int> gpus;            // -G g0,g1,...: one rank process per listed GPU (RCCL over xGMI, libk4comm.so)
+  int rank = 0, n_ranks = 1;        // this process's place in a -G run
+  struct MultiShared* shared = nullptr;
+  int print_slices = 0;             // -W <n>: print the byte offsets -G would cut the reads files at for n ranks, and stop (no GPU needed)
   bool legacy = false;              // -Z: the serial whole-input path of round 1 (one batch, no overlap), kept for comparison
   int chunk_mb = 256;               // -B <MB>: size of one pinned upload buffer of the pipeline
-  int io_threads = 4;               // -t <n>: concurrent pread / pwrite calls per buffer
+  int io_threads = 8;               // -t <n>: concurrent pread / pwrite calls per buffer
 };
 
 struct Parsed {  // one reads file after k4_parse_fastx_dev: everything lives in HBM
@@ -257,12 +265,116 @@ int feed_end(k4_pipeline* pl, int end, const std::vector<std::string>& files, in
   return rc;
 }
 
+
+// ---- k4align -G: one rank process per GPU ---------------------------------------------------------------------------------------
+#define K4_MAX_RANKS 64
+struct MultiShared {  // an anonymous shared mapping the parent creates before it forks the ranks
+  uint8_t id[K4_COMM_ID_BYTES];
+  std::atomic<int> id_ready, slices_ready, failed;
+  uint64_t slice_off[2][K4_MAX_RANKS + 1];  // byte offsets of the ranks' contiguous record slices in each reads file
+  uint64_t n_records;
+};
+
+// Byte offsets of the records r * R / N (r = 0..N) of an uncompressed FASTA / FASTQ file: reads are independent units, every
+// rank takes one contiguous slice (pairs stay together: both files are cut at the same record numbers).  Two parallel passes
+// over the mapped file: record starts per range, then the positions of the N - 1 inner boundaries.
+bool slice_records(const std::string& path, int n_ranks, uint64_t want_records, uint64_t* offs, uint64_t* n_records, int nt) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  const uint64_t len = file_size(path);
+  if (len == 0) { close(fd); for (int r = 0; r <= n_ranks; r++) offs[r] = 0; *n_records = 0; return true; }
+  const uint8_t* t = (const uint8_t*)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (t == MAP_FAILED) return false;
+  const bool fastq = t[0] == '@';
+  // a "mark" is what starts a record: FASTA -- a '>' at the start of a line; FASTQ -- every 4th line start
+  auto count = [&](uint64_t a, uint64_t b) -> uint64_t {  // FASTA: header lines starting in [a, b); FASTQ: newlines in [a, b)
+    uint64_t c = 0;
+    if (fastq) {
+      const uint8_t* p = t + a;
+      while (p < t + b) { const void* q = memchr(p, '\n', (size_t)(t + b - p)); if (!q) break; c++; p = (const uint8_t*)q + 1; }
+    } else {
+      for (uint64_t p = a; p < b;) {
+        const void* q = memchr(t + p, '>', (size_t)(b - p));
+        if (!q) break;
+        const uint64_t at = (uint64_t)((const uint8_t*)q - t);
+        if (at == 0 || t[at - 1] == '\n') c++;
+        p = at + 1;
+      }
+    }
+    return c;
+  };
+  std::vector<uint64_t> part((size_t)nt + 1, 0);
+  {
+    std::vector<std::thread> th;
+    for (int k = 0; k < nt; k++) th.emplace_back([&, k] { part[(size_t)k + 1] = count(len * k / nt, len * (k + 1) / nt); });
+    for (std::thread& x : th) x.join();
+  }
+  for (int k = 0; k < nt; k++) part[(size_t)k + 1] += part[(size_t)k];
+  uint64_t R;
+  if (fastq) { const uint64_t lines = part[(size_t)nt] + (t[len - 1] != '\n' ? 1 : 0); R = lines / 4; }
+  else R = part[(size_t)nt];
+  if (want_records != UINT64_MAX && R != want_records) { munmap((void*)t, len); *n_records = R; return false; }
+  *n_records = R;
+  offs[0] = 0;
+  offs[n_ranks] = len;
+  for (int r = 1; r < n_ranks; r++) {
+    const uint64_t rec = R * (uint64_t)r / (uint64_t)n_ranks;  // the slice of rank r starts at record `rec`
+    if (rec == 0) { offs[r] = 0; continue; }
+    if (rec >= R) { offs[r] = len; continue; }
+    // FASTQ: the byte behind newline number 4 * rec; FASTA: the position of header number rec (0-based)
+    const uint64_t target = fastq ? 4 * rec : rec + 1;  // the target-th mark (1-based) of the file
+    int k = 0;
+    while (k + 1 < nt && part[(size_t)k + 1] < target) k++;
+    uint64_t seen = part[(size_t)k], p = len * k / nt;
+    const uint64_t end = len * (k + 1) / nt;
+    uint64_t at = len;
+    if (fastq) {
+      while (p < end) { const void* q = memchr(t + p, '\n', (size_t)(end - p)); if (!q) break; p = (uint64_t)((const uint8_t*)q - t) + 1; if (++seen == target) { at = p; break; } }
+    } else {
+      while (p < end) {
+        const void* q = memchr(t + p, '>', (size_t)(end - p));
+        if (!q) break;
+        const uint64_t a2 = (uint64_t)((const uint8_t*)q - t);
+        if ((a2 == 0 || t[a2 - 1] == '\n') && ++seen == target) { at = a2; break; }
+        p = a2 + 1;
+      }
+    }
+    offs[r] = at;
+  }
+  munmap((void*)t, len);
+  return true;
+}
+
+// the byte range [a, b) of one uncompressed file into the pipeline
+int feed_range(k4_pipeline* pl, int end, const std::string& path, uint64_t a, uint64_t b, int io_threads, double* secs_read) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return K4_ERR_OPEN_FILE;
+  double busy = 0;
+  uint64_t pos = a;
+  int rc = K4_OK;
+  do {
+    void* buf = nullptr;
+    uint64_t cap = 0;
+    if ((rc = k4_pipeline_acquire(pl, end, &buf, &cap)) != K4_OK) break;
+    const uint64_t len = std::min<uint64_t>(cap, b - pos);
+    auto t0 = std::chrono::steady_clock::now();
+    if (len && !pread_parallel(fd, pos, (uint8_t*)buf, len, io_threads)) { rc = K4_ERR_FILE_ACCESS; break; }
+    busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    pos += len;
+    rc = k4_pipeline_submit(pl, end, len, pos == b);
+  } while (rc == K4_OK && pos < b);
+  close(fd);
+  if (secs_read) *secs_read = busy;
+  return rc;
+}
+
 const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"};
 
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=4] [-Z] [-g gpu=0]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
 }  // namespace
@@ -292,87 +404,41 @@ struct GlibcRand {
 };
 static GlibcRand draws;
 
-int main(int argc, char** argv) {
-  Opts o;
-  for (int i = 1; i < argc; i++) {
-    std::string a = argv[i];
-    if (a.size() < 2 || a[0] != '-') { usage(); return 1; }
-    auto val = [&]() -> std::string { return a.size() > 2 ? a.substr(2) : (i + 1 < argc ? std::string(argv[++i]) : std::string()); };
-    switch (a[1]) {
-      case 'i': o.in1.push_back(val()); break;
-      case 'u': o.in2.push_back(val()); break;
-      case 'I': o.sfx = val(); break;
-      case 'o': o.out = val(); break;
-      case 's': o.max_subs = atoi(val().c_str()); break;
-      case 'e': o.min_edit = atoi(val().c_str()); break;
-      case 'm': o.pmode = atoi(val().c_str()); break;
-      case 'n': o.max_ns = atoi(val().c_str()); break;
-      case 'U': o.pe_mode = atoi(val().c_str()); break;
-      case 'd': o.pair_min = atoi(val().c_str()); break;
-      case 'D': o.pair_max = atoi(val().c_str()); break;
-      case 'E': o.pair_strand = 1; break;
-      case 'l': o.min_len = atoi(val().c_str()); break;
-      case 'L': o.max_len = atoi(val().c_str()); break;
-      case 'r': o.ml_mode = atoi(val().c_str()); break;
-      case 'R': o.max_multi = atoi(val().c_str()); break;
-      case 'c': o.min_chimeric = atoi(val().c_str()); break;
-      case 'a': o.micro_indel = atoi(val().c_str()); break;
-      case 'A': o.splice_junct = atoi(val().c_str()); break;
-      case 'x': o.min_flank_exacts = atoi(val().c_str()); break;
-      case 'X': o.clamp = true; break;
-      case 'N': o.best = true; break;
-      case 'S': { std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2) { usage(); return 1; } break; }
-      case 'g': o.gpu = atoi(val().c_str()); break;
-      case 'b': o.batch_mb = atof(val().c_str()); break;
-      case 'B': o.chunk_mb = std::max(1, atoi(val().c_str())); break;
-      case 't': o.io_threads = std::max(1, atoi(val().c_str())); break;
-      case 'Z': o.legacy = true; break;
-      case 'T': case 'F': (void)val(); break;  // accepted and ignored (threads, log file)
-      default: usage(); return 1;
-    }
-  }
-  if (o.in1.empty() || o.sfx.empty() || o.out.empty()) { usage(); return 1; }
-  const bool pe = !o.in2.empty();
-  // multi-loci modes (KAlignerCL.cpp:686-707): 0 slough, 1 statistics only, 5 report every locus up to -R; the modes that
-  // pick or cluster one locus (2 random, 3/4 AssignMultiMatches) are not part of this path
-  if (o.ml_mode < 0 || o.ml_mode > 5) { fprintf(stderr, "k4align: -r%d is not supported (0..5 are)\n", o.ml_mode); return 1; }
-  if (o.ml_mode != 0 && pe) { fprintf(stderr, "k4align: multiloci processing '-r%d' not supported in paired end processing\n", o.ml_mode); return 1; }
-  if (o.n_shards < 1 || o.shard < 0 || o.shard >= o.n_shards) { fprintf(stderr, "k4align: -S i/N needs 0 <= i < N\n"); return 1; }
-  if ((o.clamp || o.best) && o.ml_mode != 5) { fprintf(stderr, "k4align: -X / -N are supported together with -r5 only\n"); return 1; }
-  int max_ml = 1;
-  if (o.ml_mode != 0) {
-    max_ml = o.max_multi ? o.max_multi : 5;  // cDfltMaxMultiHits
-    const int lim = o.ml_mode == 5 ? 100000 : 500;  // cMaxAllHits / cMaxMultiHits
-    if (max_ml < 2 || max_ml > lim) { fprintf(stderr, "k4align: -R%d outside of range 2..%d\n", max_ml, lim); return 1; }
-  }
-  // the optional AlignReads phases and the stages they bring with them: the same argument rules as kalign (KAlignerCL.cpp:545-569,
-  // 667-761,823-830)
-  o.min_chimeric = abs(o.min_chimeric);
-  if (o.min_chimeric != 0 && (o.min_chimeric < 15 || o.min_chimeric > 99)) { fprintf(stderr, "k4align: minimum chimeric length percentage '-c%d' specified outside of range 15..99\n", o.min_chimeric); return 1; }
-  if (o.micro_indel < 0 || o.micro_indel > 20) { fprintf(stderr, "k4align: microInDel length maximum '-a%d' specified outside of range 0..20\n", o.micro_indel); return 1; }
-  if (o.splice_junct != 0 && (o.splice_junct < 25 || o.splice_junct > 100000)) { fprintf(stderr, "k4align: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000\n", o.splice_junct); return 1; }
-  if (o.min_flank_exacts < 0 || o.min_flank_exacts > 7) { fprintf(stderr, "k4align: max flank trimming '-x%d' specified outside of range 0..7\n", o.min_flank_exacts); return 1; }
-  if (pe && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDel '-a' / splice junction '-A' processing not supported in paired end processing\n"); return 1; }
-  if (pe && o.min_chimeric) { fprintf(stderr, "k4align: chimeric trimming '-c' is not supported in paired end processing yet (the mate rescue's trimmed branch, SfxArray.cpp:8616-8766)\n"); return 3; }
-  if (o.ml_mode == 5 && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDels / splice junctions not supported when reporting multiloci alignments '-r5'\n"); return 1; }
-  if (o.min_chimeric && (o.best || o.ml_mode == 3 || o.ml_mode == 4)) { fprintf(stderr, "k4align: chimeric read processing cannot be combined with -N / -r3 / -r4\n"); return 1; }
-  if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830
-  if (o.min_flank_exacts > 7) o.min_flank_exacts = 7;
-  if (pe && o.pe_mode == 0) o.pe_mode = 1;  // kalign: -u without -U defaults to orphan recovery
-  if (!pe) o.pe_mode = 0;
+static int run_multi_gpu(Opts& o, bool pe, int max_ml);
 
+// one process, one GPU: the whole run, or rank o.rank of a -G run
+static int run_rank(Opts& o, const bool pe, const int max_ml) {
   auto t0 = std::chrono::steady_clock::now();
   k4_index* ix = nullptr;
-  int rc = k4_open(o.sfx.c_str(), o.gpu, 0, &ix);
-  if (rc != K4_OK) { fprintf(stderr, "k4align: unable to load '%s': %s (%d)\n", o.sfx.c_str(), k4_global_error(), rc); return 2; }
+  k4_comm* comm = nullptr;
+  int rc;
+  const bool multi = o.n_ranks > 1 || o.shared;
+  const bool chatty = o.rank == 0;  // only rank 0 of a -G run reports
+  if (multi) {
+    // the communicator id: rank 0 makes it, the others pick it up from the shared mapping
+    MultiShared* sh = o.shared;
+    if (o.rank == 0) {
+      if ((rc = k4_comm_unique_id(sh->id)) != K4_OK) { fprintf(stderr, "k4align: ncclGetUniqueId failed\n"); sh->failed = 1; return 2; }
+      sh->id_ready = 1;
+    } else
+      while (!sh->id_ready.load()) { if (sh->failed.load()) return 2; usleep(1000); }
+    if ((rc = k4_comm_init(o.gpu, o.rank, o.n_ranks, sh->id, &comm)) != K4_OK) { fprintf(stderr, "k4align: rank %d: RCCL communicator failed (%d)\n", o.rank, rc); sh->failed = 1; return 2; }
+    // rank 0 reads the .sfx once; sequence + suffix array reach the peers over xGMI; every rank builds its own tables
+    rc = k4_comm_open_index(comm, o.rank == 0 ? o.sfx.c_str() : nullptr, 0, &ix);
+    if (rc != K4_OK) { fprintf(stderr, "k4align: rank %d: index broadcast failed: %s (%d)\n", o.rank, k4_comm_last_error(comm), rc); sh->failed = 1; return 2; }
+  } else {
+    rc = k4_open(o.sfx.c_str(), o.gpu, 0, &ix);
+    if (rc != K4_OK) { fprintf(stderr, "k4align: unable to load '%s': %s (%d)\n", o.sfx.c_str(), k4_global_error(), rc); return 2; }
+  }
   k4_info_t info;
   k4_info(ix, &info);
   // SetMaxIter by sensitivity, KAligner.cpp:373-388
   k4_set_max_iter(ix, o.pmode == 2 ? 20000 : o.pmode == 1 ? 10000 : o.pmode == 0 ? 5000 : 2500);
   int slides = 0;
   const int mcl = k4_min_core_len(ix, o.pmode, &slides);
-  fprintf(stderr, "k4align: index '%s' %u sequences, %llu bp; minimum core size %dbp\n", info.dataset, info.n_entries,
-          (unsigned long long)info.tot_seqs_len, mcl);
+  if (chatty)
+    fprintf(stderr, "k4align: index '%s' %u sequences, %llu bp; minimum core size %dbp%s\n", info.dataset, info.n_entries,
+            (unsigned long long)info.tot_seqs_len, mcl, multi ? " (read once, sent to the other GPUs over xGMI)" : "");
   auto t_open = std::chrono::steady_clock::now();
 
   if ((o.ml_mode == 3 || o.ml_mode == 4) && (o.batch_mb > 0 || o.n_shards > 1)) {
@@ -568,8 +634,28 @@ int main(int argc, char** argv) {
     int rc_end[2] = {K4_OK, K4_OK};
     double rd[2] = {0, 0};
     std::thread t2;
-    if (pe) t2 = std::thread([&] { rc_end[1] = feed_end(pl, 1, o.in2, o.io_threads, &rd[1]); });
-    rc_end[0] = feed_end(pl, 0, o.in1, o.io_threads, &rd[0]);
+    if (multi) {
+      // reads are independent units: rank r aligns the r-th contiguous slice of the records (pairs stay together).  Rank 0
+      // finds the slice boundaries (one pass over the files), every rank then reads only its own byte range
+      MultiShared* sh = o.shared;
+      if (o.rank == 0) {
+        uint64_t R = 0, R2 = 0;
+        bool ok = slice_records(o.in1[0], o.n_ranks, UINT64_MAX, sh->slice_off[0], &R, o.io_threads);
+        if (ok && pe) {
+          ok = slice_records(o.in2[0], o.n_ranks, R, sh->slice_off[1], &R2, o.io_threads);
+          if (!ok && R2 != R) fprintf(stderr, "k4align: the PE1 and PE2 files hold different numbers of reads (%llu, %llu)\n", (unsigned long long)R, (unsigned long long)R2);
+        }
+        if (!ok) { fprintf(stderr, "k4align: unable to cut the reads into slices\n"); sh->failed = 1; return 2; }
+        sh->n_records = R;
+        sh->slices_ready = 1;
+      } else
+        while (!sh->slices_ready.load()) { if (sh->failed.load()) return 2; usleep(1000); }
+      if (pe) t2 = std::thread([&] { rc_end[1] = feed_range(pl, 1, o.in2[0], sh->slice_off[1][o.rank], sh->slice_off[1][o.rank + 1], o.io_threads, &rd[1]); });
+      rc_end[0] = feed_range(pl, 0, o.in1[0], sh->slice_off[0][o.rank], sh->slice_off[0][o.rank + 1], o.io_threads, &rd[0]);
+    } else {
+      if (pe) t2 = std::thread([&] { rc_end[1] = feed_end(pl, 1, o.in2, o.io_threads, &rd[1]); });
+      rc_end[0] = feed_end(pl, 0, o.in1, o.io_threads, &rd[0]);
+    }
     if (pe) t2.join();
     s_read = std::max(rd[0], rd[1]);
     for (int e = 0; e < 2; e++)
@@ -619,13 +705,24 @@ int main(int argc, char** argv) {
   f2.close();
 
   // ---- statistics (ReportAlignStats) ------------------------------------------------------------------------------
+  const uint64_t my_lines = tot.n_lines;
+  if (comm) {  // the final aligned-read count/merge: one all-reduce of the tallies (north_star: the only collective on the path)
+    uint64_t t[26];
+    for (int k = 0; k < 20; k++) t[k] = tot.nar[k];
+    t[20] = tot.plus; t[21] = tot.minus; t[22] = tot.n_lines; t[23] = n_under; t[24] = n_over; t[25] = n_units;
+    if ((rc = k4_comm_allreduce_sum_u64(comm, t, 26)) != K4_OK) { fprintf(stderr, "k4align: rank %d: all-reduce failed: %s\n", o.rank, k4_comm_last_error(comm)); return 2; }
+    for (int k = 0; k < 20; k++) tot.nar[k] = t[k];
+    tot.plus = t[20]; tot.minus = t[21]; tot.n_lines = t[22]; n_under = t[23]; n_over = t[24]; n_units = t[25];
+  }
   const uint64_t n_loaded = (uint64_t)(pe ? 2 : 1) * (n_units - n_under - n_over);
-  fprintf(stderr, "k4align: From %llu source reads there are %llu accepted alignments, %llu on '+' strand, %llu on '-' strand\n",
-          (unsigned long long)n_loaded, (unsigned long long)tot.nar[1], (unsigned long long)tot.plus, (unsigned long long)tot.minus);
-  if (n_under || n_over)
-    fprintf(stderr, "k4align: %llu under length and %llu over length reads were sloughed\n", (unsigned long long)n_under,
-            (unsigned long long)n_over);
-  for (int k = 0; k < 20; k++) fprintf(stderr, "k4align:    %llu (%s)\n", (unsigned long long)tot.nar[k], kNarAbbr[k]);
+  if (chatty) {
+    fprintf(stderr, "k4align: From %llu source reads there are %llu accepted alignments, %llu on '+' strand, %llu on '-' strand\n",
+            (unsigned long long)n_loaded, (unsigned long long)tot.nar[1], (unsigned long long)tot.plus, (unsigned long long)tot.minus);
+    if (n_under || n_over)
+      fprintf(stderr, "k4align: %llu under length and %llu over length reads were sloughed\n", (unsigned long long)n_under,
+              (unsigned long long)n_over);
+    for (int k = 0; k < 20; k++) fprintf(stderr, "k4align:    %llu (%s)\n", (unsigned long long)tot.nar[k], kNarAbbr[k]);
+  }
 
   // ---- SAM file: header here, body as formatted on the device ----------------------------------------------------------
   auto tw = now();
@@ -634,7 +731,9 @@ int main(int argc, char** argv) {
   static char iobuf[1 << 22];
   setvbuf(fp, iobuf, _IOFBF, sizeof(iobuf));
   fprintf(fp, "@HD\tVN:1.4\tSO:coordinate\n");
-  const bool all_chroms = info.n_entries <= 10000;  // m_MaxRptSAMSeqsThres, KAligner.cpp:5785-5821
+  // m_MaxRptSAMSeqsThres, KAligner.cpp:5785-5821: with more sequences only those that were hit are declared -- a shard (-S, -G)
+  // declares all of them and leaves that rule to the merge, which sees every shard's records
+  const bool all_chroms = info.n_entries <= 10000 || o.n_shards > 1 || multi;
   std::map<std::string, long> order;
   for (uint32_t c = 1; c <= info.n_entries; c++) {
     k4_entry e;
@@ -647,6 +746,7 @@ int main(int argc, char** argv) {
     fflush(fp);
     const int fd = fileno(fp);
     uint64_t fpos = (uint64_t)ftello(fp);
+    if (ftruncate(fd, (off_t)(fpos + pl_sam_bytes)) != 0) { /* (the size is only a hint for the file system) */ }
     for (;;) {
       const void* ptr = nullptr;
       uint64_t len = 0;
@@ -715,11 +815,165 @@ int main(int argc, char** argv) {
     }
     for (size_t i = 0; i < parts.size(); i++) { fclose(src[i].f); remove(parts[i].c_str()); }
   }
-  fclose(fp);
+  fflush(fp);
+  const bool wfail = ferror(fp) != 0;
+  if (fclose(fp) != 0 || wfail) { fprintf(stderr, "k4align: write to %s failed\n", o.out.c_str()); return 5; }
   s_write += secs(tw, now());
-  fprintf(stderr, "k4align: %llu alignments written to %s (%zu batch%s); index %.2fs, read files %.2fs, upload+parse %.2fs, align+format %.2fs, write %.2fs\n",
-          (unsigned long long)tot.n_lines, o.out.c_str(), parts.empty() ? (size_t)1 : parts.size(), parts.size() > 1 ? "es" : "",
-          secs(t0, t_open), s_read, s_parse, s_align, s_write);
+  fprintf(stderr, "k4align: %s%llu alignments written to %s (%zu batch%s); index %.2fs, read files %.2fs, upload+parse %.2fs, align+format %.2fs, write %.2fs\n",
+          multi ? ("rank " + std::to_string(o.rank) + ": ").c_str() : "", (unsigned long long)my_lines, o.out.c_str(),
+          parts.empty() ? (size_t)1 : parts.size(), parts.size() > 1 ? "es" : "", secs(t0, t_open), s_read, s_parse, s_align, s_write);
+  if (comm) { k4_comm_barrier(comm); }
   k4_close(ix);
+  if (comm) k4_comm_close(comm);
   return 0;
+}
+
+// k4align -G g0,g1,...: the parent forks one rank per GPU BEFORE anything touches HIP and only waits and merges; the ranks
+// form an RCCL communicator (the id travels through a shared anonymous mapping), rank 0 reads the .sfx once and every rank
+// receives sequence + suffix array over xGMI (k4_comm_open_index), each aligns its contiguous slice of the reads, the NAR
+// tallies are summed with one all-reduce, and the parent merges the ranks' coordinate-sorted shards.
+static int run_multi_gpu(Opts& o, bool pe, int max_ml) {
+  const int N = (int)o.gpus.size();
+  if (N > K4_MAX_RANKS) { fprintf(stderr, "k4align: at most %d GPUs\n", K4_MAX_RANKS); return 1; }
+  if (o.batch_mb > 0 || o.n_shards > 1 || o.legacy) { fprintf(stderr, "k4align: -G cannot be combined with -b, -S or -Z\n"); return 1; }
+  if (o.ml_mode == 2 || o.ml_mode == 3 || o.ml_mode == 4 || o.micro_indel || o.splice_junct) {
+    fprintf(stderr, "k4align: -r2 / -r3 / -r4 / -a / -A look at all reads of the run; they cannot be combined with -G\n");
+    return 1;
+  }
+  if (o.in1.size() != 1 || (pe && o.in2.size() != 1)) { fprintf(stderr, "k4align: -G takes one reads file per end\n"); return 1; }
+  for (const std::string& q : {o.in1[0], pe ? o.in2[0] : o.in1[0]})
+    if (is_gzip(q)) { fprintf(stderr, "k4align: -G cuts the reads file by record offsets: '%s' must be uncompressed\n", q.c_str()); return 1; }
+  MultiShared* sh = (MultiShared*)mmap(nullptr, sizeof(MultiShared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  if (sh == MAP_FAILED) { fprintf(stderr, "k4align: unable to map shared memory\n"); return 2; }
+  memset((void*)sh, 0, sizeof(*sh));
+  const std::string final_out = o.out;
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<pid_t> kids;
+  for (int r = 0; r < N; r++) {
+    const pid_t pid = fork();
+    if (pid < 0) { fprintf(stderr, "k4align: fork failed\n"); sh->failed = 1; break; }
+    if (pid == 0) {
+      o.rank = r; o.n_ranks = N; o.gpu = o.gpus[(size_t)r]; o.shared = sh;
+      o.out = final_out + ".rank" + std::to_string(r);
+      const int rc = run_rank(o, pe, max_ml);
+      if (rc != 0) sh->failed = 1;
+      fflush(nullptr);
+      _exit(rc);
+    }
+    kids.push_back(pid);
+  }
+  int worst = 0;
+  for (pid_t k : kids) {
+    int st = 0;
+    waitpid(k, &st, 0);
+    const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 9;
+    if (rc) worst = rc;
+  }
+  std::vector<std::string> shards;
+  for (int r = 0; r < N; r++) shards.push_back(final_out + ".rank" + std::to_string(r));
+  if (worst || sh->failed) {
+    for (const std::string& q : shards) remove(q.c_str());
+    fprintf(stderr, "k4align: a rank failed (%d)\n", worst);
+    return worst ? worst : 2;
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  unsigned long long n = 0;
+  const int rc = k4merge::merge_sam(shards, final_out, 10000, &n, "k4align");
+  for (const std::string& q : shards) remove(q.c_str());
+  if (rc) return rc;
+  fprintf(stderr, "k4align: %llu alignments from %d GPUs written to %s; ranks %.2fs, merge %.2fs\n", n, N, final_out.c_str(),
+          std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+  munmap((void*)sh, sizeof(*sh));
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  Opts o;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    if (a.size() < 2 || a[0] != '-') { usage(); return 1; }
+    auto val = [&]() -> std::string { return a.size() > 2 ? a.substr(2) : (i + 1 < argc ? std::string(argv[++i]) : std::string()); };
+    switch (a[1]) {
+      case 'i': o.in1.push_back(val()); break;
+      case 'u': o.in2.push_back(val()); break;
+      case 'I': o.sfx = val(); break;
+      case 'o': o.out = val(); break;
+      case 's': o.max_subs = atoi(val().c_str()); break;
+      case 'e': o.min_edit = atoi(val().c_str()); break;
+      case 'm': o.pmode = atoi(val().c_str()); break;
+      case 'n': o.max_ns = atoi(val().c_str()); break;
+      case 'U': o.pe_mode = atoi(val().c_str()); break;
+      case 'd': o.pair_min = atoi(val().c_str()); break;
+      case 'D': o.pair_max = atoi(val().c_str()); break;
+      case 'E': o.pair_strand = 1; break;
+      case 'l': o.min_len = atoi(val().c_str()); break;
+      case 'L': o.max_len = atoi(val().c_str()); break;
+      case 'r': o.ml_mode = atoi(val().c_str()); break;
+      case 'R': o.max_multi = atoi(val().c_str()); break;
+      case 'c': o.min_chimeric = atoi(val().c_str()); break;
+      case 'a': o.micro_indel = atoi(val().c_str()); break;
+      case 'A': o.splice_junct = atoi(val().c_str()); break;
+      case 'x': o.min_flank_exacts = atoi(val().c_str()); break;
+      case 'X': o.clamp = true; break;
+      case 'N': o.best = true; break;
+      case 'S': { std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2) { usage(); return 1; } break; }
+      case 'g': o.gpu = atoi(val().c_str()); break;
+      case 'G': { std::string v = val(); for (size_t q = 0; q < v.size();) { size_t e = v.find(',', q); if (e == std::string::npos) e = v.size(); o.gpus.push_back(atoi(v.substr(q, e - q).c_str())); q = e + 1; } break; }
+      case 'b': o.batch_mb = atof(val().c_str()); break;
+      case 'B': o.chunk_mb = std::max(1, atoi(val().c_str())); break;
+      case 't': o.io_threads = std::max(1, atoi(val().c_str())); break;
+      case 'Z': o.legacy = true; break;
+      case 'W': o.print_slices = atoi(val().c_str()); break;
+      case 'T': case 'F': (void)val(); break;  // accepted and ignored (threads, log file)
+      default: usage(); return 1;
+    }
+  }
+  if (o.print_slices > 0 && !o.in1.empty()) {  // the slice table of a -G run (host only)
+    uint64_t offs[2][K4_MAX_RANKS + 1], R = 0, R2 = 0;
+    if (o.print_slices > K4_MAX_RANKS) return 1;
+    if (!slice_records(o.in1[0], o.print_slices, UINT64_MAX, offs[0], &R, o.io_threads)) { fprintf(stderr, "k4align: unable to cut '%s'\n", o.in1[0].c_str()); return 2; }
+    if (!o.in2.empty() && !slice_records(o.in2[0], o.print_slices, R, offs[1], &R2, o.io_threads)) {
+      fprintf(stderr, "k4align: the PE1 and PE2 files hold different numbers of reads (%llu, %llu)\n", (unsigned long long)R, (unsigned long long)R2);
+      return 3;
+    }
+    printf("records %llu\n", (unsigned long long)R);
+    for (int e = 0; e < (o.in2.empty() ? 1 : 2); e++) {
+      printf("end %d", e);
+      for (int r = 0; r <= o.print_slices; r++) printf(" %llu", (unsigned long long)offs[e][r]);
+      printf("\n");
+    }
+    return 0;
+  }
+  if (o.in1.empty() || o.sfx.empty() || o.out.empty()) { usage(); return 1; }
+  const bool pe = !o.in2.empty();
+  // multi-loci modes (KAlignerCL.cpp:686-707): 0 slough, 1 statistics only, 5 report every locus up to -R; the modes that
+  // pick or cluster one locus (2 random, 3/4 AssignMultiMatches) are not part of this path
+  if (o.ml_mode < 0 || o.ml_mode > 5) { fprintf(stderr, "k4align: -r%d is not supported (0..5 are)\n", o.ml_mode); return 1; }
+  if (o.ml_mode != 0 && pe) { fprintf(stderr, "k4align: multiloci processing '-r%d' not supported in paired end processing\n", o.ml_mode); return 1; }
+  if (o.n_shards < 1 || o.shard < 0 || o.shard >= o.n_shards) { fprintf(stderr, "k4align: -S i/N needs 0 <= i < N\n"); return 1; }
+  if ((o.clamp || o.best) && o.ml_mode != 5) { fprintf(stderr, "k4align: -X / -N are supported together with -r5 only\n"); return 1; }
+  int max_ml = 1;
+  if (o.ml_mode != 0) {
+    max_ml = o.max_multi ? o.max_multi : 5;  // cDfltMaxMultiHits
+    const int lim = o.ml_mode == 5 ? 100000 : 500;  // cMaxAllHits / cMaxMultiHits
+    if (max_ml < 2 || max_ml > lim) { fprintf(stderr, "k4align: -R%d outside of range 2..%d\n", max_ml, lim); return 1; }
+  }
+  // the optional AlignReads phases and the stages they bring with them: the same argument rules as kalign (KAlignerCL.cpp:545-569,
+  // 667-761,823-830)
+  o.min_chimeric = abs(o.min_chimeric);
+  if (o.min_chimeric != 0 && (o.min_chimeric < 15 || o.min_chimeric > 99)) { fprintf(stderr, "k4align: minimum chimeric length percentage '-c%d' specified outside of range 15..99\n", o.min_chimeric); return 1; }
+  if (o.micro_indel < 0 || o.micro_indel > 20) { fprintf(stderr, "k4align: microInDel length maximum '-a%d' specified outside of range 0..20\n", o.micro_indel); return 1; }
+  if (o.splice_junct != 0 && (o.splice_junct < 25 || o.splice_junct > 100000)) { fprintf(stderr, "k4align: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000\n", o.splice_junct); return 1; }
+  if (o.min_flank_exacts < 0 || o.min_flank_exacts > 7) { fprintf(stderr, "k4align: max flank trimming '-x%d' specified outside of range 0..7\n", o.min_flank_exacts); return 1; }
+  if (pe && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDel '-a' / splice junction '-A' processing not supported in paired end processing\n"); return 1; }
+  if (pe && o.min_chimeric) { fprintf(stderr, "k4align: chimeric trimming '-c' is not supported in paired end processing yet (the mate rescue's trimmed branch, SfxArray.cpp:8616-8766)\n"); return 3; }
+  if (o.ml_mode == 5 && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDels / splice junctions not supported when reporting multiloci alignments '-r5'\n"); return 1; }
+  if (o.min_chimeric && (o.best || o.ml_mode == 3 || o.ml_mode == 4)) { fprintf(stderr, "k4align: chimeric read processing cannot be combined with -N / -r3 / -r4\n"); return 1; }
+  if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830
+  if (o.min_flank_exacts > 7) o.min_flank_exacts = 7;
+  if (pe && o.pe_mode == 0) o.pe_mode = 1;  // kalign: -u without -U defaults to orphan recovery
+  if (!pe) o.pe_mode = 0;
+
+  if (!o.gpus.empty()) return run_multi_gpu(o, pe, max_ml);
+  return run_rank(o, pe, max_ml);
 }

@@ -68,3 +68,21 @@ def test_product_does_not_reference_the_oracle():
                     continue
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "k4oracle" not in txt and "oracle_bindings" not in txt and "libk4ref" not in txt, (dp, fn)
+
+
+def test_comm_library_exports_its_header():
+    """include/k4comm.h (the RCCL side: index broadcast over xGMI, all-reduce of the tallies) <-> kit4b_amd/libk4comm.so"""
+    hdr = open(os.path.join(ROOT, "include", "k4comm.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(k4_comm_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) == 9
+    so = os.path.join(ROOT, "kit4b_amd", "libk4comm.so")
+    assert os.path.exists(so), "make -C kit4b_amd/csrc"
+    kit4b_amd.lib()  # libk4sfx.so first: libk4comm.so is linked against it
+    Lc = C.CDLL(so)
+    for s in declared:
+        assert hasattr(Lc, s), s
+    # RCCL is a dependency of this library only: the hot-path library stays free of it
+    import subprocess
+
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "kit4b_amd", "libk4sfx.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in needed and "rccl" in subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout

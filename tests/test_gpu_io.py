@@ -440,3 +440,37 @@ def test_k4align_several_input_files(golden_dir, tmp_path, case):
     p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-i", files[1],
                         "-i", str(tmp_path / "missing.fa")], capture_output=True, text=True, timeout=60)
     assert p.returncode != 0 and "unable to open" in p.stderr
+
+
+@pytest.mark.parametrize("case", ["se_s2", "pe_u1"])
+def test_k4align_rank_mode_over_rccl(golden_dir, tmp_path, case):
+    """`k4align -G 0`: the product form of the multi-GPU split with ONE rank (all this box has) -- the parent forks the rank
+    before HIP is touched, the rank forms an RCCL communicator, receives the index through k4_comm_open_index (rank 0 reads the
+    .sfx, ncclBroadcast of the geometry; the all-link exchange is empty with one rank), reads its record slice by byte
+    offsets, all-reduces the NAR tallies and writes a shard that the parent merges.  Same SAM as the reference's."""
+    import json
+    import lzma
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(golden_dir, "sam_cases.json")))
+
+    def unxz(name):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        return dst
+
+    files = ["-i", unxz("sam_%s.fa.xz" % case)] if case.startswith("se_") else \
+        ["-i", unxz("sam_%s_1.fa.xz" % case), "-u", unxz("sam_%s_2.fa.xz" % case)]
+    out = str(tmp_path / "o.sam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-G", "0"]
+                       + cases[case]["args"] + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "sent to the other GPUs over xGMI" in p.stderr and "from 1 GPUs written" in p.stderr
+    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    want = [l for l in lzma.open(os.path.join(golden_dir, "sam_%s.sam.xz" % case)).read().decode().splitlines() if not l.startswith("@PG")]
+    assert [l for l in got if l.startswith("@")] == [l for l in want if l.startswith("@")]
+    assert sorted(got) == sorted(want)
+    for name, n in cases[case]["nar"].items():
+        assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+    assert not os.path.exists(out + ".rank0")
