@@ -361,7 +361,9 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
 #pragma unroll
       for (int j = 0; j < PFN; j++) {
         if (j < cnt) {
-          if (!CAPTURE && j == 0 && first_group && tshift == 0) {
+          // (64-bit table: the first phase may have looked at a sub-bucket only, k + 2 bases deep -- what it noted holds for
+          // cores at least that long)
+          if (!CAPTURE && j == 0 && first_group && tshift == 0 && (sizeof(KT) == 4 || cl >= kk + 2)) {
             const uint64_t mv = ln.memo[s * K4_BS(NCH)];
             const int kind = (int)(mv >> 62), fm = (int)((mv >> 48) & 0x3FFF), mmv = (int)((mv >> 40) & 0xFF);
             if (kind == 1 || (kind == 2 && fm < cl)) continue;                   // nothing starts with this core
@@ -372,14 +374,23 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
             }
           }
           const uint64_t code = ln.chunk_at(s, oo[j]) >> (64 - 2 * kk);
-          k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j]);
+          uint64_t sub;
+          k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j], sub);
+          if (sizeof(KT) == 8 && tshift == 0 && cl >= kk + 2 && sub != K4_KTAB64_IRREGULAR) {
+            // straight to the suffixes that continue with the core's next two bases
+            uint32_t before, count;
+            k4d_ktab_sub(sub, (uint32_t)(ln.chunk_at(s, oo[j] + kk) >> 60), before, count);
+            if (before) ps0[j] = (KT)K4_KTAB64_MASK;  // pos0 is the whole bucket's first suffix, not this one's
+            lb0[j] += (KT)before;
+            lb1[j] = lb0[j] + (KT)count;
+          }
           if (CAPTURE && j == 0 && first_group && tshift == 0) {
             if (lb1[0] == lb0[0]) ln.memo[s * K4_BS(NCH)] = k4d_memo_pack(1, 0, 0, 0);
             else memo_pending = lb1[0] == lb0[0] + 1;
           }
           // a bucket of one suffix whose next bases already disagree with the core cannot hold a match: drop it here
-          if (tshift == 0 && lb1[j] == lb0[j] + 1 && cl > kk) {
-            const int nb = min(sizeof(KT) == 4 ? K4_SIG_BASES32 : K4_SIG_BASES64, cl - kk);
+          if (sizeof(KT) == 4 && tshift == 0 && lb1[j] == lb0[j] + 1 && cl > kk) {
+            const int nb = min(K4_SIG_BASES32, cl - kk);
             const uint32_t cb = (uint32_t)(ln.chunk_at(s, oo[j] + kk) >> 32);
             const uint32_t df = (cb ^ sig[j]) & (0xFFFFFFFFu << (32 - 2 * nb));
             if (df) {
@@ -397,7 +408,8 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       uint32_t touch = 0;
 #pragma unroll
       for (int j = 0; j < PFN; j++)
-        if (j < cnt && tshift == 0 && lb1[j] > lb0[j] && !(j == 0 && memo_hit)) touch |= ix.ref2[((int64_t)ps0[j] - oo[j]) >> 4];
+        if (j < cnt && tshift == 0 && lb1[j] > lb0[j] && !(j == 0 && memo_hit) && (sizeof(KT) == 4 || (uint64_t)ps0[j] != K4_KTAB64_MASK))
+          touch |= ix.ref2[((int64_t)ps0[j] - oo[j]) >> 4];
 
 #pragma unroll
       for (int j = 0; j < PFN; j++) {
@@ -415,7 +427,8 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           const int64_t mid = (lo + hi) >> 1;
           // pos0 belongs to the bucket of the exact k-mer: with a core shorter than k the interval spans several
           // buckets and the first of them may be empty (pos0 unset), so the suffix array is read instead
-          const uint64_t p = (tshift == 0 && mid == (int64_t)lb0[j]) ? (uint64_t)ps0[j] : k4d_sa_at<EL>(ix, (uint64_t)mid);
+          const uint64_t p = (tshift == 0 && mid == (int64_t)lb0[j] && (sizeof(KT) == 4 || (uint64_t)ps0[j] != K4_KTAB64_MASK))
+                                 ? (uint64_t)ps0[j] : k4d_sa_at<EL>(ix, (uint64_t)mid);
           K4Probe pr;
           if (!CAPTURE && j == 0 && memo_hit) { pr.cmp = 0; pr.mm = memo_mm; pr.fm = len; pr.exc = false; }
           else {

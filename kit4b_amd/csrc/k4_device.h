@@ -46,21 +46,30 @@ K4_DEV uint64_t k4d_sa_at(const K4DevIndex& ix, uint64_t i) {
 }
 
 // k-mer table entry c = {lb, pos0, sig}: lb = number of suffixes sorting before k-mer c (its bucket is
-// [lb(c), lb(c+1))), pos0 = SA[lb] (offset of the bucket's first suffix, valid when the bucket is not empty) and
-// sig = the bases that follow the k-mer in that first suffix (MSB-first; 16 of them in the 32-bit form, 12 in the 64-bit
-// form where they share a word with the 40-bit pos0), a filter that settles most single-suffix buckets without
-// touching the suffix array or the reference.
+// [lb(c), lb(c+1))), pos0 = SA[lb] (offset of the bucket's first suffix, valid when the bucket is not empty) and, in the
+// 32-bit form, sig = the 16 bases that follow the k-mer in that first suffix (MSB-first), a filter that settles most
+// single-suffix buckets without touching the suffix array or the reference.
+// 64-bit form (blocks of 2^32 symbols or more: k stays at 16 while the block holds 4^17 suffixes and more, so a bucket
+// averages several suffixes and a 12-base signature of its first one says little): two 64-bit words, lb and pos0 in their
+// low 40 bits, and in the 2 x 24 bits above them SIXTEEN 3-bit counts -- how many of the bucket's suffixes continue with each
+// of the 16 two-base extensions of the k-mer.  A core of k + 2 bases or more goes straight to its sub-bucket
+// [lb + sum of the counts below it, + its own count), i.e. the table answers like a k = 18 table of 4^18 entries would.  All
+// ones = the bucket is irregular (a count of 7 or more, or a suffix that meets N / a separator within k + 2 symbols): the
+// whole bucket is searched as before.
 #define K4_SIG_BASES32 16
-#define K4_SIG_BASES64 12
 #define K4_KTAB_STRIDE32 3
 #define K4_KTAB_STRIDE64 2
+#define K4_KTAB64_MASK 0xFFFFFFFFFFull
+#define K4_KTAB64_IRREGULAR 0xFFFFFFFFFFFFull
 K4_DEV uint64_t k4d_ktab_lb(const K4DevIndex& ix, uint64_t c) {
-  return ix.ktab64 ? reinterpret_cast<const uint64_t*>(ix.ktab)[K4_KTAB_STRIDE64 * c]
+  return ix.ktab64 ? reinterpret_cast<const uint64_t*>(ix.ktab)[K4_KTAB_STRIDE64 * c] & K4_KTAB64_MASK
                    : reinterpret_cast<const uint32_t*>(ix.ktab)[K4_KTAB_STRIDE32 * c];
 }
-// bucket of the k-mer prefix range [c0, c1): lb0 = lb(c0), pos0 = pos0(c0), sig = sig(c0), lb1 = lb(c1).  KT = field type.
+// bucket of the k-mer prefix range [c0, c1): lb0 = lb(c0), pos0 = pos0(c0), lb1 = lb(c1); sig = sig(c0) (32-bit form) /
+// sub = the 48 bits of sub-bucket counts of c0 (64-bit form).  KT = field type.
 template <typename KT>
-K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& lb0, KT& pos0, uint32_t& sig, KT& lb1) {
+K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& lb0, KT& pos0, uint32_t& sig, KT& lb1, uint64_t& sub) {
+  sub = K4_KTAB64_IRREGULAR;
   if (sizeof(KT) == 4) {
     const uint32_t* t = reinterpret_cast<const uint32_t*>(ix.ktab);
     const uint32_t* e = t + K4_KTAB_STRIDE32 * c0;
@@ -74,9 +83,19 @@ K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& l
   } else {
     const uint64_t* t = reinterpret_cast<const uint64_t*>(ix.ktab);
     const k4_u64x2_a8 v = *reinterpret_cast<const k4_u64x2_a8*>(t + K4_KTAB_STRIDE64 * c0);
-    // 64-bit form: word 0 = lb, word 1 = pos0 (40 bits) | the 12 bases after the k-mer (24 bits, MSB first) << 40
-    lb0 = (KT)v.x; pos0 = (KT)(v.y & 0xFFFFFFFFFFull); sig = (uint32_t)(v.y >> 40) << 8; lb1 = (KT)t[K4_KTAB_STRIDE64 * c1];
+    lb0 = (KT)(v.x & K4_KTAB64_MASK); pos0 = (KT)(v.y & K4_KTAB64_MASK); sig = 0;
+    sub = (v.x >> 40) | ((v.y >> 40) << 24);
+    lb1 = (KT)(t[K4_KTAB_STRIDE64 * c1] & K4_KTAB64_MASK);
   }
+}
+// the sub-bucket of two-base extension e (0..15) inside a regular bucket: (suffixes in front of it, its own count)
+K4_DEV void k4d_ktab_sub(uint64_t sub, uint32_t e, uint32_t& before, uint32_t& count) {
+  count = (uint32_t)(sub >> (3 * e)) & 7u;
+  uint64_t below = sub & ((1ull << (3 * e)) - 1ull);  // the fields of the extensions that sort in front
+  // sum of 3-bit fields: fold to 6-bit, then 12-bit lanes, then multiply-add
+  below = (below & 0x1C71C71C71C7ull) + ((below >> 3) & 0x1C71C71C71C7ull);   // 8 sums of two fields, 6 bits apart
+  below = (below & 0x03F03F03F03Full) + ((below >> 6) & 0x03F03F03F03Full);   // 4 sums of four fields, 12 bits apart
+  before = (uint32_t)((below & 0xFFF) + ((below >> 12) & 0xFFF) + ((below >> 24) & 0xFFF) + ((below >> 36) & 0xFFF));
 }
 
 // 32 bases [pos, pos+32) as one MSB-first 64-bit chunk.  pos may be as low as -K4_PAD_BASES.

@@ -147,8 +147,8 @@ __global__ void __launch_bounds__(256) k4k_ktab_mark(K4DevIndex ix, T* __restric
       if (sizeof(T) == 4) {
         tab[ST * c + 1] = (T)pos;
         tab[ST * c + 2] = (T)(k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 32);  // the next 16 bases
-      } else  // 40-bit pos0 and the next 12 bases in one word
-        tab[ST * c + 1] = (T)((pos & 0xFFFFFFFFFFull) | ((k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 40) << 40));
+      } else  // 40-bit pos0; the bits above it receive sub-bucket counts in k4k_ktab_subcounts
+        tab[ST * c + 1] = (T)(pos & K4_KTAB64_MASK);
     }
   }
 }
@@ -224,6 +224,33 @@ __global__ void __launch_bounds__(256) k4k_scan_apply(T* __restrict__ tab, uint6
     if (base + j < n) tab[(sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64) * (base + j)] = k4_tmin<T>(v[j], right);
 }
 
+// 64-bit form, after the lb scan: sixteen 3-bit counts per bucket (k4_device.h) -- one thread per k-mer code walks its
+// bucket's suffixes (a handful on average: the block holds a few times 4^k of them) and looks at the two symbols behind the
+// k-mer.  Packed into the 24 bits above lb and above pos0.
+template <int EL>
+__global__ void __launch_bounds__(256) k4k_ktab_subcounts(K4DevIndex ix, uint64_t* __restrict__ tab, uint64_t n_codes) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < n_codes; c += stride) {
+    const uint64_t w0 = tab[2 * c];
+    const uint64_t lb = w0 & K4_KTAB64_MASK, lb1 = tab[2 * (c + 1)] & K4_KTAB64_MASK;  // (a neighbour only ever changes its high bits)
+    const uint64_t size = lb1 - lb;
+    uint64_t cnt = 0;
+    if (size > 6 * 16)
+      cnt = K4_KTAB64_IRREGULAR;
+    else
+      for (uint64_t j = 0; j < size; j++) {
+        const uint64_t pos = k4d_sa_at<EL>(ix, lb + j);
+        // (a suffix of the bucket that meets N / a separator within its first k symbols sorts behind the clean ones: irregular too)
+        if (pos + ix.k + 2 > ix.n || k4d_any_exc(ix, (int64_t)pos, (int64_t)pos + ix.k + 2)) { cnt = K4_KTAB64_IRREGULAR; break; }
+        const uint32_t e = (uint32_t)(k4d_ref_chunk(ix, (int64_t)(pos + ix.k)) >> 60);
+        if (((cnt >> (3 * e)) & 7) == 6) { cnt = K4_KTAB64_IRREGULAR; break; }
+        cnt += 1ull << (3 * e);
+      }
+    tab[2 * c] = lb | ((cnt & 0xFFFFFFull) << 40);
+    tab[2 * c + 1] = (tab[2 * c + 1] & K4_KTAB64_MASK) | ((cnt >> 24) << 40);
+  }
+}
+
 __global__ void k4k_unpack_range(K4DevIndex ix, uint64_t start, uint64_t len, uint8_t* __restrict__ out) {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < len) out[t] = (uint8_t)k4d_ref_base(ix, start + t);
@@ -261,6 +288,13 @@ static int build_ktab(k4_index* ix) {
   K4_HIP(ix, hipGetLastError());
   K4_HIP(ix, hipDeviceSynchronize());
   K4_HIP(ix, hipFree(agg));
+  if (sizeof(T) == 8) {
+    const uint64_t n_codes = nent - 1;
+    hipLaunchKernelGGL((k4k_ktab_subcounts<EL>), dim3((unsigned)std::min<uint64_t>((n_codes + 255) / 256, 1ull << 22)), dim3(256), 0, 0, ix->d,
+                       (uint64_t*)tab, n_codes);
+    K4_HIP(ix, hipGetLastError());
+    K4_HIP(ix, hipDeviceSynchronize());
+  }
   return K4_OK;
 }
 
@@ -632,14 +666,15 @@ extern "C" int k4_set_max_iter(k4_index* ix, int max_iter) {  // CSfxArray::SetM
   return prev;
 }
 
-// test hook (not part of the ABI header): raw k-mer table entry {lb, pos0[, sig]} of code c
+// test hook (not part of the ABI header): k-mer table entry {lb, pos0, sig | sub-bucket counts} of code c
 extern "C" int k4i_debug_ktab(const k4_index* ix, uint64_t c, uint64_t* out) {
   if (!ix || !out) return K4_ERR_PARAMS;
   hipSetDevice(ix->device);
   if (ix->d.ktab64) {
     if (hipMemcpy(out, (const uint64_t*)ix->ktab + K4_KTAB_STRIDE64 * c, 16, hipMemcpyDeviceToHost) != hipSuccess) return K4_ERR_NO_DEVICE;
-    out[2] = out[1] >> 40;
-    out[1] &= 0xFFFFFFFFFFull;
+    out[2] = (out[0] >> 40) | ((out[1] >> 40) << 24);  // the sixteen 3-bit sub-bucket counts
+    out[0] &= K4_KTAB64_MASK;
+    out[1] &= K4_KTAB64_MASK;
   } else {
     uint32_t v[3];
     if (hipMemcpy(v, (const uint32_t*)ix->ktab + K4_KTAB_STRIDE32 * c, 12, hipMemcpyDeviceToHost) != hipSuccess) return K4_ERR_NO_DEVICE;
