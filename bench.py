@@ -777,8 +777,9 @@ def cpu_baseline(args, engine, seq, reads, out, hits, out_pe, n, el, n_chrom, ch
         ref = time_reference(ix, reads, pe, L, args.max_subs, cores, Sr, dev, lambda *a: log(rank, *a))
         if ref is not None:
             g_nar = torch.bincount(out[:Sr, 4].to(torch.int64), minlength=20).tolist()
-            ref["nar_equal_to_gpu"] = all(ref["nar"].get(k, 0) == g_nar[c] for k, c in
-                                          (("AA", 1), ("EN", 2), ("NL", 3), ("MH", 4), ("ML", 5), ("UP", 15)))
+            codes = (("AA", 1), ("EN", 2), ("NL", 3), ("MH", 4), ("ML", 5), ("UP", 15))
+            ref["nar_gpu_same_reads"] = {k: g_nar[c] for k, c in codes if g_nar[c]}
+            ref["nar_equal_to_gpu"] = all(ref["nar"].get(k, 0) == g_nar[c] for k, c in codes)
             ref["port"] = cpu
             cpu = ref
     return cpu, parity_sample

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libk4sfx.so")
+LIB_PATH = os.path.join(PKG_DIR, os.environ.get("K4SFX_LIB_NAME", "libk4sfx.so"))  # (the override: development builds, tools/slow_prof.py)
 
 STRAND_BOTH, STRAND_WATSON, STRAND_CRICK = 0, 1, 2
 HR_NONE, HR_HITS, HR_MMDELTA, HR_HITINSTS, HR_RMMDELTA, HR_SEQERRS = 0, 1, 2, 3, 4, 5

@@ -48,6 +48,15 @@
 #ifndef K4_PF5
 #define K4_PF5 4 // ... in the 5-word (129..160 bp) instantiation (3 measured +1 % on C3: noise)
 #endif
+// general kernel: waves per SIMD the compiler must fit its registers to.  Standard phases: 4 (128 VGPRs, ~60 spilled) -- the
+// kernel waits on memory, a fourth wave is worth more than the spills cost (measured: 3 waves 36.1 ms, 4 waves 33.8 ms per
+// 20 M reads of the repeat-rich workload).  With the optional phases compiled in (EXT): 2, without spills.
+#ifndef K4_SLOW_WAVES_PER_EU
+#define K4_SLOW_WAVES_PER_EU 4
+#endif
+#ifndef K4_SLOW_WAVES_PER_EU_EXT
+#define K4_SLOW_WAVES_PER_EU_EXT 2
+#endif
 #ifndef K4_SLOW_KB
 #define K4_SLOW_KB 1  // general kernel: suffixes per lane per walk step (measured: 2 and 4 cost occupancy and lose 25 %)
 #endif
@@ -772,6 +781,11 @@ struct K4Slow {
   uint64_t* pk;         // LDS: the probe in its current orientation as 2-bit words, MSB first, zero word behind the end
   bool packed;          // pk is usable: the probe holds only A/C/G/T
   bool small;       // first general pass: small tables, overflow defers the read to the pass with big tables
+  const uint32_t* sup;  // LDS copy of the coarse exception bitmap (K4_SUP_WORDS words)
+  const uint32_t* ent_id;  // entry ids: LDS copy when the entry table is in LDS, the index's array otherwise
+#ifdef K4_SLOW_PROF
+  unsigned long long prof[16];
+#endif
 };
 
 // CmpProbeTarg (SfxArray.cpp:2508-2525): lanes compare 64 symbols at a time, the first differing / EOS position decides
@@ -846,6 +860,44 @@ K4_DEV bool k4d_hash_insert_lane(const K4Slow& sc, uint32_t id, uint32_t& slot) 
 // generation so that probe chains through it stay intact, but holds the impossible id 0 (TargSeqID is 1 + offset)
 K4_DEV void k4d_hash_retract(const K4Slow& sc, uint32_t slot) {
   atomicExch(reinterpret_cast<unsigned long long*>(sc.hash) + slot, (unsigned long long)sc.gen << 32);
+}
+
+// A divergent wave pays per lane-request, not per byte (k4_device.h): the general kernel's lanes therefore fetch a
+// candidate's window with 16-byte loads (nine words hold 128 bases at any alignment) and ask the LDS copy of the coarse
+// exception bitmap before the fine one in L2, as the fast kernel's k4d_probe does.
+K4_DEV bool k4d_any_exc_sup(const K4DevIndex& ix, const uint32_t* sup, int64_t start, int64_t end) {
+  if (start < 0) start = 0;
+  if (end <= start) return false;
+  const uint64_t b0 = (uint64_t)start >> ix.sup_shift, b1 = (uint64_t)(end - 1) >> ix.sup_shift;
+  const uint64_t v = (((uint64_t)sup[(b0 >> 5) + 1] << 32) | sup[b0 >> 5]) >> (b0 & 31);
+  bool f = (v & ((2ull << (b1 - b0)) - 1ull)) != 0;
+  if (f && ix.sup_shift != K4_EXC_SHIFT) f = k4d_any_exc(ix, start, end);
+  return f;
+}
+// the nine packed words that hold the bases [pos + 32 c0, + 128); eight: the caller needs no base behind the eighth word
+K4_DEV void k4d_ref_words9(const K4DevIndex& ix, int64_t pos, int c0, bool eight, uint32_t (&wv)[9]) {
+  const uint32_t* wp = ix.ref2 + ((pos >> 4) + 2 * c0);
+  if (eight) {
+    uint32_t w8[8];
+    k4d_load_words<8>(wp, w8);
+#pragma unroll
+    for (int j = 0; j < 9; j++) wv[j] = j < 8 ? w8[j] : 0u;
+  } else
+    k4d_load_words<9>(wp, wv);
+}
+// ... as four MSB-first chunks
+K4_DEV void k4d_words_to_chunks4(const uint32_t (&wv)[9], int64_t pos, uint64_t (&out)[4]) {
+  const uint32_t sh = (uint32_t)(pos & 15) * 2;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint64_t hi = ((uint64_t)wv[2 * c] << 32) | wv[2 * c + 1];
+    out[c] = sh ? (hi << sh) | (wv[2 * c + 2] >> (32 - sh)) : hi;
+  }
+}
+K4_DEV void k4d_ref_chunks4(const K4DevIndex& ix, int64_t pos, int c0, bool eight, uint64_t (&out)[4]) {
+  uint32_t wv[9];
+  k4d_ref_words9(ix, pos, c0, eight, wv);
+  k4d_words_to_chunks4(wv, pos, out);
 }
 
 // One lane: compare probe[j] with the target symbol at left + j for j in [jlo, jhi).  all_eq: every symbol equal and no
@@ -938,15 +990,58 @@ K4_DEV uint64_t k4d_probe_chunk(const K4Slow& sc, int j) {  // 32 probe bases fr
   return sh ? (hi << sh) | (sc.pk[w + 1] >> (64 - sh)) : hi;
 }
 
+// Hamming distance of the packed probe against the window [left, left + len) (no exception in it): two 16-byte loads per
+// 113 bases
+// first: the words of the first 128 bases when the caller fetched them already (k4d_ref_words9 with c0 = 0)
+K4_DEV int k4d_lane_hamming(const K4DevIndex& ix, const K4Slow& sc, int len, int64_t left, const uint32_t (*first)[9] = nullptr) {
+  int mm = 0;
+  const int a = (int)(left & 15);
+  for (int c0 = 0; 32 * c0 < len; c0 += 4) {
+    const int rem = len - 32 * c0;
+    uint64_t rc[4];
+    if (first && c0 == 0) k4d_words_to_chunks4(*first, left, rc);
+    else k4d_ref_chunks4(ix, left, c0, rem + a <= 128, rc);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      if (32 * c < rem) mm += (int)k4d_mm_count((rc[c] ^ k4d_probe_chunk(sc, 32 * (c0 + c))) & k4d_range_mask(0, rem - 32 * c));
+  }
+  return mm;
+}
+
 // CmpProbeTarg (SfxArray.cpp:2508-2525) by one lane: core [o, o+cl) of the probe against the suffix at pos; 0 equal,
 // 1 probe greater, -1 probe smaller (a target EOS, or the end of the block, sorts above every probe symbol)
 K4_DEV int k4d_lane_cmp(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, uint64_t pos) {
   const uint8_t* probe = sc.probe;
-  if (sc.packed && pos + (uint64_t)cl <= ix.n && !k4d_any_exc(ix, (int64_t)pos, (int64_t)pos + cl)) {
-    for (int c = 0; 32 * c < cl; c++) {  // 32 bases per step: XOR of packed chunks, MSB-first order == symbol order
-      const uint64_t m = k4d_range_mask(0, cl - 32 * c);
-      const uint64_t rc = k4d_ref_chunk(ix, (int64_t)pos + 32 * c) & m, pc = k4d_probe_chunk(sc, o + 32 * c) & m;
+  if (sc.packed && pos + (uint64_t)cl <= ix.n && !k4d_any_exc_sup(ix, sc.sup, (int64_t)pos, (int64_t)pos + cl)) {
+    // XOR of packed chunks, MSB-first order == symbol order.  One 16-byte load holds the first 49 bases or more: most
+    // comparisons end there.
+    const int al = (int)(pos & 15);
+    {
+      uint32_t w[4];
+      k4d_load_words<4>(ix.ref2 + (pos >> 4), w);
+      const uint32_t sh = 2 * (uint32_t)al;
+      const uint64_t hi0 = ((uint64_t)w[0] << 32) | w[1], hi1 = ((uint64_t)w[2] << 32) | w[3];
+      uint64_t m = k4d_range_mask(0, cl);
+      uint64_t rc = (sh ? (hi0 << sh) | (w[2] >> (32 - sh)) : hi0) & m, pc = k4d_probe_chunk(sc, o) & m;
       if (rc != pc) return pc > rc ? 1 : -1;
+      if (cl <= 32) return 0;
+      if (cl <= 64 - al) {  // (what the fifth word would add lies behind the core)
+        m = k4d_range_mask(0, cl - 32);
+        rc = (hi1 << sh) & m; pc = k4d_probe_chunk(sc, o + 32) & m;
+        return rc == pc ? 0 : pc > rc ? 1 : -1;
+      }
+    }
+    for (int c0 = 1; 32 * c0 < cl; c0 += 4) {
+      const int rem = cl - 32 * c0;
+      uint64_t rc4[4];
+      k4d_ref_chunks4(ix, (int64_t)pos, c0, rem + al <= 128, rc4);
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (32 * c < rem) {
+          const uint64_t m = k4d_range_mask(0, rem - 32 * c);
+          const uint64_t rc = rc4[c] & m, pc = k4d_probe_chunk(sc, o + 32 * (c0 + c)) & m;
+          if (rc != pc) return pc > rc ? 1 : -1;
+        }
     }
     return 0;
   }
@@ -1025,6 +1120,83 @@ K4_DEV int64_t k4d_first_exact_wave(const K4DevIndex& ix, const K4Slow& sc, int 
   return found >= 0 ? found + 1 : 0;
 }
 
+// Profiling build (-DK4_SLOW_PROF, tools/slow_prof.py): where the general kernel's cycles go, summed over waves into the
+// slots behind k4_counters.  0 run search, 1 walk (suffix elements, entries, dedupe), 2 Hamming extension, 3 replay,
+// 4 whole reads, 5 read set-up; 6 lookups, 7 pivots of the run searches, 10 in-bounds run members, 8 runs, 9 walk steps, 11 reads, 12 run members, 13..15 reads that arrive with
+// 0, 1, 2 or more phases already done by the fast kernel.
+#ifdef K4_SLOW_PROF
+#define K4_PROF_T(v) const long long v = clock64()
+#define K4_PROF_ADD(slot, x) do { sc.prof[slot] += (unsigned long long)(x); } while (0)  // flushed once per wave
+#else
+#define K4_PROF_T(v)
+#define K4_PROF_ADD(slot, x)
+#endif
+
+// The whole run of suffixes that start with the core, [first, last] (first > last: none), for the walk of
+// LocateCoreMultiples: the reference finds the first by LocateFirstExact and then compares suffix after suffix until one
+// differs (:5971-6016) -- one random window per suffix visited, which is what a read from a 400-copy repeat family spends
+// its time on.  The suffix array is sorted by the very comparison that loop uses, so the run is the interval between two
+// lower bounds (first suffix not below the core, first suffix above it); lanes 0..31 search the one and lanes 32..63 the
+// other in the same rounds, 32 evenly spaced pivots each: a bucket of 32 suffixes is settled in one round of memory
+// accesses, one of 1024 in two.  end_cmp: would the reference have compared the suffix behind the run (it does not when
+// there is none or when it is closer than the core length to the end of the block, :5981-5985).
+template <int EL>
+K4_DEV void k4d_exact_run_wave(const K4DevIndex& ix, K4Slow& sc, int o, int cl, uint32_t& n_probe, int64_t& first,
+                               int64_t& last, bool& end_cmp) {
+  int64_t lo = 0, hi = (int64_t)ix.n - 1;
+  const int kk = min((int)ix.k, cl);
+  bool acgt = true;
+  uint64_t code = 0;
+  for (int j = 0; j < kk; j++) {  // uniform: every lane reads the same LDS bytes
+    const uint32_t b = sc.probe[o + j] & 0x0f;
+    if (b > 3) { acgt = false; break; }
+    code = (code << 2) | b;
+  }
+  if (acgt) {
+    const int sh = 2 * ((int)ix.k - kk);
+    lo = (int64_t)k4d_ktab_lb(ix, code << sh);
+    hi = (int64_t)k4d_ktab_lb(ix, (code + 1) << sh) - 1;
+  }
+  // search h (0: lowest index whose suffix is not below the core, 1: lowest whose suffix is above it): the answer lies in
+  // [slo[h], shi[h] + 1]; everything below slo[h] fails the predicate, shi[h] + 1 passes it or is the end of the bucket
+  int64_t slo[2] = {lo, lo}, shi[2] = {hi, hi}, ans[2] = {hi + 1, hi + 1};
+  bool open[2] = {lo <= hi, lo <= hi};
+  const int half = sc.lane >> 5, hl = sc.lane & 31;
+  while (open[0] || open[1]) {
+    const int64_t my_lo = half ? slo[1] : slo[0], my_hi = half ? shi[1] : shi[0];
+    const int64_t my_step = (my_hi - my_lo + 1 + 31) / 32;
+    const int64_t pv = my_lo + (int64_t)hl * my_step;
+    const bool have = (half ? open[1] : open[0]) && pv <= my_hi;
+    int c = 1;
+    if (have) c = k4d_lane_cmp(ix, sc, o, cl, k4d_sa_at<EL>(ix, (uint64_t)pv));
+    const unsigned long long hm = __ballot(have);
+    const unsigned long long pm = __ballot(have && (half ? c < 0 : c <= 0));
+    n_probe += (uint32_t)__popcll(hm);
+    K4_PROF_ADD(7, __popcll(hm));
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (!open[h]) continue;
+      const uint32_t hm_h = (uint32_t)(hm >> (32 * h)), pm_h = (uint32_t)(pm >> (32 * h));
+      const int64_t step = (shi[h] - slo[h] + 1 + 31) / 32;
+      if (!pm_h) {  // every pivot fails: the answer lies behind the last one
+        slo[h] += (int64_t)(__popc(hm_h) - 1) * step + 1;
+        if (slo[h] > shi[h]) { ans[h] = shi[h] + 1; open[h] = false; }
+        continue;
+      }
+      const int f = __ffs((int)pm_h) - 1;
+      const int64_t pvf = slo[h] + (int64_t)f * step;
+      if (f == 0 || step == 1) { ans[h] = pvf; open[h] = false; continue; }
+      slo[h] = pvf - step + 1;  // behind the last failing pivot
+      shi[h] = pvf - 1;         // (pvf itself passes)
+      // (slo <= shi here: step > 1)
+    }
+  }
+  first = ans[0];
+  last = ans[1] - 1;
+  end_cmp = false;
+  if (last >= first && last + 1 < (int64_t)ix.n) end_cmp = (int64_t)k4d_sa_at<EL>(ix, (uint64_t)last + 1) + cl <= (int64_t)ix.n;
+}
+
 #include "k4_ext.h"
 
 // CHIM: the chimeric branch (:6064-6189) -- every new in-bounds candidate is flank-trimmed by AdaptiveTrim (one lane each,
@@ -1049,7 +1221,6 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
   }
   st.cur_hit = st.inst < rp.max_hits ? st.inst : -1;
   const int max_iter = ix.max_iter;
-  const int64_t n = (int64_t)ix.n;
   const int lane = sc.lane;
   int strand = rp.strand;
   char cur_strand = '+';
@@ -1068,54 +1239,49 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
          slides++, o += cur_delta) {
       if (o + cl + cur_delta > len) cur_delta = len - (o + cl);
       n_lookup++;
-      int64_t t = k4d_first_exact_wave<EL>(ix, sc, o, cl, n_probe);
-      if (t == 0) continue;
-      t -= 1;
-      // The walk over the run of suffixes that start with the core (:5971-6321), 64 suffixes per step, one per lane: the
-      // memory-bound part (suffix element, core comparison, entry lookup, dedupe insert, Hamming distance) runs in
-      // parallel; what the reference's sequential loop makes order-dependent -- where the run ends, MaxIter and the node
-      // limit counting only new in-bounds candidates, the fold into (LowMMCnt, NxtLowMMCnt, instances, hits) and its
-      // early exit -- is then replayed in suffix order from the lanes' results.
+      int64_t t, t_last;
+      bool end_cmp;
+      K4_PROF_T(pt0);
+      K4_PROF_ADD(6, 1);
+      k4d_exact_run_wave<EL>(ix, sc, o, cl, n_probe, t, t_last, end_cmp);
+      K4_PROF_T(pt1);
+      K4_PROF_ADD(0, pt1 - pt0);
+      if (t > t_last) continue;
+      K4_PROF_ADD(8, 1);
+      K4_PROF_ADD(12, t_last - t + 1);
+      // The walk over the run of suffixes that start with the core (:5971-6321), 64 suffixes per step, one per lane.  Where
+      // the run ends is known (k4d_exact_run_wave), so no suffix is compared with the core again; the memory-bound part
+      // (suffix element, entry lookup, dedupe insert, Hamming distance of the new candidates) runs in parallel; what the
+      // reference's sequential loop makes order-dependent -- MaxIter and the node limit counting only new in-bounds
+      // candidates, the fold into (LowMMCnt, NxtLowMMCnt, instances, hits) and its early exit -- is then replayed in suffix
+      // order from the lanes' results.
       int iter = 0;
-      bool run_over = false, done_all = false;
+      bool run_over = false, done_all = false, limit_seen = false;
       constexpr int KB = K4_SLOW_KB;  // suffixes per lane per step: KB * 64 per step, their memory accesses in flight together
-      int kb_eff = 1;  // the first step looks at 64 suffixes (most runs are short), the following ones at KB * 64
-      for (int64_t base = t; !run_over; base += 64 * kb_eff, kb_eff = KB) {
+      // (the suffix elements of a step are fetched during the step before it)
+      uint64_t pos_ahead[KB];
+#pragma unroll
+      for (int k = 0; k < KB; k++) pos_ahead[k] = t + 64 * k + lane <= t_last ? k4d_sa_at<EL>(ix, (uint64_t)(t + 64 * k + lane)) : 0;
+      for (int64_t base = t; !run_over; base += 64 * KB) {
+        K4_PROF_T(ps0);
+        K4_PROF_ADD(9, 1);
         uint64_t pos[KB];
-        bool fits[KB], core_ok[KB], isnew[KB];
+        bool isnew[KB];
         int r[KB], e[KB], mm[KB];
         uint32_t loci[KB], slot[KB];
-        bool endc[KB], eos[KB];
+        bool eos[KB], clean[KB];
+        uint32_t win[KB][9];
         unsigned long long newm[KB];
-        // 1. suffix elements
+        // 1. suffix elements; members of sub-batch k are its lanes [0, r[k])
 #pragma unroll
         for (int k = 0; k < KB; k++) {
-          const int64_t idx = base + 64 * k + lane;
-          const bool have = k < kb_eff && idx < n;
-          pos[k] = have ? k4d_sa_at<EL>(ix, (uint64_t)idx) : 0;
-          fits[k] = have && (idx == t || (int64_t)pos[k] + cl <= n);  // (:5981-5985 for the suffixes after the first)
+          const int64_t idx_ahead = base + 64 * KB + 64 * k + lane;
+          pos[k] = pos_ahead[k];
+          pos_ahead[k] = idx_ahead <= t_last ? k4d_sa_at<EL>(ix, (uint64_t)idx_ahead) : 0;
+          const int64_t left_in_run = t_last - (base + 64 * k) + 1;
+          r[k] = left_in_run >= 64 ? 64 : left_in_run > 0 ? (int)left_in_run : 0;
         }
-        // 2. does the suffix still start with the core?  (the one LocateFirstExact returned is taken as it is)
-#pragma unroll
-        for (int k = 0; k < KB; k++) {
-          core_ok[k] = false;
-          if (k < kb_eff && base + 64 * k + lane == t) core_ok[k] = true;
-          else if (fits[k]) core_ok[k] = k4d_lane_cmp(ix, sc, o, cl, pos[k]) == 0;
-        }
-        // 3. where the run ends: members are lanes [0, r[k]) of sub-batch k, nothing behind the first non-member
-        bool ended = false;
-#pragma unroll
-        for (int k = 0; k < KB; k++) {
-          r[k] = 0;
-          endc[k] = false;
-          const unsigned long long bad = __ballot(!(fits[k] && core_ok[k]));
-          if (!ended && k < kb_eff) {
-            r[k] = bad ? __ffsll((long long)bad) - 1 : 64;
-            // was the suffix that ended the run compared (a probe in the reference's count) or was it out of range?
-            endc[k] = r[k] < 64 && __shfl((int)(fits[k] ? 1 : 0), r[k], 64) != 0;
-            ended = r[k] < 64;
-          }
-        }
+        const bool ended = base + 64 * KB > t_last;
         // 4. filters that precede the dedupe (:6019-6036: before the core offset, on a separator, over the entry end),
         //    then the dedupe insert, all lanes at once
 #pragma unroll
@@ -1129,7 +1295,12 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
           loci[k] = (uint32_t)(left - e_start);
           isnew[k] = false;
           slot[k] = 0;
+          // the window's first words are on their way while the dedupe table is probed (nearly every in-bounds member of
+          // a run turns out to be new: the same trip, not one more)
+          clean[k] = !CHIM && in_bounds && sc.packed && !k4d_any_exc_sup(ix, sc.sup, (int64_t)left, (int64_t)left + len);
+          if (clean[k]) k4d_ref_words9(ix, (int64_t)left, 0, len + (int)(left & 15) <= 128, win[k]);
           if (in_bounds) isnew[k] = k4d_hash_insert_lane(sc, (uint32_t)(1 + pos[k] - (uint32_t)o), slot[k]);
+          K4_PROF_ADD(10, __popcll(__ballot(in_bounds)));
         }
         // 5. MaxIter / node limit: both count new in-bounds candidates only; the walk stops before the suffix after the
         //    last one it may take.  Inserts behind that point are retracted.
@@ -1143,7 +1314,7 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
           last[k] = r[k] - 1;
           if (hit_limit) {  // the walk ended in an earlier sub-batch
             if (isnew[k]) k4d_hash_retract(sc, slot[k]);
-            newm[k] = 0; last[k] = -1; r[k] = 0; endc[k] = false;
+            newm[k] = 0; last[k] = -1; r[k] = 0;
             continue;
           }
           const uint32_t c = (uint32_t)__popcll(newm[k]);
@@ -1155,12 +1326,14 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
             const unsigned long long beyond = last[k] >= 63 ? 0ull : (~0ull << (last[k] + 1));
             if (isnew[k] && ((beyond >> lane) & 1)) k4d_hash_retract(sc, slot[k]);
             newm[k] &= ~beyond;
-            endc[k] = false;
           } else
             remaining -= c;
         }
-        run_over = hit_limit || ended;  // (ended is false when every sub-batch looked at was full of members)
+        run_over = hit_limit || ended;
+        limit_seen = hit_limit;
         // 6. the Hamming extension (:6200-6261) for the candidates that are new in this strand pass
+        K4_PROF_T(ps1);
+        K4_PROF_ADD(1, ps1 - ps0);
         K4Trim trim[KB];
 #pragma unroll
         for (int k = 0; k < KB; k++) {
@@ -1176,10 +1349,8 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
           }
           if ((newm[k] >> lane) & 1) {
             const uint64_t left = pos[k] - (uint64_t)o;
-            if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
-              for (int c = 0; 32 * c < len; c++)
-                mm[k] += (int)k4d_mm_count((k4d_ref_chunk(ix, (int64_t)left + 32 * c) ^ k4d_probe_chunk(sc, 32 * c)) &
-                                           k4d_range_mask(0, len - 32 * c));
+            if (clean[k]) {
+              mm[k] = k4d_lane_hamming(ix, sc, len, (int64_t)left, &win[k]);
             } else {
               bool all_eq;
               k4d_lane_range(ix, sc.probe, 0, len, left, false, all_eq, eos[k], mm[k]);
@@ -1188,11 +1359,15 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
         }
         // 7. replay in suffix order: only candidates that pass the order-independent part of the acceptance test can
         //    change the state; the rest just count
+        K4_PROF_T(ps2);
+        K4_PROF_ADD(2, ps2 - ps1);
 #pragma unroll
         for (int k = 0; k < KB; k++) {
           if (done_all) break;
-          unsigned long long todo = CHIM ? __ballot(((newm[k] >> lane) & 1) && trim[k].len >= min_probe_chim && trim[k].len > 0)
-                                         : __ballot(((newm[k] >> lane) & 1) && !eos[k] && mm[k] <= allow_mm);
+          const bool cand = CHIM ? ((newm[k] >> lane) & 1) && trim[k].len >= min_probe_chim && trim[k].len > 0
+                                 : ((newm[k] >> lane) & 1) && !eos[k] && mm[k] <= allow_mm;
+          unsigned long long todo = __ballot(cand);
+          const uint32_t ent_id_l = cand ? sc.ent_id[e[k]] : 0u;  // (looked up by all lanes at once, not per candidate in the loop below)
           int stop_lane = -1;
           while (todo) {
             const int c = __ffsll((long long)todo) - 1;
@@ -1200,7 +1375,7 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
             if (CHIM) {  // the fold of :6106-6188
               const int c_len = __shfl(trim[k].len, c, 64), c_mms = __shfl(trim[k].mms, c, 64);
               const int t5 = __shfl(trim[k].t5, c, 64), t3 = __shfl(trim[k].t3, c, 64);
-              const int e_c = __shfl(e[k], c, 64);
+              const uint32_t ent_c = (uint32_t)__shfl((int)ent_id_l, c, 64);
               const uint32_t loci_c = (uint32_t)__shfl((int)loci[k], c, 64);
               const uint32_t tl = cur_strand == '+' ? (uint32_t)t5 : (uint32_t)t3, tr = cur_strand == '+' ? (uint32_t)t3 : (uint32_t)t5;
               const uint32_t ext = K4_EXT_CHIMERIC | (tl & 0xFFFu) | ((tr & 0xFFFu) << 12);
@@ -1211,12 +1386,12 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
                 st.inst = 1;
                 st.nxt = st.low;
                 st.low = c_mms;
-                if (hits_w) k4d_store_hit(&hits_w[0], ix.ent_id[e_c], loci_c, len, cur_strand, c_mms, ext);
+                if (hits_w) k4d_store_hit(&hits_w[0], ent_c, loci_c, len, cur_strand, c_mms, ext);
               } else if (c_len == best_len && c_mms == best_mms) {
                 st.inst += 1;
                 if (st.cur_hit != -1 && st.inst <= rp.max_hits) {
                   st.cur_hit += 1;
-                  if (hits_w && st.cur_hit < rp.max_hits) k4d_store_hit(&hits_w[st.cur_hit], ix.ent_id[e_c], loci_c, len, cur_strand, c_mms, ext);
+                  if (hits_w && st.cur_hit < rp.max_hits) k4d_store_hit(&hits_w[st.cur_hit], ent_c, loci_c, len, cur_strand, c_mms, ext);
                 }
               } else if (c_len == best_len && c_mms < st.nxt)
                 st.nxt = c_mms;
@@ -1225,10 +1400,20 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
             }
             const int mm_c = __shfl(mm[k], c, 64);
             if (mm_c >= st.nxt) continue;
-            const int e_c = __shfl(e[k], c, 64);
+            const uint32_t ent_c = (uint32_t)__shfl((int)ent_id_l, c, 64);
             const uint32_t loci_c = (uint32_t)__shfl((int)loci[k], c, 64);
-            k4d_fold(st, mm_c, hits_w, rp.max_hits, ix.ent_id[e_c], loci_c, len, cur_strand);
+            k4d_fold(st, mm_c, hits_w, rp.max_hits, ent_c, loci_c, len, cur_strand);
             if (st.inst > rp.max_hits && st.low == 0) { stop_lane = c; break; }
+            // what is left of a repeat family's batch mostly cannot change the state any more: candidates at or above
+            // NxtLowMMCnt are no-ops (it only ever drops), and once the hit slots are full a candidate that ties with
+            // LowMMCnt only counts -- those in front of the next better one are counted in one go
+            todo &= __ballot(mm[k] < st.nxt);
+            if (st.inst >= rp.max_hits && st.low > 0) {
+              const unsigned long long better = todo & __ballot(mm[k] < st.low);
+              const unsigned long long ties = todo & __ballot(mm[k] == st.low) & (better ? (better & (0ull - better)) - 1ull : ~0ull);
+              st.inst += (int)__popcll(ties);
+              todo &= ~ties;
+            }
           }
           const uint32_t first_adj = (base == t && k == 0) ? 1u : 0u;  // the first suffix of the run is not a probe
           if (stop_lane >= 0) {  // early exit of :6313-6321: candidates behind it were never examined
@@ -1237,14 +1422,16 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
             iter += (int)took; n_cand += took; n_nodes += took;
             n_probe += (uint32_t)(stop_lane + 1) - first_adj;
             done_all = true;
-          } else if (last[k] >= 0 || endc[k]) {
+          } else if (last[k] >= 0) {
             const uint32_t took = (uint32_t)__popcll(newm[k]);
             iter += (int)took; n_cand += took; n_nodes += took;
-            // probes the reference counted: every member reached after the first suffix, plus the comparison that ended the run
-            n_probe += (uint32_t)(last[k] + 1) - (last[k] >= 0 ? first_adj : 0u) + (uint32_t)(endc[k] ? 1 : 0);
+            n_probe += (uint32_t)(last[k] + 1) - first_adj;  // probes the reference counted: every member reached after the first suffix
           }
         }
+        K4_PROF_T(ps3);
+        K4_PROF_ADD(3, ps3 - ps2);
         if (done_all) break;
+        if (run_over && !limit_seen && end_cmp) n_probe++;  // ... plus the comparison that ended the run
         if (n_nodes >= node_cap && node_cap < (uint32_t)K4_MAX_IDENT_NODES && sc.small) {
           if (cur_strand == '-') k4d_revcomp_wave(sc, len);
           return K4_NEED_SLOW;
@@ -1332,11 +1519,9 @@ K4_DEV int k4d_best_slow(const K4AlignArgs& a, K4Slow& sc, int len, int max_tot_
         n_cand++;
         int mm = 0;
         bool eos = false, all_eq;
-        if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
-          for (int c = 0; 32 * c < len; c++)
-            mm += (int)k4d_mm_count((k4d_ref_chunk(ix, (int64_t)left + 32 * c) ^ k4d_probe_chunk(sc, 32 * c)) &
-                                    k4d_range_mask(0, len - 32 * c));
-        } else
+        if (sc.packed && !k4d_any_exc_sup(ix, sc.sup, (int64_t)left, (int64_t)left + len))
+          mm = k4d_lane_hamming(ix, sc, len, (int64_t)left);
+        else
           k4d_lane_range(ix, sc.probe, 0, len, left, false, all_eq, eos, mm);
         if (eos || mm > max_tot_mm) continue;  // :7060-7127
         // :7129-7176 sorted insert (lane 0 owns the list), then every lane learns the new state
@@ -1430,12 +1615,14 @@ K4_DEV int k4d_ext_phases(const K4AlignArgs& a, K4Slow& sc, int len, const K4Rea
 // EXT: the instantiation that also holds the optional phases (k4_ext.h); launched only when one of them is requested, so
 // that the standard path keeps the register budget (and with it the occupancy) of the lean one.
 template <int EL, bool EXT>
-__global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_waves, int pass, uint64_t* hash_base,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K4_SLOW_WAVES_PER_EU_EXT : K4_SLOW_WAVES_PER_EU))) k4k_align_slow(K4AlignArgs a, uint32_t n_waves, int pass, uint64_t* hash_base,
                                                      uint32_t hash_cap, uint32_t* gen_base, int max_len) {
-  // dynamic LDS, sized by the batch (k4_slow_lds_bytes): entry table copy | packed probe | probe bytes
+  // dynamic LDS, sized by the batch: entry table copy (starts, ends, ids) | coarse exception bitmap | packed probe | probe bytes
   extern __shared__ uint64_t slow_lds[];
   uint64_t* ent_s = slow_lds;
-  uint64_t* pk_s = slow_lds + (a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES : 0);
+  uint32_t* entid_s = reinterpret_cast<uint32_t*>(slow_lds + (a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES : 0));
+  uint32_t* sup_s = entid_s + (a.ix.n_entries <= K4_LDS_ENTRIES ? K4_LDS_ENTRIES : 0);
+  uint64_t* pk_s = reinterpret_cast<uint64_t*>(sup_s + K4_SUP_WORDS);
   uint8_t* probe_s = reinterpret_cast<uint8_t*>(pk_s + (max_len / 32 + 2));
   // (chimeric phase only) one mismatch bit vector per lane behind the probe bytes, word w of lane l at mk_s[w * 64 + l]
   uint32_t* mk_s = reinterpret_cast<uint32_t*>(probe_s + ((max_len + 64 + 7) & ~7)) + threadIdx.x;
@@ -1447,10 +1634,17 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
     for (int q = lane; q < (int)a.ix.n_entries; q += 64) {
       ent_s[q] = a.ix.ent_start[q];
       ent_s[K4_LDS_ENTRIES + q] = a.ix.ent_end[q];
+      entid_s[q] = a.ix.ent_id[q];
     }
+  for (int q = lane; q < K4_SUP_WORDS; q += 64) sup_s[q] = a.ix.excsup[q];
   __syncthreads();
   if (wave < n_waves) {
     K4Slow sc;
+    sc.sup = sup_s;
+    sc.ent_id = ent_in_lds ? entid_s : a.ix.ent_id;
+#ifdef K4_SLOW_PROF
+    for (int q = 0; q < 16; q++) sc.prof[q] = 0;
+#endif
     sc.probe = probe_s;
     sc.ent = ent_in_lds ? ent_s : nullptr;
     sc.pk = pk_s;
@@ -1472,7 +1666,8 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
       const int64_t i = list[q];
       const int from_phase = steps[q];
       int phase = 0;
-      uint32_t t0 = n_lookup, t1 = n_probe, t2 = n_cand;
+      K4_PROF_T(pr0);
+      K4_PROF_ADD(from_phase < 3 ? 13 + from_phase : 15, 1);
       const uint32_t r0 = n_lookup, r1 = n_probe, r2 = n_cand;
       const int len = (int)a.lens[i];
       const K4ReadParams rp = k4d_read_params(a, len);
@@ -1487,6 +1682,8 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
       for (int j = lane; j < len; j += 64) probe_s[j] = src[j] & 7;
       __syncthreads();
       k4d_pack_probe_wave(sc, len);
+      K4_PROF_T(pr1);
+      K4_PROF_ADD(5, pr1 - pr0);
       if ((a.mode == 1 && a.kp.pe_mode == 4) || a.best) {  // -N (KAligner.cpp:9776-9796): LocateBestMatches instead of AlignReads
         const int r = k4d_best_slow<EL>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, hits, n_lookup, n_probe, n_cand);
         if (r == K4_NEED_SLOW) {
@@ -1519,21 +1716,21 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
         inst = 0; low = nxt = rp.tot_mm + rp.mm_delta + 1;
       } else {
         if (rp.tot_mm > 0) {
+          // A phase the fast kernel completed (and tallied) is not run again: the read is still unaligned, so that phase
+          // returned eHRnone, i.e. it folded no candidate -- every candidate it accepts has fewer mismatches than the
+          // LowMMCnt it starts from -- stored no hit and left (instances, LowMMCnt, NxtLowMMCnt) as LocateCoreMultiples
+          // initialises them, which the next call does again (:5902-5907).
           for (allow = 0; allow <= rp.tot_mm; allow++) {
             int cl = len / (allow + rp.mm_delta);
             if (cl <= rp.core_len) break;
-            t0 = n_lookup; t1 = n_probe; t2 = n_cand;
+            if (phase++ < from_phase) continue;
             rslt = k4d_lcm_slow<EL, false>(a, sc, len, allow, cl, cl, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
-            if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }  // tallied by the fast path already
             if (rslt != 0) break;
           }
         }
-        if (rslt == 0 && allow <= rp.tot_mm) {
-          t0 = n_lookup; t1 = n_probe; t2 = n_cand;
+        if (rslt == 0 && allow <= rp.tot_mm && phase++ >= from_phase)
           rslt = k4d_lcm_slow<EL, false>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, &low, &nxt, hits,
                                          n_lookup, n_probe, n_cand);
-          if (phase++ < from_phase) { n_lookup = t0; n_probe = t1; n_cand = t2; }
-        }
       }
       if (EXT && rslt == 0 && a.ext_on)  // SfxArray.cpp:7894-7930
         rslt = k4d_ext_phases<EL>(a, sc, len, rp, &inst, &low, &nxt, hits, a.seg2 ? a.seg2 + i : nullptr, mk_s, n_lookup, n_probe, n_cand);
@@ -1553,8 +1750,16 @@ __global__ void __launch_bounds__(64) k4k_align_slow(K4AlignArgs a, uint32_t n_w
         if (rslt < 0) k4d_finalize(a, i, len, rp, a.mode == 0 ? rslt : K4_HR_FATAL, 0, 0, 0);
         else k4d_finalize(a, i, len, rp, rslt, inst, low, nxt);
       }
+      K4_PROF_T(pr2);
+      K4_PROF_ADD(4, pr2 - pr0);
+      K4_PROF_ADD(11, 1);
     }
     if (lane == 0) gen_base[wave] = sc.gen;
+#ifdef K4_SLOW_PROF
+    if (lane == 0)
+      for (int q = 0; q < 16; q++)
+        if (sc.prof[q]) atomicAdd(&a.counters[6 + q], sc.prof[q]);
+#endif
   }
   if (lane == 0) {  // the tallies are wave-uniform
     if (n_lookup) atomicAdd(&a.counters[1], (unsigned long long)n_lookup);
@@ -1719,7 +1924,7 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
   if (rc != K4_OK) return rc;
   const int slow_len = std::min(std::max(max_len, 1), K4_MAX_READ_LEN);
   const bool chim = a.ext_on && (a.mode == 0 ? a.ap.min_chimeric_len : a.kp.min_chimeric_len) > 0;
-  const size_t slow_lds = (size_t)(a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES : 0) * 8 + (size_t)(slow_len / 32 + 2) * 8 +
+  const size_t slow_lds = (size_t)(a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES * 8 + K4_LDS_ENTRIES * 4 : 0) + (size_t)K4_SUP_WORDS * 4 + (size_t)(slow_len / 32 + 2) * 8 +
                           (size_t)((slow_len + 64 + 7) & ~7) + (chim ? (size_t)64 * 4 * ((slow_len + 31) / 32 + 1) : 0) + 16;
   if (slow_lds > 48 * 1024) K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_slow<EL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slow_lds));
   // (no more waves than reads: a batch of one -- the facade's AlignReads -- should not pay for 8192 idle blocks)
@@ -2094,6 +2299,16 @@ extern "C" int k4_get_counters(k4_index* ix, k4_counters* out) {
   K4_HIP(ix, hipSetDevice(ix->device));
   K4_HIP(ix, hipDeviceSynchronize());
   K4_HIP(ix, hipMemcpy(out, ix->counters, sizeof(k4_counters), hipMemcpyDeviceToHost));
+  return K4_OK;
+}
+
+// test/profiling hook (not part of the ABI header): the K4_PROF_SLOTS slots behind the counters; zeroes them
+extern "C" int k4i_debug_prof(k4_index* ix, uint64_t* out) {
+  if (!ix || !out) return K4_ERR_PARAMS;
+  K4_HIP(ix, hipSetDevice(ix->device));
+  K4_HIP(ix, hipDeviceSynchronize());
+  K4_HIP(ix, hipMemcpy(out, (char*)ix->counters + sizeof(k4_counters), K4_PROF_SLOTS * 8, hipMemcpyDeviceToHost));
+  K4_HIP(ix, hipMemset((char*)ix->counters + sizeof(k4_counters), 0, K4_PROF_SLOTS * 8));
   return K4_OK;
 }
 

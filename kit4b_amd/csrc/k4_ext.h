@@ -131,9 +131,15 @@ K4_DEV uint32_t k4d_mm_bits(uint64_t x) {
 
 // the mismatch vector of the probe laid on [left, left+len) into this lane's column of mk (N == N is a match, :5618,5651)
 K4_DEV void k4d_build_mm_vector(const K4DevIndex& ix, const K4Slow& sc, int len, uint64_t left, uint32_t* mk) {
-  if (sc.packed && !k4d_any_exc(ix, (int64_t)left, (int64_t)left + len)) {
-    for (int c = 0; 32 * c < len; c++)
-      mk[c * 64] = k4d_mm_bits((k4d_ref_chunk(ix, (int64_t)left + 32 * c) ^ k4d_probe_chunk(sc, 32 * c)) & k4d_range_mask(0, len - 32 * c));
+  if (sc.packed && !k4d_any_exc_sup(ix, sc.sup, (int64_t)left, (int64_t)left + len)) {
+    for (int c0 = 0; 32 * c0 < len; c0 += 4) {
+      const int rem = len - 32 * c0;
+      uint64_t rc[4];
+      k4d_ref_chunks4(ix, (int64_t)left, c0, rem + (int)(left & 15) <= 128, rc);
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (32 * c < rem) mk[(c0 + c) * 64] = k4d_mm_bits((rc[c] ^ k4d_probe_chunk(sc, 32 * (c0 + c))) & k4d_range_mask(0, rem - 32 * c));
+    }
     return;
   }
   K4Tb t;

@@ -367,8 +367,8 @@ int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
     K4_HIP(ix, hipMemcpy(ix->ent_end, ee.data(), (size_t)ne * 8, hipMemcpyHostToDevice));
     K4_HIP(ix, hipMemcpy(ix->ent_id, ei.data(), (size_t)ne * 4, hipMemcpyHostToDevice));
   }
-  K4_HIP(ix, hipMalloc(&ix->counters, sizeof(k4_counters)));
-  K4_HIP(ix, hipMemset(ix->counters, 0, sizeof(k4_counters)));
+  K4_HIP(ix, hipMalloc(&ix->counters, sizeof(k4_counters) + K4_PROF_SLOTS * 8));  // (+ the profiling build's slots, k4_align.hip)
+  K4_HIP(ix, hipMemset(ix->counters, 0, sizeof(k4_counters) + K4_PROF_SLOTS * 8));
   ix->d.ref2 = ref2;
   ix->d.excbm = ix->excbm;
   ix->d.excsup = ix->excsup;

@@ -31,6 +31,7 @@
 #define K4_PAD_WORDS (K4_PAD_BASES / 16)
 #define K4_MAX_FAST_READ_LEN 512   // longer reads run in the general kernel
 #define K4_MAX_READ_LEN 4096       // cMaxSeqLen is 2000 (KAligner.h:115)
+#define K4_PROF_SLOTS 32          // u64 slots behind k4_counters for builds with -DK4_SLOW_PROF (tools/slow_prof.py)
 #define K4_DEDUP_CAP 6             // distinct candidates per strand pass kept by the fast kernel
 #define K4_MAX_IDENT_NODES 1024000 // cMaxNumIdentNodes, libkit4b/SfxArray.h:15
 
