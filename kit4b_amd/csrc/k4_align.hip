@@ -874,32 +874,6 @@ K4_DEV bool k4d_any_exc_sup(const K4DevIndex& ix, const uint32_t* sup, int64_t s
   if (f && ix.sup_shift != K4_EXC_SHIFT) f = k4d_any_exc(ix, start, end);
   return f;
 }
-// the nine packed words that hold the bases [pos + 32 c0, + 128); eight: the caller needs no base behind the eighth word
-K4_DEV void k4d_ref_words9(const K4DevIndex& ix, int64_t pos, int c0, bool eight, uint32_t (&wv)[9]) {
-  const uint32_t* wp = ix.ref2 + ((pos >> 4) + 2 * c0);
-  if (eight) {
-    uint32_t w8[8];
-    k4d_load_words<8>(wp, w8);
-#pragma unroll
-    for (int j = 0; j < 9; j++) wv[j] = j < 8 ? w8[j] : 0u;
-  } else
-    k4d_load_words<9>(wp, wv);
-}
-// ... as four MSB-first chunks
-K4_DEV void k4d_words_to_chunks4(const uint32_t (&wv)[9], int64_t pos, uint64_t (&out)[4]) {
-  const uint32_t sh = (uint32_t)(pos & 15) * 2;
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const uint64_t hi = ((uint64_t)wv[2 * c] << 32) | wv[2 * c + 1];
-    out[c] = sh ? (hi << sh) | (wv[2 * c + 2] >> (32 - sh)) : hi;
-  }
-}
-K4_DEV void k4d_ref_chunks4(const K4DevIndex& ix, int64_t pos, int c0, bool eight, uint64_t (&out)[4]) {
-  uint32_t wv[9];
-  k4d_ref_words9(ix, pos, c0, eight, wv);
-  k4d_words_to_chunks4(wv, pos, out);
-}
-
 // One lane: compare probe[j] with the target symbol at left + j for j in [jlo, jhi).  all_eq: every symbol equal and no
 // target EOS (CmpProbeTarg == 0 when the range is a core); mm: number of unequal symbols (N == N is equal, :6202-6234);
 // eos: the range holds a target EOS.  Exact symbols: when no 256-base block of the range is flagged the packed words are

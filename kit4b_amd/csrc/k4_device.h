@@ -107,6 +107,32 @@ K4_DEV uint64_t k4d_ref_chunk(const K4DevIndex& ix, int64_t pos) {
   return s ? (hi << s) | (p[2] >> (32 - s)) : hi;
 }
 
+// the nine packed words that hold the bases [pos + 32 c0, + 128); eight: the caller needs no base behind the eighth word
+K4_DEV void k4d_ref_words9(const K4DevIndex& ix, int64_t pos, int c0, bool eight, uint32_t (&wv)[9]) {
+  const uint32_t* wp = ix.ref2 + ((pos >> 4) + 2 * c0);
+  if (eight) {
+    uint32_t w8[8];
+    k4d_load_words<8>(wp, w8);
+#pragma unroll
+    for (int j = 0; j < 9; j++) wv[j] = j < 8 ? w8[j] : 0u;
+  } else
+    k4d_load_words<9>(wp, wv);
+}
+// ... as four MSB-first chunks
+K4_DEV void k4d_words_to_chunks4(const uint32_t (&wv)[9], int64_t pos, uint64_t (&out)[4]) {
+  const uint32_t sh = (uint32_t)(pos & 15) * 2;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint64_t hi = ((uint64_t)wv[2 * c] << 32) | wv[2 * c + 1];
+    out[c] = sh ? (hi << sh) | (wv[2 * c + 2] >> (32 - sh)) : hi;
+  }
+}
+K4_DEV void k4d_ref_chunks4(const K4DevIndex& ix, int64_t pos, int c0, bool eight, uint64_t (&out)[4]) {
+  uint32_t wv[9];
+  k4d_ref_words9(ix, pos, c0, eight, wv);
+  k4d_words_to_chunks4(wv, pos, out);
+}
+
 // any non-ACGT symbol in [start, end) ?  (end - start) must stay below 32 blocks; one 8-byte fetch
 K4_DEV bool k4d_any_exc(const K4DevIndex& ix, int64_t start, int64_t end) {
   if (start < 0) start = 0;

@@ -13,12 +13,20 @@
 // three or the last two bases (AdaptiveTrim :5622-5631 with MinFlankMatches 3) and the count is < rate + 1
 // (PrevBestMaxChimericMMs :8684).  The reference keeps the first strictly better locus and stops at a 0-mismatch one,
 // i.e. the lexicographic minimum of (mismatches, locus).
-// Wave-cooperative; rs = K4_MAX_READ_LEN bytes of LDS owned by this wave.  Returns the AlignPairedRead result
-// (1 placed, 0 not, < 0 error), identical in every lane; h is filled when 1.
+// One lane per locus: the window comes in with 16-byte loads (neighbouring lanes share its cache lines) and is XORed
+// against the packed mate 32 bases at a time -- popcount for the mismatches, two masks for the flank rule; a window that
+// touches N / a separator, or a mate that holds N, is compared symbol by symbol through the exact store instead.
+// Windows of 1000 loci or more: the reference switches to exact seeds there (:8685-8726), but outside its chimeric mode it
+// passes a seed length of 0 to IterateExactsRange, whose loop then never meets a mismatch and walks off the end of the suffix
+// array -- `ngskit4b kalign -U1 -d100 -D1500` dies with SIGSEGV at the first rescue (known reference defects).
+// There is no reference behaviour to reproduce: the linear-scan rule is applied to windows of any size.
+// Wave-cooperative; rs = K4_RESCUE_LDS bytes of LDS owned by this wave (the oriented mate as symbols, then packed).
+// Returns the AlignPairedRead result (1 placed, 0 not, < 0 error), identical in every lane; h is filled when 1.
+#define K4_RESCUE_LDS (K4_MAX_READ_LEN + 8 * (K4_MAX_READ_LEN / 32 + 2))
 K4_DEV int k4d_mate_rescue(const K4DevIndex& ix, const k4_rescue_task& tk, const uint8_t* __restrict__ reads, int lane,
                            uint8_t* rs, k4_hit& h) {
   int res = 0;
-  uint32_t best = 0xFFFFFFFFu;  // (mm << 20) | (locus - sp)
+  unsigned long long best = ~0ull;  // (mm << 32) | (locus - sp)
   uint32_t sp = 0, ep = 0;
   const int len = (int)tk.read_len;
   bool run = false;
@@ -44,11 +52,11 @@ K4_DEV int k4d_mate_rescue(const K4DevIndex& ix, const k4_rescue_task& tk, const
           ep = tk.end_loci - min_ins;
         }
       }
-      if (run && (ep - sp) >= 1000) { run = false; res = K4_ERR_UNSUPPORTED; }  // the reference's CoreLen==0 path
       // AdaptiveTrim parameter validation (:5598-5603): failing it means no locus is ever accepted
       if (run && (len < 25 || len > 2048 || (uint32_t)tk.max_allowed_mm > (uint32_t)((15 * len + 99) / 100))) run = false;
     }
     if (run) {
+      uint64_t* pk = reinterpret_cast<uint64_t*>(rs + K4_MAX_READ_LEN);
       __syncthreads();  // (blocks are one wave)
       const uint8_t* src = reads + tk.read_off;
       for (int q = lane; q < len; q += 64) {
@@ -57,31 +65,71 @@ K4_DEV int k4d_mate_rescue(const K4DevIndex& ix, const k4_rescue_task& tk, const
         rs[q] = b;
       }
       __syncthreads();
+      const int nw = (len + 31) >> 5;
+      bool has_n = false;
+      for (int w = lane; w < nw; w += 64) {
+        uint64_t acc = 0;
+        for (int q = 0; q < 32; q++) {
+          const int j = 32 * w + q;
+          uint32_t b = j < len ? rs[j] : 0u;
+          if (b > 3) { has_n = true; b = 0; }
+          acc = (acc << 2) | b;
+        }
+        pk[w] = acc;
+      }
+      const bool packed = __ballot(has_n) == 0;
+      __syncthreads();
       const uint32_t max_allowed = ((uint32_t)len * (uint32_t)tk.max_allowed_mm + 99) / 100;
       for (uint32_t loci = sp + lane; loci <= ep; loci += 64) {
         const uint64_t g = cs + loci;
         uint32_t mm = 0;
         bool ok = true;
-        for (int o = 0; o < len; o++) {
-          if (rs[o] != k4d_ref_base(ix, g + o)) {
-            if (++mm > max_allowed) { ok = false; break; }
-            if (o < 3 || (len - o) < 3) { ok = false; break; }
+        if (packed && !k4d_any_exc(ix, (int64_t)g, (int64_t)g + len)) {
+          const int al = (int)(g & 15);
+          uint64_t flank = 0;
+          for (int c0 = 0; 32 * c0 < len; c0 += 4) {
+            const int rem = len - 32 * c0;
+            uint64_t rc[4];
+            k4d_ref_chunks4(ix, (int64_t)g, c0, rem + al <= 128, rc);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              if (32 * c < rem) {
+                const int base = 32 * (c0 + c);
+                const uint64_t x = (rc[c] ^ pk[c0 + c]) & k4d_range_mask(0, rem - 32 * c);
+                mm += k4d_mm_count(x);
+                if (base < 3) flank |= x & k4d_range_mask(0, 3 - base);                                   // read bases 0..2
+                if (len - 2 - base < 32 && len - base > 0) flank |= x & k4d_range_mask(len - 2 - base, len - base);  // the last two
+              }
+          }
+          ok = flank == 0 && mm <= max_allowed;
+        } else {
+          for (int o = 0; o < len; o++) {
+            if (rs[o] != k4d_ref_base(ix, g + o)) {
+              if (++mm > max_allowed) { ok = false; break; }
+              if (o < 3 || (len - o) < 3) { ok = false; break; }
+            }
           }
         }
-        if (ok && mm <= (uint32_t)tk.max_allowed_mm) best = min(best, (mm << 20) | (loci - sp));
+        if (ok && mm <= (uint32_t)tk.max_allowed_mm) {
+          const unsigned long long v = ((unsigned long long)mm << 32) | (loci - sp);
+          best = v < best ? v : best;
+        }
       }
     }
   } else
     res = -1;
-  for (int d = 32; d > 0; d >>= 1) best = min(best, (uint32_t)__shfl_xor(best, d, 64));
+  for (int d = 32; d > 0; d >>= 1) {
+    const unsigned long long o = __shfl_xor(best, d, 64);
+    best = o < best ? o : best;
+  }
   memset(&h, 0, sizeof(h));
-  if (run && best != 0xFFFFFFFFu) {
+  if (run && best != ~0ull) {
     res = 1;
     h.chrom_id = tk.chrom_id;
-    h.match_loci = sp + (best & 0xFFFFF);
+    h.match_loci = sp + (uint32_t)(best & 0xFFFFFFFFu);
     h.match_len = (uint16_t)len;
     h.strand = tk.antisense ? '-' : '+';
-    h.mismatches = (uint8_t)(best >> 20);
+    h.mismatches = (uint8_t)(best >> 32);
   }
   return res;
 }
@@ -89,7 +137,7 @@ K4_DEV int k4d_mate_rescue(const K4DevIndex& ix, const k4_rescue_task& tk, const
 __global__ void __launch_bounds__(64) k4k_mate_rescue(K4DevIndex ix, const k4_rescue_task* __restrict__ tasks,
                                                       const uint8_t* __restrict__ reads, int64_t n_tasks,
                                                       int32_t* __restrict__ rslt, k4_hit* __restrict__ hits) {
-  __shared__ uint8_t rs[K4_MAX_READ_LEN];  // the mate, oriented as it must align ('-': reverse complemented)
+  __shared__ __attribute__((aligned(8))) uint8_t rs[K4_RESCUE_LDS];  // the mate, oriented as it must align ('-': reverse complemented)
   const int lane = threadIdx.x;
   for (int64_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
     const k4_rescue_task tk = tasks[t];
@@ -141,8 +189,7 @@ extern "C" int k4_mate_rescue_batch(k4_index* ix, int64_t n, const k4_rescue_tas
   int rc = k4_check_hip(ix, hipStreamSynchronize(st), "mate rescue");
   if (rc != K4_OK) return rc;
   for (int64_t i = 0; i < n; i++)
-    if (rslt[i] == K4_ERR_UNSUPPORTED)
-      return k4_fail(ix, K4_ERR_UNSUPPORTED, "insert window of 1000 or more loci (reference takes its CoreLen==0 seed path): keep -D minus -d below 1000");
+
   return K4_OK;
 }
 
@@ -251,7 +298,7 @@ __global__ void __launch_bounds__(64) k4k_pe_orphans(K4DevIndex ix, k4_pe_params
                                                      const uint64_t* __restrict__ offs, const uint32_t* __restrict__ lens,
                                                      const uint32_t* __restrict__ orphans, k4_pe_read* __restrict__ out,
                                                      uint32_t* __restrict__ ctl) {
-  __shared__ uint8_t rs[K4_MAX_READ_LEN];
+  __shared__ __attribute__((aligned(8))) uint8_t rs[K4_RESCUE_LDS];
   const int lane = threadIdx.x;
   const uint32_t n_orph = ctl[0];
   for (uint32_t t = blockIdx.x; t < n_orph; t += gridDim.x) {
@@ -281,7 +328,6 @@ __global__ void __launch_bounds__(64) k4k_pe_orphans(K4DevIndex ix, k4_pe_params
       tk.max_allowed_mm = max_subs;  // the per-100 bp rate, as the reference passes it (KAligner.cpp:3379, Q15)
       k4_hit h;
       const int res = k4d_mate_rescue(ix, tk, reads, lane, rs, h);
-      if (res == K4_ERR_UNSUPPORTED && lane == 0) atomicOr(&ctl[1], 1u);
       if (res != 1) continue;
       const uint32_t hs = h.match_loci, he = h.match_loci + h.match_len - 1;
       const uint32_t as = anchor.hit.match_loci, ae = anchor.hit.match_loci + anchor.hit.match_len - 1;
@@ -353,11 +399,7 @@ extern "C" int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, c
                        (const uint8_t*)d_reads, (const uint64_t*)d_offs, (const uint32_t*)d_lens, ix->pe_list,
                        (k4_pe_read*)d_out, ix->pe_ctl);
   K4_HIP(ix, hipGetLastError());
-  uint32_t ctl[2] = {0, 0};
-  K4_HIP(ix, hipMemcpyAsync(ctl, ix->pe_ctl, 8, hipMemcpyDeviceToHost, st));
-  K4_HIP(ix, hipStreamSynchronize(st));
-  if (ctl[1])
-    return k4_fail(ix, K4_ERR_UNSUPPORTED, "insert window of 1000 or more loci (reference takes its CoreLen==0 seed path): keep -D minus -d below 1000");
+  K4_HIP(ix, hipStreamSynchronize(st));  // (the call's contract, include/k4sfx.h: the stream is waited for)
   return K4_OK;
 }
 

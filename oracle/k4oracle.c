@@ -917,8 +917,13 @@ static int adaptive_trim_full(int seq_len, const uint8_t* probe, const uint8_t* 
   return 0;
 }
 
-/* AlignPairedRead, SfxArray.cpp:8571-8767, MinChimericLen == 0, insert window < 1000 (linear scan :8731-8766).
- * Returns 1 with *out filled, 0 no match, -1 bad arguments, -3 window >= 1000 (degenerate CoreLen==0 path, unsupported) */
+/* AlignPairedRead, SfxArray.cpp:8571-8767, MinChimericLen == 0: the linear scan of :8731-8766.
+ * Returns 1 with *out filled, 0 no match, -1 bad arguments.
+ * Windows of 1000 loci or more: the reference takes its seed branch there (:8685-8726) with CoreLen forced to 0 (:8616-8620),
+ * and IterateExactsRange (:3461-3553) with a zero-length probe never sees a mismatch, so its do/while walks past the end of
+ * the suffix array: `ngskit4b kalign -U1 -d100 -D1500` on tests/golden/g1.sfx ends with SIGSEGV at the first rescue.  There
+ * is nothing to restate; the linear-scan rule is applied to windows of any size (parity UNPINNED for that case: no reference
+ * output can exist). */
 int k4o_align_paired_read(const k4o_index* ix, int b3prime, int antisense, uint32_t chrom_id, uint32_t start_loci,
                           uint32_t end_loci, int min_insert, int max_insert, int max_allowed_mm, int read_len,
                           const uint8_t* read, k4o_hit* out) {
@@ -941,7 +946,6 @@ int k4o_align_paired_read(const k4o_index* ix, int b3prime, int antisense, uint3
     sp = end_loci <= (uint32_t)max_insert ? 0 : end_loci - max_insert;
     ep = end_loci - min_insert;
   }
-  if ((ep - sp) >= 1000) return -3;
   uint8_t* rs = (uint8_t*)malloc((size_t)read_len + 1);
   memcpy(rs, read, (size_t)read_len);
   if (antisense) k4o_revcomp(rs, read_len);
@@ -997,7 +1001,6 @@ static int try_rescue(pe_job* j, const k4o_pe_read* anchor, int anchor_is_pe1, c
   int r = k4o_align_paired_read(j->ix, b3, anti, anchor->hit.chrom_id, st, en, pe->pair_min_len, pe->pair_max_len,
                                 j->kp.max_subs, mate_len, seq, hit);
   free(seq);
-  if (r == -3) j->bad = 1;
   if (r == 1) {
     uint32_t hs = hit->match_loci, he = hit->match_loci + hit->match_len - 1;
     *frag = anchor_is_pe1 ? k4o_pe_insert_size(pe->pair_min_len, pe->pair_max_len, pe->pair_strand, anchor->hit.strand, st, en, hit->strand, hs, he)

@@ -306,6 +306,31 @@ def test_reference_sam_end_to_end(k4, golden_dir, g2_path, case):
     ix.close()
 
 
+@pytest.mark.parametrize("lo,hi", [(100, 1500), (150, 5000)])
+def test_mate_rescue_over_windows_of_1000_loci_and_more(k4, oracle, golden_dir, lo, hi):
+    """Insert windows of 1000 loci or more: the reference itself has no behaviour there (its zero-length-seed loop walks off the
+    suffix array: tests/test_oracle_sam_golden.py::test_reference_dies_on_wide_rescue_window); device and oracle apply the
+    linear-scan rule (SfxArray.cpp:8731-8766) to the whole window -- packed XOR/popcount scan vs the symbol loop."""
+    names, chroms = synth.golden_genome()
+    pe1, pe2, _ = synth.make_pe_reads(chroms, 2500, 125, seed=77 + hi, sub_lambda=2.2, n_prob=0.04, random_mate_frac=0.05,
+                                      frag_min=260, frag_max=min(hi, 1400))
+    ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    ho = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    ix.set_max_iter(5000)
+    oracle.set_max_iter(ho, 5000)
+    kw = dict(pe_mode=1, pair_min_len=lo, pair_max_len=hi, pair_strand=False, max_subs=3)
+    g = ix.kalign_pe_batch(pe1, pe2, **kw)
+    o = oracle_kalign_pe(oracle, ho, pe1, pe2, threads=8, **kw)
+    for f in ("nar", "num_hits", "inst", "low_mm", "pe_aligned", "rescued"):
+        bad = np.nonzero(g[f] != o[f])[0]
+        assert len(bad) == 0, (f, bad[:6], g[f][bad[:6]], o[f][bad[:6]])
+    acc = g["nar"] == 1
+    assert np.array_equal(g["hit"][acc], o["hit"][acc])
+    assert g["rescued"].sum() > 20
+    ix.close()
+    oracle.close(ho)
+
+
 @pytest.mark.parametrize("pe_mode,pair_strand", [(1, False), (2, False), (3, False), (4, False), (1, True)])
 def test_pe_flow_vs_oracle(k4, oracle, golden_dir, pe_mode, pair_strand):
     names, chroms = synth.golden_genome()

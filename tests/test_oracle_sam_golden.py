@@ -157,3 +157,32 @@ def test_pe_matches_reference_sam(oracle, golden_dir, case):
     if case == "pe_u1":
         assert out["rescued"].sum() > 0  # the mate-rescue path (AlignPairedRead) is exercised
     oracle.close(h)
+
+
+def test_reference_dies_on_wide_rescue_window(golden_dir, tmp_path):
+    """Why there is no golden SAM for `-U1 -d100 -D1500`: outside its chimeric mode AlignPairedRead (SfxArray.cpp:8616-8620,
+    8685-8690) hands IterateExactsRange (:3461-3553) a seed of length 0 for insert windows of 1000 loci or more; that loop ends
+    only on a mismatch, so it runs past the end of the suffix array.  The reference binary (built by oracle/Makefile, present in
+    the build container only) is run on the pe_u1 reads: it must die on a signal, not write a SAM."""
+    import subprocess
+
+    ngs = os.path.join(os.path.dirname(golden_dir), "..", "oracle", "_ref", "ngskit4b")
+    if not os.path.exists(ngs):
+        pytest.skip("oracle/_ref/ngskit4b is not built here")
+    files = []
+    for s_ in ("1", "2"):
+        n, r = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_pe_u1_%s.fa.xz" % s_))
+        fa = tmp_path / ("r%s.fa" % s_)
+        with open(fa, "w") as f:
+            for a, b in zip(n, r):
+                f.write(">%s\n%s\n" % (a, "".join("ACGTN"[min(int(x), 4)] for x in b)))
+        files.append(str(fa))
+    r = subprocess.run([ngs, "kalign", "-I", os.path.join(golden_dir, "g1.sfx"), "-o", str(tmp_path / "o.sam"), "-T", "2", "-F",
+                        str(tmp_path / "log.txt"), "-s2", "-U1", "-d100", "-D1500", "-i", files[0], "-u", files[1]],
+                       capture_output=True, timeout=300)
+    assert r.returncode < 0, r.returncode  # killed by a signal (SIGSEGV)
+    # the same reads with a window below 1000 loci run to completion (the committed golden sam_pe_u1 is -d200 -D600)
+    r = subprocess.run([ngs, "kalign", "-I", os.path.join(golden_dir, "g1.sfx"), "-o", str(tmp_path / "o2.sam"), "-T", "2", "-F",
+                        str(tmp_path / "log2.txt"), "-s2", "-U1", "-d200", "-D600", "-i", files[0], "-u", files[1]],
+                       capture_output=True, timeout=300)
+    assert r.returncode == 0
