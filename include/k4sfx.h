@@ -366,6 +366,16 @@ int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, const void* d_r
                           const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
                           const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
                           uint8_t* chrom_hit, void* stream);
+/* k4_format_bam_dev <- the same alignments as uncompressed BAM records in coordinate order (CSAMfile::AddAlignment's BAM branch,
+ * SAMfile.cpp:2379-2640: block_size, refID, pos, bin<<16|MAPQ<<8|l_read_name, FLAG<<16|n_cigar_op, l_seq, next_refID,
+ * next_pos, tlen, read_name, cigar, 4-bit seq -- reverse complemented for a Crick alignment --, qual 0xff).  refID is the
+ * index in the header's reference dictionary: every sequence of the index when sq_all, else those that received a hit, in
+ * index order (WriteBAMReadHits, KAligner.cpp:5785-5821).  Magic, header text, dictionary, BGZF blocks and the .bai index
+ * are the caller's (include/k4_bam.hpp does them on host threads). */
+int k4_format_bam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                      const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
+                      const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes, k4_sam_stats* stats,
+                      uint8_t* chrom_hit, void* stream);
 /* k4_select_hits_dev <- MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962) after k4_kalign_batch_dev with pe_mode 2: every accepted
  * read keeps ONE instance, hits[choice[i] % NumHits] moved to slot 0, NumHits = 1.  d_choice: uint32 per read, the caller's
  * draws (the reference: rand() once per read within the limit, in load order when it runs one thread). */
@@ -413,6 +423,8 @@ int k4_pipeline_submit(k4_pipeline* pl, int end, uint64_t bytes, int final_chunk
 int k4_pipeline_submit_host(k4_pipeline* pl, int end, const void* text, uint64_t bytes, int final_chunk);
 int k4_pipeline_wait_aligned(k4_pipeline* pl, k4_pipeline_view* view); /* after the final chunks: every read is aligned */
 int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit /* host, n_entries + 1, or NULL */, uint64_t* sam_bytes);
+/* ... as BAM records (k4_format_bam_dev); the pieces come down through k4_pipeline_next_sam / k4_pipeline_read_sam all the same */
+int k4_pipeline_format_bam(k4_pipeline* pl, int32_t sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* bam_bytes);
 int k4_pipeline_next_sam(k4_pipeline* pl, const void** ptr, uint64_t* bytes); /* valid until the next call; 0 bytes: done */
 int k4_pipeline_read_sam(k4_pipeline* pl, void* dst, uint64_t cap, uint64_t* bytes); /* the whole body into caller memory */
 void k4_pipeline_close(k4_pipeline* pl);

@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
-    "k4_get_kernel_times", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
+    "k4_get_kernel_times", "k4_format_bam_dev", "k4_pipeline_format_bam", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
     "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
     "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",
@@ -199,6 +199,9 @@ def lib():
     L.k4_remove_orphan_juncts_dev.argtypes = [vp, u32, i64, C.c_int32, vp, vp, vp, C.POINTER(C.c_int64), vp]
     L.k4_format_sam_ext_dev.argtypes = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(SamNames), C.POINTER(vp),
                                         C.POINTER(u64), C.POINTER(SamStats), vp, vp]
+    L.k4_format_bam_dev.argtypes = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(SamNames), C.c_int32, C.POINTER(vp),
+                                    C.POINTER(u64), C.POINTER(SamStats), vp, vp]
+    L.k4_pipeline_format_bam.argtypes = [vp, C.c_int32, C.POINTER(SamStats), vp, C.POINTER(u64)]
     L.k4_pipeline_open.argtypes = [vp, C.POINTER(PipelineParams), C.POINTER(vp)]
     L.k4_pipeline_acquire.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u64)]
     L.k4_pipeline_submit.argtypes = [vp, i32, u64, i32]
@@ -512,8 +515,9 @@ class SfxIndex:
         return {"reads": reads, "offs": d_offs[:tot], "lens": d_lens[:tot], "n_under": under.value, "n_over": over.value,
                 "max_len": ml.value, "n_units": n, "pe": pe}
 
-    def format_sam(self, prep, p1, p2=None, rr=None, hits=None, max_ml=1, pe_recs=None, seg2=None):
-        """SAM body (bytes), stats dict and per-chromosome hit flags for device-resident results."""
+    def format_sam(self, prep, p1, p2=None, rr=None, hits=None, max_ml=1, pe_recs=None, seg2=None, bam=False, sq_all=True):
+        """SAM body (bytes), stats dict and per-chromosome hit flags for device-resident results.  bam=True: the same
+        alignments as uncompressed BAM records (k4_format_bam_dev), refIDs for a header of all (sq_all) / the hit sequences."""
         import torch
 
         names = SamNames()
@@ -525,14 +529,15 @@ class SfxIndex:
         d_sam, nbytes, stats = C.c_void_p(), C.c_uint64(), SamStats()
         ne = self.info()["n_entries"]
         chrom_hit = np.zeros(ne + 1, dtype=np.uint8)
-        self._ck(lib().k4_format_sam_ext_dev(self.h, 1 if prep["pe"] else 0, prep["n_units"],
-                                         rr.data_ptr() if rr is not None else None,
-                                         hits.data_ptr() if hits is not None else None, max_ml,
-                                         pe_recs.data_ptr() if pe_recs is not None else None,
-                                         seg2.data_ptr() if seg2 is not None else None, prep["reads"].data_ptr(),
-                                         prep["offs"].data_ptr(), prep["lens"].data_ptr(), C.byref(names), C.byref(d_sam),
-                                         C.byref(nbytes), C.byref(stats), chrom_hit.ctypes.data,
-                                         torch.cuda.current_stream().cuda_stream))
+        head = (self.h, 1 if prep["pe"] else 0, prep["n_units"], rr.data_ptr() if rr is not None else None,
+                hits.data_ptr() if hits is not None else None, max_ml, pe_recs.data_ptr() if pe_recs is not None else None,
+                seg2.data_ptr() if seg2 is not None else None, prep["reads"].data_ptr(), prep["offs"].data_ptr(),
+                prep["lens"].data_ptr(), C.byref(names))
+        tail = (C.byref(d_sam), C.byref(nbytes), C.byref(stats), chrom_hit.ctypes.data, torch.cuda.current_stream().cuda_stream)
+        if bam:
+            self._ck(lib().k4_format_bam_dev(*head, 1 if sq_all else 0, *tail))
+        else:
+            self._ck(lib().k4_format_sam_ext_dev(*head, *tail))
         body = b""
         if nbytes.value:
             buf = np.empty(nbytes.value, dtype=np.uint8)

@@ -453,6 +453,7 @@ struct K4SamArgs {
   const char* cnames;           // n_entries x K4_SAM_NAME_STRIDE
   const uint8_t* cname_len;
   uint32_t n_entries;
+  const int32_t* refid;         // BAM: chromosome id - 1 -> index in the header's reference dictionary
 };
 #define K4_SAM_NAME_STRIDE 96
 
@@ -470,6 +471,7 @@ K4_DEV bool k4d_sam_reported(const K4SamArgs& a, int64_t v) {
 
 struct K4SamFields {
   uint32_t flag, pos, mapq, pnext;
+  uint32_t aligned;  // AdjAlignHitLen: aligned bases of both segments
   int32_t tlen;
   bool mate_eq;
   uint32_t n_ops;
@@ -495,6 +497,7 @@ K4_DEV K4SamFields k4d_sam_fields(const K4SamArgs& a, int64_t v, const k4_hit& h
   const uint32_t tl = K4_HIT_TRIM_LEFT(h), tr = K4_HIT_TRIM_RIGHT(h);
   const uint32_t len0 = k4d_adj_len0(h), len1 = two ? s2.match_len : 0u;
   f.pos = k4d_adj_start(h) + 1;
+  f.aligned = len0 + len1;
   f.n_ops = 0;
   const uint32_t lead = h.strand == '+' ? tl : tr, trail = h.strand == '+' ? tr : tl;
   if (lead) { f.op_len[f.n_ops] = lead; f.op[f.n_ops++] = 'S'; }
@@ -604,9 +607,88 @@ K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t v) {
   n += a.lens[i] + 1 + 1 /* '*' */ + 1 /* '\n' */;
   return n;
 }
+// the same alignment as a BAM record (CSAMfile::AddAlignment's BAM branch, SAMfile.cpp:2379-2640, over ReportBAMread's fields):
+// block_size | refID pos bin_mq_nl flag_nc l_seq next_refID next_pos tlen | read_name\0 | cigar | seq (4-bit) | qual (0xff: none)
+K4_DEV uint32_t k4d_bam_n_ops(const K4SamArgs& a, int64_t v, const k4_hit& h) {
+  const uint32_t tl = K4_HIT_TRIM_LEFT(h), tr = K4_HIT_TRIM_RIGHT(h);
+  const bool two = !a.pe && a.seg2 && k4d_two_segs(h);
+  return 1u + (tl ? 1u : 0u) + (tr ? 1u : 0u) + (two ? 2u : 0u);
+}
+K4_DEV uint32_t k4d_bam_rec_len(const K4SamArgs& a, int64_t v) {
+  const k4_hit h = k4d_sam_hit(a, v);
+  const int64_t i = k4d_sam_read(a, v);
+  const int w = a.pe ? (int)(i & 1) : 0;
+  const int64_t rec = a.pe ? (i >> 1) : i;
+  const uint32_t len = a.lens[i];
+  return 4u + 32u + a.name_len[w][rec] + 1u + 4u * k4d_bam_n_ops(a, v, h) + (len + 1) / 2 + len;
+}
+template <bool BAM>
 __global__ void __launch_bounds__(256) k4k_sam_line_lens(K4SamArgs a, const uint32_t* __restrict__ order, uint64_t m, uint32_t* __restrict__ ll) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j < m) ll[j] = k4d_sam_line_len(a, order[j]);
+  if (j < m) ll[j] = BAM ? k4d_bam_rec_len(a, order[j]) : k4d_sam_line_len(a, order[j]);
+}
+// calculate bin given an alignment covering [beg, end) (SAM specification; CKAligner::BAMreg2bin, KAligner.cpp:5929-5938)
+K4_DEV uint32_t k4d_bam_reg2bin(int32_t beg, int32_t end) {
+  --end;
+  if (beg >> 14 == end >> 14) return ((1 << 15) - 1) / 7 + (beg >> 14);
+  if (beg >> 17 == end >> 17) return ((1 << 12) - 1) / 7 + (beg >> 17);
+  if (beg >> 20 == end >> 20) return ((1 << 9) - 1) / 7 + (beg >> 20);
+  if (beg >> 23 == end >> 23) return ((1 << 6) - 1) / 7 + (beg >> 23);
+  if (beg >> 26 == end >> 26) return ((1 << 3) - 1) / 7 + (beg >> 26);
+  return 0;
+}
+K4_DEV void k4d_put_le32(char* p, uint32_t v) { p[0] = (char)v; p[1] = (char)(v >> 8); p[2] = (char)(v >> 16); p[3] = (char)(v >> 24); }
+// one record (or sub-lane `sub`'s share of its sequence and quality bytes) at `line`
+K4_DEV void k4d_bam_put_rec(const K4SamArgs& a, int64_t v, const k4_hit& h, int64_t i, char* line, uint32_t line_len, int sub, int lpl) {
+  const uint32_t len = a.lens[i];
+  const uint32_t nseq = (len + 1) / 2;
+  char* seq = line + line_len - len - nseq;
+  char* qual = line + line_len - len;
+  if (sub == 0) {
+    const K4SamFields f = k4d_sam_fields(a, v, h);
+    const int w = a.pe ? (int)(i & 1) : 0;
+    const int64_t rec = a.pe ? (i >> 1) : i;
+    const uint32_t nl_ = a.name_len[w][rec];
+    const int32_t refid = a.refid[h.chrom_id - 1];
+    const int32_t pos0 = (int32_t)f.pos - 1;
+    k4d_put_le32(line, line_len - 4);
+    k4d_put_le32(line + 4, (uint32_t)refid);
+    k4d_put_le32(line + 8, (uint32_t)pos0);
+    k4d_put_le32(line + 12, (k4d_bam_reg2bin(pos0, pos0 + (int32_t)f.aligned) << 16) | (f.mapq << 8) | (nl_ + 1));
+    k4d_put_le32(line + 16, (f.flag << 16) | f.n_ops);
+    k4d_put_le32(line + 20, len);
+    k4d_put_le32(line + 24, f.mate_eq ? (uint32_t)refid : 0xFFFFFFFFu);
+    k4d_put_le32(line + 28, f.mate_eq ? f.pnext - 1 : 0xFFFFFFFFu);
+    k4d_put_le32(line + 32, (uint32_t)f.tlen);
+    char* p = line + 36;
+    const uint8_t* nm = a.text[w] + a.name_off[w][rec];
+    for (uint32_t q = 0; q < nl_; q++) p[q] = (char)nm[q];
+    p[nl_] = 0;
+    p += nl_ + 1;
+    for (uint32_t q = 0; q < f.n_ops; q++) {
+      const char c = f.op[q];
+      const uint32_t code = c == 'M' ? 0u : c == 'I' ? 1u : c == 'D' ? 2u : c == 'N' ? 3u : 4u;
+      k4d_put_le32(p, (f.op_len[q] << 4) | code);
+      p += 4;
+    }
+  }
+  // sequence: `=ACMGRSVTWYHKDBN' codes, first base in the high nibble, reverse complemented for a Crick alignment (:6254-6300)
+  const uint8_t* s = a.reads + a.offs[i];
+  const uint32_t b0 = (uint32_t)((uint64_t)nseq * sub / lpl), b1 = (uint32_t)((uint64_t)nseq * (sub + 1) / lpl);
+  const uint64_t fwd = 0x0F0F0F0F08040201ull, rev = 0x0F0F0F0F01020408ull;  // by symbol: A C G T N.. / their complements
+  for (uint32_t b = b0; b < b1; b++) {
+    uint32_t hi, lo = 0;
+    if (h.strand == '+') {
+      hi = (uint32_t)(fwd >> (8 * (s[2 * b] & 7))) & 0xF;
+      if (2 * b + 1 < len) lo = (uint32_t)(fwd >> (8 * (s[2 * b + 1] & 7))) & 0xF;
+    } else {
+      hi = (uint32_t)(rev >> (8 * (s[len - 1 - 2 * b] & 7))) & 0xF;
+      if (2 * b + 1 < len) lo = (uint32_t)(rev >> (8 * (s[len - 2 - 2 * b] & 7))) & 0xF;
+    }
+    seq[b] = (char)((hi << 4) | lo);
+  }
+  const uint32_t q0 = (uint32_t)((uint64_t)len * sub / lpl), q1 = (uint32_t)((uint64_t)len * (sub + 1) / lpl);
+  for (uint32_t q = q0; q < q1; q++) qual[q] = (char)0xFF;
 }
 
 // QNAME FLAG RNAME POS MAPQ <len>M RNEXT PNEXT TLEN SEQ * (AddAlignment, SAMfile.cpp:2194-2377).  The lines of the sorted
@@ -682,7 +764,7 @@ K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int
   }
 }
 
-template <int LPL>
+template <int LPL, bool BAM>
 __global__ void __launch_bounds__(256) k4k_sam_write(K4SamArgs a, const uint32_t* __restrict__ order, const uint64_t* __restrict__ loff,
                                                      uint64_t m, char* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) char sm[4][K4_SAM_WAVE_BUF];
@@ -703,8 +785,9 @@ __global__ void __launch_bounds__(256) k4k_sam_write(K4SamArgs a, const uint32_t
       const k4_hit h = k4d_sam_hit(a, v);
       const int64_t i = k4d_sam_read(a, v);
       const uint64_t l0 = loff[j], l1 = loff[j + 1];
-      if (fits) k4d_sam_put_line(a, v, h, i, &sm[wave][pad + (uint32_t)(l0 - b0)], (uint32_t)(l1 - l0), sub, LPL);
-      else k4d_sam_put_line(a, v, h, i, out + l0, (uint32_t)(l1 - l0), sub, LPL);
+      char* dst_line = fits ? &sm[wave][pad + (uint32_t)(l0 - b0)] : out + l0;
+      if (BAM) k4d_bam_put_rec(a, v, h, i, dst_line, (uint32_t)(l1 - l0), sub, LPL);
+      else k4d_sam_put_line(a, v, h, i, dst_line, (uint32_t)(l1 - l0), sub, LPL);
     }
     __syncthreads();
     if (fits) {
@@ -781,10 +864,28 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
   return k4_format_sam_ext_dev(ix, pe, n_units, d_rr, d_hits, max_ml, d_pe, nullptr, d_reads, d_offs, d_lens, names, d_sam, sam_bytes,
                                stats, chrom_hit, stream);
 }
+static int format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                          const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
+                          const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
+                          k4_sam_stats* stats, uint8_t* chrom_hit, void* stream);
 extern "C" int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                                      const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
                                      const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
                                      k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
+  return format_records(ix, 0, 0, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_sam, sam_bytes, stats,
+                        chrom_hit, stream);
+}
+extern "C" int k4_format_bam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                                 const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
+                                 const void* d_lens, const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes,
+                                 k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
+  return format_records(ix, 1, sq_all, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_bam, bam_bytes, stats,
+                        chrom_hit, stream);
+}
+static int format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                          const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
+                          const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
+                          k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
   if (!ix || !names || !d_sam || !sam_bytes) return K4_ERR_PARAMS;
   *d_sam = nullptr;
   *sam_bytes = 0;
@@ -854,8 +955,20 @@ extern "C" int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, cons
     stats->minus = hs[21];
     stats->n_lines = m;
   }
-  if (chrom_hit) K4_HIP(ix, hipMemcpy(chrom_hit, chb.p, ne + 1, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> ch_host(ne + 1, 0);
+  K4_HIP(ix, hipMemcpy(ch_host.data(), chb.p, ne + 1, hipMemcpyDeviceToHost));
+  if (chrom_hit) memcpy(chrom_hit, ch_host.data(), ne + 1);
   if (m == 0) return K4_OK;
+  Buf refid;
+  if (bam) {  // the reference dictionary of the header the caller writes: every sequence, or those with a hit, in index order
+    std::vector<int32_t> map(ne, -1);
+    int32_t next = 0;
+    for (uint32_t e = 0; e < ne; e++)
+      if (sq_all || ch_host[e + 1]) map[e] = next++;
+    K4_HIP(ix, refid.alloc((size_t)ne * 4));
+    K4_HIP(ix, hipMemcpy(refid.p, map.data(), (size_t)ne * 4, hipMemcpyHostToDevice));
+    a.refid = refid.as<int32_t>();
+  }
   // SortHitMatch (KAligner.cpp:10969): chrom, start, len, strand, mismatches; equal keys keep load order.
   // Two stable radix sorts: minor key first, then (chrom, start).
   K4_HIP(ix, idx1.alloc(m * 4));
@@ -890,7 +1003,8 @@ extern "C" int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, cons
   K4_HIP(ix, ll.alloc((m + 1) * 4));
   K4_HIP(ix, lo.alloc((m + 1) * 8));
   K4_HIP(ix, hipMemsetAsync(ll.as<uint32_t>() + m, 0, 4, st));
-  hipLaunchKernelGGL(k4k_sam_line_lens, dim3(mb), dim3(256), 0, st, a, order, m, ll.as<uint32_t>());
+  if (bam) hipLaunchKernelGGL(k4k_sam_line_lens<true>, dim3(mb), dim3(256), 0, st, a, order, m, ll.as<uint32_t>());
+  else hipLaunchKernelGGL(k4k_sam_line_lens<false>, dim3(mb), dim3(256), 0, st, a, order, m, ll.as<uint32_t>());
   {
     size_t tb = 0;
     K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, ll.as<uint32_t>(), lo.as<uint64_t>(), (uint64_t)0, (size_t)(m + 1),
@@ -910,9 +1024,15 @@ extern "C" int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, cons
     const int lpl = avg * 64 * 5 / 4 <= K4_SAM_WAVE_BUF ? 1 : avg * 32 * 5 / 4 <= K4_SAM_WAVE_BUF ? 2 : 4;
     const uint64_t per_block = 4 * (64 / lpl);
     const dim3 grid((unsigned)std::min<uint64_t>((m + per_block - 1) / per_block, 1u << 16));
-    if (lpl == 1) hipLaunchKernelGGL(k4k_sam_write<1>, grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
-    else if (lpl == 2) hipLaunchKernelGGL(k4k_sam_write<2>, grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
-    else hipLaunchKernelGGL(k4k_sam_write<4>, grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+    if (bam) {
+      if (lpl == 1) hipLaunchKernelGGL((k4k_sam_write<1, true>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+      else if (lpl == 2) hipLaunchKernelGGL((k4k_sam_write<2, true>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+      else hipLaunchKernelGGL((k4k_sam_write<4, true>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+    } else {
+      if (lpl == 1) hipLaunchKernelGGL((k4k_sam_write<1, false>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+      else if (lpl == 2) hipLaunchKernelGGL((k4k_sam_write<2, false>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+      else hipLaunchKernelGGL((k4k_sam_write<4, false>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+    }
   }
   int rc = k4_check_hip(ix, hipGetLastError(), "SAM write");
   if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(st), "SAM write");

@@ -398,7 +398,16 @@ extern "C" int k4_pipeline_wait_aligned(k4_pipeline* pl, k4_pipeline_view* v) {
   return K4_OK;
 }
 
+static int pipeline_format(k4_pipeline* pl, int bam, int sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* sam_bytes);
 extern "C" int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* sam_bytes) {
+  return pipeline_format(pl, 0, 0, stats, chrom_hit, sam_bytes);
+}
+// the same alignments as BAM records (uncompressed, coordinate order): the caller deflates them into BGZF blocks as the pieces
+// come down (k4_pipeline_next_sam) and writes header and index
+extern "C" int k4_pipeline_format_bam(k4_pipeline* pl, int32_t sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* bam_bytes) {
+  return pipeline_format(pl, 1, sq_all, stats, chrom_hit, bam_bytes);
+}
+static int pipeline_format(k4_pipeline* pl, int bam, int sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* sam_bytes) {
   if (!pl) return K4_ERR_PARAMS;
   k4_pipeline_view v;
   int rc = k4_pipeline_wait_aligned(pl, &v);
@@ -407,8 +416,10 @@ extern "C" int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t*
   pl->sam_bytes = pl->sam_next = pl->sam_given = 0;
   if (stats) memset(stats, 0, sizeof(*stats));
   if (v.n_units > 0 && v.max_read_len > 0)
-    rc = k4_format_sam_ext_dev(pl->ix, pl->n_ends == 2 ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_seg2, v.d_reads, v.d_offs,
-                               v.d_lens, &v.names, &pl->d_sam, &pl->sam_bytes, stats, chrom_hit, pl->s_comp);
+    rc = bam ? k4_format_bam_dev(pl->ix, pl->n_ends == 2 ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_seg2, v.d_reads, v.d_offs,
+                                 v.d_lens, &v.names, sq_all, &pl->d_sam, &pl->sam_bytes, stats, chrom_hit, pl->s_comp)
+             : k4_format_sam_ext_dev(pl->ix, pl->n_ends == 2 ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_seg2, v.d_reads, v.d_offs,
+                                     v.d_lens, &v.names, &pl->d_sam, &pl->sam_bytes, stats, chrom_hit, pl->s_comp);
   if (sam_bytes) *sam_bytes = pl->sam_bytes;
   return rc;
 }

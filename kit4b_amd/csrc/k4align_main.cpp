@@ -31,6 +31,7 @@
 #include <sys/wait.h>
 #include "../../include/k4comm.h"
 #include "../../include/k4sfx.h"
+#include "../../include/k4_bam.hpp"
 #include "k4_merge.h"
 
 namespace {
@@ -52,7 +53,8 @@ struct Opts {
   int print_slices = 0;             // -W <n>: print the byte offsets -G would cut the reads files at for n ranks, and stop (no GPU needed)
   bool legacy = false;              // -Z: the serial whole-input path of round 1 (one batch, no overlap), kept for comparison
   int chunk_mb = 256;               // -B <MB>: size of one pinned upload buffer of the pipeline
-  int io_threads = 8;               // -t <n>: concurrent pread / pwrite calls per buffer
+  int io_threads = 8;               // -t <n>: concurrent pread / pwrite calls per buffer; BAM: deflate threads
+  int bam_level = 6;                // -z <0..9>: BGZF deflate level of a .bam output (WriteBAMReadHits is called with 6, KAligner.cpp:759)
 };
 
 struct Parsed {  // one reads file after k4_parse_fastx_dev: everything lives in HBM
@@ -373,7 +375,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 
 void usage() {
   fprintf(stderr,
-          "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
+          "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam|out.bam [-z bgzf level=6] [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
           "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
@@ -612,6 +614,9 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   k4_pipeline* pl = nullptr;
   uint64_t pl_sam_bytes = 0;
   const bool pipelined = o.batch_mb <= 0 && o.n_shards == 1 && !o.legacy;
+  // "-o x.bam": BGZF compressed BAM, any other extension SAM (KAlignerCL.cpp:857-866)
+  const bool bam_out = o.out.size() >= 4 && strcasecmp(o.out.c_str() + o.out.size() - 4, ".bam") == 0;
+  if (bam_out && (!pipelined || multi)) { fprintf(stderr, "k4align: BAM output is written by the pipelined single-GPU mode (not with -b, -S, -G, -Z)\n"); return 3; }
   if (pipelined) {
     for (const std::vector<std::string>* fs : {&o.in1, &o.in2})
       for (const std::string& q : *fs) {
@@ -665,7 +670,8 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     s_parse = secs(tr, now()) - s_read;  // what the device side added behind the reading
     auto tg = now();
     CK(global_stages(v.n_units, v.max_read_len, v.d_rr, v.d_hits, v.d_seg2, v.d_pe, v.d_reads, v.d_offs, v.d_lens));
-    CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
+    if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= 10000 ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
+    else CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     s_align = secs(tg, now());
     n_under = v.n_under; n_over = v.n_over; n_units = (uint64_t)v.n_units;
   }
@@ -726,6 +732,39 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
 
   // ---- SAM file: header here, body as formatted on the device ----------------------------------------------------------
   auto tw = now();
+  if (bam_out) {
+    // ---- BAM (+ .bai): dictionary and BGZF blocks here (include/k4_bam.hpp), the records as packed on the device ------------
+    std::string hdr = "@HD\tVN:1.4\tSO:coordinate\n";
+    std::vector<k4bam::RefSeq> refs;
+    const bool all_sq = info.n_entries <= 10000;  // m_MaxRptSAMSeqsThres, KAligner.cpp:5785-5821
+    for (uint32_t c = 1; c <= info.n_entries; c++) {
+      k4_entry e;
+      k4_get_entry(ix, c, &e);
+      if (!(all_sq || hit_chrom[c])) continue;
+      hdr += std::string("@SQ\tAS:") + info.dataset + "\tSN:" + e.name + "\tLN:" + std::to_string(e.seq_len) + "\n";
+      refs.push_back({e.name, e.seq_len});
+    }
+    hdr += "@PG\tID:k4align\tVN:1.0\n";
+    k4bam::Writer bw;
+    if (!bw.open(o.out, hdr, refs, o.bam_level, std::max(o.io_threads, 1))) { fprintf(stderr, "k4align: %s\n", bw.error().c_str()); return 5; }
+    for (;;) {  // the records come down piece by piece; the previous piece is deflated and written meanwhile
+      const void* ptr = nullptr;
+      uint64_t len = 0;
+      CK(k4_pipeline_next_sam(pl, &ptr, &len));
+      if (len == 0) break;
+      if (!bw.write(ptr, (size_t)len)) { fprintf(stderr, "k4align: %s\n", bw.error().c_str()); return 5; }
+    }
+    if (!bw.close()) { fprintf(stderr, "k4align: %s\n", bw.error().c_str()); return 5; }
+    if (bw.n_records() != my_lines) { fprintf(stderr, "k4align: internal error: %llu BAM records for %llu alignments\n", (unsigned long long)bw.n_records(), (unsigned long long)my_lines); return 5; }
+    k4_pipeline_close(pl);
+    const double s_write_bam = secs(tw, now());
+    if (chatty)
+      fprintf(stderr, "k4align: %llu alignments reported to %s (%llu bytes) + .bai; index %.2fs, reads %.2fs, device side behind the reads %.2fs, "
+                      "global stages + sort + records %.2fs, deflate + write %.2fs\n", (unsigned long long)bw.n_records(), o.out.c_str(),
+              (unsigned long long)bw.compressed_bytes() + 28, secs(t0, t_open), s_read, s_parse, s_align, s_write_bam);
+    k4_close(ix);
+    return 0;
+  }
   FILE* fp = fopen(o.out.c_str(), "wb");
   if (!fp) { fprintf(stderr, "k4align: unable to create %s\n", o.out.c_str()); return 5; }
   static char iobuf[1 << 22];
@@ -923,6 +962,7 @@ int main(int argc, char** argv) {
       case 'B': o.chunk_mb = std::max(1, atoi(val().c_str())); break;
       case 't': o.io_threads = std::max(1, atoi(val().c_str())); break;
       case 'Z': o.legacy = true; break;
+      case 'z': o.bam_level = std::min(9, std::max(0, atoi(val().c_str()))); break;
       case 'W': o.print_slices = atoi(val().c_str()); break;
       case 'T': case 'F': (void)val(); break;  // accepted and ignored (threads, log file)
       default: usage(); return 1;

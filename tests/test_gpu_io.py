@@ -474,3 +474,55 @@ def test_k4align_rank_mode_over_rccl(golden_dir, tmp_path, case):
     for name, n in cases[case]["nar"].items():
         assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
     assert not os.path.exists(out + ".rank0")
+
+
+@pytest.mark.parametrize("case,level", [("se_s2", "6"), ("pe_u1", "1"), ("se_all_120", "6")])
+def test_k4align_writes_the_reference_bam(golden_dir, tmp_path, case, level):
+    """`k4align -o x.bam`: records packed on the device (k4_pipeline_format_bam), BGZF blocks and .bai on host threads
+    (include/k4_bam.hpp) -- decoded, the file holds the reference's BAM record for record (tests/golden/bam_<case>.bam, written by
+    `ngskit4b kalign -o x.bam`: every fixed field incl. bin and MAPQ, name, CIGAR, packed sequence, qualities), the same
+    dictionary and header text but for the @PG line; region queries through the .bai find what a scan finds."""
+    import json
+    import lzma
+    import random
+    import subprocess
+
+    import samutil
+    from test_bam_cpu import brute, regions
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(golden_dir, "sam_cases.json")))
+
+    def unxz(name):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        return dst
+
+    index = cases[case].get("index", "g1")
+    sfx = os.path.join(golden_dir, index + ".sfx") if os.path.exists(os.path.join(golden_dir, index + ".sfx")) else unxz(index + ".sfx.xz")
+    files = ["-i", unxz("sam_%s.fa.xz" % case)] if case.startswith("se_") else \
+        ["-i", unxz("sam_%s_1.fa.xz" % case), "-u", unxz("sam_%s_2.fa.xz" % case)]
+    out = str(tmp_path / "o.BAM")  # (the extension decides, in any case: KAlignerCL.cpp:864)
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", sfx, "-o", out, "-z", level, "-t", "3"] + cases[case]["args"] + files,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    text, refs, recs, blocks = samutil.read_bam(out, with_offsets=True)
+    wtext, wrefs, wrecs = samutil.read_bam(os.path.join(golden_dir, "bam_%s.bam" % case))
+    assert refs == wrefs
+    assert [l for l in text.splitlines() if not l.startswith("@PG")] == [l for l in wtext.splitlines() if not l.startswith("@PG")]
+    key = lambda r: (r["ref"], r["pos"], r["name"], r["flag"])  # noqa: E731
+    strip = lambda r: {k: v for k, v in r.items() if k not in ("ubeg", "uend")}  # noqa: E731
+    assert sorted(map(strip, recs), key=key) == sorted(wrecs, key=key)
+    assert [(r["ref"], r["pos"]) for r in recs] == sorted((r["ref"], r["pos"]) for r in recs)  # coordinate order
+    bai = samutil.read_bai(out + ".bai")
+    rng = random.Random(11)
+    for ref, beg, end in regions(refs, rng, 60):
+        assert samutil.bai_fetch(recs, blocks, bai, ref, beg, end) == brute(recs, ref, beg, end)
+    for name, n in cases[case]["nar"].items():
+        assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+    # modes that do not write BAM say so
+    if index != "g1":
+        return
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", sfx, "-o", out, "-b", "1"] + cases[case]["args"] + files,
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3 and "BAM output" in p.stderr
