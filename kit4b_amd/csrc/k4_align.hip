@@ -24,6 +24,7 @@
 #include "k4_device.h"
 
 #define K4_NEED_SLOW (-100)
+#define K4_DEFER (-101)  // first launch only: the read met a deep k-mer bucket; it is taken again in the launch of its like
 #define K4_RF_HAS_N 1u
 #define K4_RF_INVALID 2u
 #define K4_RF_TOOLONG 4u
@@ -57,6 +58,19 @@
 #ifndef K4_SLOW_WAVES_PER_EU_EXT
 #define K4_SLOW_WAVES_PER_EU_EXT 2
 #endif
+// A read whose first phase meets a k-mer bucket deeper than this (a repeat family: the lower-bound search alone costs
+// log2(depth) dependent probes where its 63 wave mates need one or two) is set aside by the first launch and taken in a
+// launch of its own together with the others of its kind, so that the many waves without such a read do not wait for it;
+// its survivors stay together in their own chunks through the later phases.
+#ifndef K4_DEFER_BUCKET
+#define K4_DEFER_BUCKET K4_DEEP_BUCKET
+#endif
+// ... and one whose bucket is this deep goes to the general kernel at once: a family of hundreds of copies overflows the
+// fast path's candidate list whatever the phase
+#ifndef K4_GENERAL_BUCKET
+#define K4_GENERAL_BUCKET 160
+#endif
+#define K4_DEFER_MIN_FRAC 0.002  // of the index's suffixes in buckets that deep: below it the first launch is not split
 #ifndef K4_SLOW_KB
 #define K4_SLOW_KB 1  // general kernel: suffixes per lane per walk step (measured: 2 and 4 cost occupancy and lose 25 %)
 #endif
@@ -66,6 +80,7 @@
 #define K4_SMALL_HASH 4096  // entries of a pass-0 dedupe table (2047 candidates per strand pass)
 #define K4_HUGE_WAVES 256
 #define K4_CTL_HUGE 68  // ctl[68] huge count, ctl[69] huge head
+#define K4_CTL_DEFER 70  // ctl[70] slots handed out in the deferred list of the first launch
 #define K4_CTL_WORDS 72  // [0] slow count, [1] slow head, [2+t] survivors of step t
 
 struct K4AlignArgs {
@@ -93,6 +108,7 @@ struct K4AlignArgs {
   uint8_t* slow_step;  // phase ordinal at which the read left the fast path (its earlier phases are already tallied)
   uint32_t* huge_list; // reads whose strand pass outgrew the small dedupe tables: second general pass with big tables
   uint8_t* huge_step;
+  uint32_t* defer_ids;  // first launch: list of the reads set aside (chunked like the survivor lists, ctl[K4_CTL_DEFER])
   uint32_t* ctl;
   unsigned long long* counters;
   uint8_t* slow_probe;
@@ -317,7 +333,7 @@ K4_DEV K4Probe k4d_probe(const K4DevIndex& ix, const K4Lane<NCH>& ln, int s, int
 template <int EL, int NCH, typename KT, bool CAPTURE>
 K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, int allow_mm, int cl, int core_delta,
                         const K4ReadParams& rp, int* p_inst, int* p_low, int* p_nxt, k4_hit* hits,
-                        uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand) {
+                        uint32_t& n_lookup, uint32_t& n_probe, uint32_t& n_cand, bool defer_deep = false) {
   const K4DevIndex& ix = a.ix;
   if (*p_inst > rp.max_hits && *p_low == 0) return K4_HR_HITINSTS;  // :5889-5895 (unreachable for fresh reads)
   if (*p_inst >= 1 && *p_low == 0 && (*p_nxt - *p_low) < rp.mm_delta) return K4_HR_MMDELTA;
@@ -385,6 +401,8 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           const uint64_t code = ln.chunk_at(s, oo[j]) >> (64 - 2 * kk);
           uint64_t sub;
           k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j], sub);
+          if (CAPTURE && defer_deep && tshift == 0 && (uint64_t)(lb1[j] - lb0[j]) > K4_DEFER_BUCKET)
+            return (uint64_t)(lb1[j] - lb0[j]) > K4_GENERAL_BUCKET ? K4_NEED_SLOW : K4_DEFER;
           if (sizeof(KT) == 8 && tshift == 0 && cl >= kk + 2 && sub != K4_KTAB64_IRREGULAR) {
             // straight to the suffixes that continue with the core's next two bases
             uint32_t before, count;
@@ -596,7 +614,7 @@ K4_DEV uint32_t k4d_pack_read(const uint8_t* __restrict__ src, int len, uint64_t
 
 // One AlignReads phase per launch.  FIRST: lanes take reads j = 0..n_reads-1 and pack them; later steps take the
 // compacted survivors (ids + packed rows) of the previous step.
-template <int EL, int NCH, bool FIRST, typename KT>
+template <int EL, int NCH, bool FIRST, typename KT, bool DEFER = false>
 __global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : NCH >= 8 ? K4_STEP_WAVES_MID : NCH == 5 ? K4_STEP_WAVES_5 : K4_STEP_WAVES)) k4k_align_step(K4AlignArgs a, int step, const uint32_t* __restrict__ in_ids,
                                                       const uint64_t* __restrict__ in_rows,
                                                       const uint32_t* __restrict__ in_count, uint32_t* __restrict__ out_ids,
@@ -622,29 +640,35 @@ __global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : 
   __syncthreads();
   uint64_t* col = lds + tid;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0, n_slow = 0, n_bases = 0, n_done = 0;
-  const int64_t count = FIRST ? a.n_reads : (int64_t)*in_count;
+  const int64_t count = (FIRST && !(DEFER && in_ids != nullptr)) ? a.n_reads : (int64_t)*in_count;
   const int64_t stride = (int64_t)gridDim.x * K4_BS(NCH);
   // Survivor slots are reserved K4_CHUNK at a time (one atomic per chunk, not per wave iteration: a single counter
   // word serialises at ~88 atomics/us).  ch_cur / ch_left are wave-uniform: every lane of the wave runs every
   // iteration of this loop, inactive lanes masked, so the copies never diverge.  Unused slots hold K4_NO_READ.
   uint32_t ch_cur = 0, ch_left = 0;
+  // FIRST comes in two launches: every read (in_ids null), then the reads the first one set aside (in_ids = that list)
+  const bool from_list = !FIRST || (DEFER && in_ids != nullptr);
+  const bool may_defer = DEFER && FIRST && in_ids == nullptr && a.defer_ids != nullptr;
+  uint32_t dch_cur = 0, dch_left = 0;  // the deferred list's chunk, as ch_cur / ch_left
   for (int64_t jb = (int64_t)blockIdx.x * K4_BS(NCH) + (tid & ~63); jb < count; jb += stride) {
     const int64_t j = jb + lane;
     bool active = j < count;
     int64_t i = 0;
     if (active) {
-      i = FIRST ? j : (int64_t)in_ids[j];
-      if (!FIRST && (uint32_t)i == K4_NO_READ) active = false;
+      i = from_list ? (int64_t)in_ids[j] : j;
+      if (from_list && (uint32_t)i == K4_NO_READ) active = false;
     }
-    bool slow = false, survive = false;
+    bool slow = false, survive = false, deferred = false;
     int ext_from = -1;  // >= 0: every standard phase ran here without a result; the general kernel starts at the optional ones
     if (active) {
       const int len = (int)a.lens[i];
       const K4ReadParams rp = k4d_read_params(a, len);
       bool skip = false;
       if (FIRST) {
-        n_done++;
-        n_bases += (uint32_t)len;
+        if (!from_list) {  // (a read taken from the deferred list was counted when it was set aside)
+          n_done++;
+          n_bases += (uint32_t)len;
+        }
         uint32_t fl = 0, n_ns = 0;
         if (len < 1 || len > 32 * NCH || len > K4_MAX_FAST_READ_LEN) {
           fl = K4_RF_TOOLONG;
@@ -706,9 +730,13 @@ __global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : 
         int inst = 0, low = 0, nxt = 0;
         const uint32_t c0 = n_lookup, c1 = n_probe, c2 = n_cand;
         if (FIRST) { ln.memo[0] = K4_MEMO_NONE; ln.memo[K4_BS(NCH)] = K4_MEMO_NONE; }
-        int rslt = k4d_lcm_fast<EL, NCH, KT, FIRST>(a, ln, len, allow, cl, delta, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand);
+        int rslt = k4d_lcm_fast<EL, NCH, KT, FIRST>(a, ln, len, allow, cl, delta, rp, &inst, &low, &nxt, hits, n_lookup, n_probe, n_cand, DEFER && may_defer);
         if (rslt == K4_NEED_SLOW) {  // the general kernel redoes (and tallies) this phase
           slow = true;
+          n_lookup = c0; n_probe = c1; n_cand = c2;
+        }
+        else if (DEFER && rslt == K4_DEFER) {  // the second launch of this step runs the phase from its start (what was stored so far is stored again)
+          deferred = true;
           n_lookup = c0; n_probe = c1; n_cand = c2;
         }
         else if (rslt == 0 && step + 1 >= n_phases && a.ext_on) { slow = true; ext_from = n_phases; }  // :7894-7930
@@ -718,6 +746,22 @@ __global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : 
       if (slow) {
         k4d_push_slow(a, i, ext_from >= 0 ? ext_from : step);
         n_slow++;
+      }
+    }
+    if (FIRST && DEFER) {  // the reads set aside: ids only, in chunks like the survivors
+      const unsigned long long dm = __ballot(deferred);
+      const uint32_t dcnt = (uint32_t)__popcll(dm);
+      if (dcnt) {
+        if (dcnt > dch_left) {
+          for (uint32_t q = lane; q < dch_left; q += 64) a.defer_ids[dch_cur + q] = K4_NO_READ;
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&a.ctl[K4_CTL_DEFER], (uint32_t)K4_CHUNK);
+          dch_cur = __shfl(base, 0, 64);
+          dch_left = K4_CHUNK;
+        }
+        if (deferred) a.defer_ids[dch_cur + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        dch_cur += dcnt;
+        dch_left -= dcnt;
       }
     }
     // compaction of the survivors: slots by prefix popcount of the wave's ballot inside the wave's current chunk
@@ -754,6 +798,8 @@ __global__ void __launch_bounds__(K4_BS(NCH), (NCH >= 16 ? K4_STEP_WAVES_LONG : 
     }
   }
   for (uint32_t q = lane; q < ch_left; q += 64) out_ids[ch_cur + q] = K4_NO_READ;
+  if (FIRST && DEFER)
+    for (uint32_t q = lane; q < dch_left; q += 64) a.defer_ids[dch_cur + q] = K4_NO_READ;
   // per-wave tallies -> one atomic per counter per wave (lookups of reads that went slow are recounted there)
   {
     unsigned long long v[6] = {n_done, n_lookup, n_probe, n_cand, n_slow, n_bases};
@@ -1834,7 +1880,8 @@ static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t s
   const size_t lds = (size_t)2 * (NCH + 1) * K4_BS(NCH) * 8 + (size_t)K4_DEDUP_CAP * K4_BS(NCH) * 4 + (size_t)2 * K4_BS(NCH) * 8 + (size_t)2 * K4_LDS_ENTRIES * 8 +
                      (size_t)K4_SUP_WORDS * 4 + 16;
   if (lds > 48 * 1024) {
-    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true, KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, true, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_step<EL, NCH, false, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   // grid-stride kernels: enough blocks to fill the chip at the kernel's occupancy, never more than the work
@@ -1851,8 +1898,21 @@ static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t s
     K4_HIP(ix, hipEventRecord(ix->ev0[ix->ev_used], st));
   }
   unsigned grid0 = (unsigned)std::min<int64_t>((a.n_reads + K4_BS(NCH) - 1) / K4_BS(NCH), full);
-  hipLaunchKernelGGL((k4k_align_step<EL, NCH, true, KT>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, 0, (const uint32_t*)nullptr,
-                     (const uint64_t*)nullptr, (const uint32_t*)nullptr, w.ids[0], w.rows[0], w.ctl + 2);
+  // step 0 in two launches: every read, then those it set aside (deep k-mer buckets), listed in the id buffer step 1 will
+  // overwrite; both append their survivors to the same list
+  // -- on an index with repeat families (share of the suffixes in deep k-mer buckets, measured when the table was built);
+  // elsewhere one launch without the code for it, which costs the first phase 4 % in registers (C2: 2335 -> 2254 M reads/s)
+  if (ix->deep_bucket_frac >= K4_DEFER_MIN_FRAC) {
+    a.defer_ids = w.ids[1];
+    hipLaunchKernelGGL((k4k_align_step<EL, NCH, true, KT, true>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, 0, (const uint32_t*)nullptr,
+                       (const uint64_t*)nullptr, (const uint32_t*)nullptr, w.ids[0], w.rows[0], w.ctl + 2);
+    hipLaunchKernelGGL((k4k_align_step<EL, NCH, true, KT, true>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, 0, (const uint32_t*)w.ids[1],
+                       (const uint64_t*)nullptr, (const uint32_t*)(w.ctl + K4_CTL_DEFER), w.ids[0], w.rows[0], w.ctl + 2);
+  } else {
+    a.defer_ids = nullptr;
+    hipLaunchKernelGGL((k4k_align_step<EL, NCH, true, KT, false>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, 0, (const uint32_t*)nullptr,
+                       (const uint64_t*)nullptr, (const uint32_t*)nullptr, w.ids[0], w.rows[0], w.ctl + 2);
+  }
   for (int t = 1; t < n_steps; t++) {
     const int in = (t - 1) & 1, out = t & 1;
     hipLaunchKernelGGL((k4k_align_step<EL, NCH, false, KT>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, t, w.ids[in], w.rows[in],

@@ -264,6 +264,21 @@ static int choose_k(uint64_t n, int want) {
   return std::max(6, k);
 }
 
+// suffixes that sit in buckets deeper than K4_DEEP_BUCKET (after the lb scan, before the 64-bit form's counts go into the high
+// bits): the share of repeat families in the index, which decides how the first alignment phase is launched (k4_align.hip)
+template <typename T>
+__global__ void __launch_bounds__(256) k4k_ktab_deep(const T* __restrict__ tab, uint64_t n_codes, unsigned long long* __restrict__ total) {
+  constexpr int ST = sizeof(T) == 4 ? K4_KTAB_STRIDE32 : K4_KTAB_STRIDE64;
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  unsigned long long mine = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < n_codes; c += stride) {
+    const uint64_t size = (uint64_t)tab[ST * (c + 1)] - (uint64_t)tab[ST * c];
+    if (size > K4_DEEP_BUCKET) mine += size;
+  }
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+}
+
 template <int EL, typename T>
 static int build_ktab(k4_index* ix) {
   uint64_t nent = (1ull << (2 * ix->d.k)) + 1;
@@ -288,6 +303,16 @@ static int build_ktab(k4_index* ix) {
   K4_HIP(ix, hipGetLastError());
   K4_HIP(ix, hipDeviceSynchronize());
   K4_HIP(ix, hipFree(agg));
+  {
+    unsigned long long* d_deep = nullptr;
+    unsigned long long deep = 0;
+    K4_HIP(ix, hipMalloc(&d_deep, 8));
+    K4_HIP(ix, hipMemset(d_deep, 0, 8));
+    hipLaunchKernelGGL((k4k_ktab_deep<T>), dim3(8192), dim3(256), 0, 0, (const T*)tab, nent - 1, d_deep);
+    K4_HIP(ix, hipMemcpy(&deep, d_deep, 8, hipMemcpyDeviceToHost));
+    K4_HIP(ix, hipFree(d_deep));
+    ix->deep_bucket_frac = ix->d.n ? (double)deep / (double)ix->d.n : 0.0;
+  }
   if (sizeof(T) == 8) {
     const uint64_t n_codes = nent - 1;
     hipLaunchKernelGGL((k4k_ktab_subcounts<EL>), dim3((unsigned)std::min<uint64_t>((n_codes + 255) / 256, 1ull << 22)), dim3(256), 0, 0, ix->d,

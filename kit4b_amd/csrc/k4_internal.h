@@ -32,6 +32,7 @@
 #define K4_MAX_FAST_READ_LEN 512   // longer reads run in the general kernel
 #define K4_MAX_READ_LEN 4096       // cMaxSeqLen is 2000 (KAligner.h:115)
 #define K4_PROF_SLOTS 32          // u64 slots behind k4_counters for builds with -DK4_SLOW_PROF (tools/slow_prof.py)
+#define K4_DEEP_BUCKET 24          // k-mer table buckets deeper than this mark repeat families (k4_align.hip: K4_DEFER_BUCKET)
 #define K4_DEDUP_CAP 6             // distinct candidates per strand pass kept by the fast kernel
 #define K4_MAX_IDENT_NODES 1024000 // cMaxNumIdentNodes, libkit4b/SfxArray.h:15
 
@@ -101,6 +102,7 @@ struct k4_index {
   uint64_t* ent_end = nullptr;
   uint32_t* ent_id = nullptr;
   uint64_t* counters = nullptr; // device k4_counters
+  double deep_bucket_frac = 0;  // share of the suffixes that sit in k-mer buckets deeper than K4_DEEP_BUCKET (k4_index.hip)
   std::vector<k4_entry> entries;
   std::string dataset;
   std::string description, title;  // header text for k4_write_sfx (k4_set_description)
