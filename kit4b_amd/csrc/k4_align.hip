@@ -65,11 +65,8 @@
 #ifndef K4_DEFER_BUCKET
 #define K4_DEFER_BUCKET K4_DEEP_BUCKET
 #endif
-// ... and one whose bucket is this deep goes to the general kernel at once: a family of hundreds of copies overflows the
-// fast path's candidate list whatever the phase
-#ifndef K4_GENERAL_BUCKET
-#define K4_GENERAL_BUCKET 160
-#endif
+// (Sending the reads with the deepest buckets straight to the general kernel instead was measured and lost: half of them are
+// settled by the fast path -- 2.08 M instead of 1.06 M reads per 50 M in the general kernel, 91 ms instead of 74.)
 #define K4_DEFER_MIN_FRAC 0.002  // of the index's suffixes in buckets that deep: below it the first launch is not split
 #ifndef K4_SLOW_KB
 #define K4_SLOW_KB 1  // general kernel: suffixes per lane per walk step (measured: 2 and 4 cost occupancy and lose 25 %)
@@ -401,8 +398,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           const uint64_t code = ln.chunk_at(s, oo[j]) >> (64 - 2 * kk);
           uint64_t sub;
           k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j], sub);
-          if (CAPTURE && defer_deep && tshift == 0 && (uint64_t)(lb1[j] - lb0[j]) > K4_DEFER_BUCKET)
-            return (uint64_t)(lb1[j] - lb0[j]) > K4_GENERAL_BUCKET ? K4_NEED_SLOW : K4_DEFER;
+          if (CAPTURE && defer_deep && tshift == 0 && (uint64_t)(lb1[j] - lb0[j]) > K4_DEFER_BUCKET) return K4_DEFER;
           if (sizeof(KT) == 8 && tshift == 0 && cl >= kk + 2 && sub != K4_KTAB64_IRREGULAR) {
             // straight to the suffixes that continue with the core's next two bases
             uint32_t before, count;
