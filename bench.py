@@ -406,7 +406,7 @@ def kernel_src_sha256():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("k4_align.hip", "k4_device.h", "k4_internal.h"):
+    for f in ("k4_align.hip", "k4_device.h", "k4_internal.h", "k4_ext.h"):
         h.update(open(os.path.join(ROOT, "kit4b_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -22,13 +22,13 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(src, "trace", "runc", "*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
+shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
 for f in ("bench_trace.json", "randgather_pmc.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 out = {}
 for kind in ("pmc_sq", "pmc_tcc", "pmc_fetch", "pmc_write", "cal_fetch", "cal_tcc"):
-    fs = glob.glob(os.path.join(src, kind, "runc", "*_counter_collection.csv"))
+    fs = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -65,7 +65,7 @@ if os.path.exists(shaf):
         v, f = ln.split()
         box[os.path.basename(f)] = v
 same = True
-for f in ("k4_align.hip", "k4_device.h", "k4_internal.h"):
+for f in ("k4_align.hip", "k4_device.h", "k4_internal.h", "k4_ext.h"):
     data = open(os.path.join("kit4b_amd", "csrc", f), "rb").read()
     h.update(data)
     same &= box.get(f, hashlib.sha256(data).hexdigest()) == hashlib.sha256(data).hexdigest()
@@ -81,7 +81,7 @@ hbm = {"tag": tag, "workload": workload, "kernel": "k4k_align_step (all phases o
        "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_EA0_RDREQ": rdreq,
        "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
        "kernel_src_sha256": h.hexdigest() if same else None,
-       "kernel_src_note": "sha256 over k4_align.hip + k4_device.h + k4_internal.h; null when the sources profiled on the GPU box "
+       "kernel_src_note": "sha256 over k4_align.hip + k4_device.h + k4_internal.h + k4_ext.h; null when the sources profiled on the GPU box "
                           "differ from the working tree at summarise time",
        "head": head + ("+uncommitted" if dirty else ""),
        "note": "read side doubled per MI355X_MICROARCH.md (FETCH_SIZE tallies 64 B per 128-B request on gfx950)"}
