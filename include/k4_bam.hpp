@@ -126,11 +126,12 @@ class Writer {
 
   bool append(const uint8_t* p, size_t n, bool records) {
     if (records) scan_records(p, n);
+    const size_t batch = kBlock * (size_t)threads_ * 64;  // blocks deflated per flush: 64 per thread (4 MB each)
     while (n) {
-      const size_t take = std::min(n, kBlock * (size_t)threads_ * 4 - pend_.size());
+      const size_t take = std::min(n, batch - pend_.size());
       pend_.insert(pend_.end(), p, p + take);
       p += take; n -= take;
-      if (pend_.size() >= kBlock * (size_t)threads_ * 4 && !flush(false)) return false;
+      if (pend_.size() >= batch && !flush(false)) return false;
     }
     return true;
   }
@@ -149,6 +150,13 @@ class Writer {
         body_.clear();
       }
       const size_t take = std::min<size_t>(need_ - body_.size(), n - i);
+      if (body_.empty() && take == need_) {  // the whole record lies in this piece: indexed in place
+        consumed_ += take;
+        index_record(p + i, need_, rec_ubeg_, header_bytes_ + consumed_);
+        i += take;
+        need_ = 0;
+        continue;
+      }
       body_.insert(body_.end(), p + i, p + i + take);
       i += take;
       consumed_ += take;

@@ -1,6 +1,6 @@
 """File-to-file timing of `k4align` on the C2 workload: a 3 Gbp index (.sfx, 15 GB) and 50 M x 100 bp FASTQ reads (10.8 GB) in
 tmpfs -> coordinate-sorted SAM in tmpfs; the overlapped pipeline (default) next to the serial whole-input path of round 1
-(-Z).    python tools/e2e_files.py [n_reads=50000000] [out.json]"""
+(-Z), and BAM (+ .bai) output at deflate levels 6 and 1.    python tools/e2e_files.py [n_reads=50000000] [out.json]"""
 import json
 import os
 import subprocess
@@ -58,12 +58,12 @@ print("reads written (%.1f GB) in %.1fs" % (os.path.getsize(fq) / 1e9, time.time
 res = {"workload": "C2: %d x 100 bp FASTQ reads (%.1f GB) vs 3 Gbp .sfx (%.1f GB), files in tmpfs, kalign -s2" % (n_reads, os.path.getsize(fq) / 1e9, os.path.getsize(sfx) / 1e9)}
 exe = os.path.join(ROOT, "kit4b_amd", "k4align")
 sams = {}
-for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r01", ["-Z"])):
-    sam = os.path.join(tmp, tag + ".sam")
+for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r01", ["-Z"]), ("bam_z6_t16", ["-t", "16"]), ("bam_z1_t16", ["-t", "16", "-z", "1"])):
+    sam = os.path.join(tmp, tag + (".bam" if tag.startswith("bam") else ".sam"))
     t0 = time.time()
     p = subprocess.run([exe, "-I", sfx, "-i", fq, "-o", sam, "-s2"] + extra, capture_output=True, text=True)
     wall = time.time() - t0
-    last = [l for l in p.stderr.splitlines() if "alignments written" in l]
+    last = [l for l in p.stderr.splitlines() if "alignments written" in l or "alignments reported to" in l]
     res[tag] = {"rc": p.returncode, "wall_s": wall, "report": last[-1] if last else p.stderr[-500:], "sam_GB": os.path.getsize(sam) / 1e9 if os.path.exists(sam) else None}
     import re
     m = re.search(r"index ([\d.]+)s", res[tag]["report"])
@@ -71,7 +71,13 @@ for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r0
         res[tag]["Mreads_s_excl_index_load"] = n_reads / (wall - float(m.group(1))) / 1e6
         res[tag]["Mreads_s_wall"] = n_reads / wall / 1e6
     print(tag, json.dumps(res[tag]), flush=True)
-    sams[tag] = sam
+    if tag.startswith("bam"):
+        res[tag]["bai_MB"] = os.path.getsize(sam + ".bai") / 1e6 if os.path.exists(sam + ".bai") else None
+        for f in (sam, sam + ".bai"):
+            if os.path.exists(f):
+                os.remove(f)
+    else:
+        sams[tag] = sam
 if all(os.path.exists(s) for s in sams.values()):
     import hashlib
 
