@@ -148,7 +148,7 @@ def make_reads(seq, n_chrom, chrom_len, n_reads, read_len, seed, dev, chunk=1 <<
         r = seq[start[:, None] + ar[None, :]]
         nsubs = mutate(r, g, dev)
         strand = torch.randint(0, 2, (m,), device=dev, generator=g)
-        rc = (3 - r).flip(1)
+        rc = torch.where(r < 4, 3 - r, r).flip(1)  # (N stays N: 3 - 4 would wrap to 255 in uint8, a symbol above N)
         r = torch.where(strand[:, None] == 1, rc, r)
         reads[b:b + m] = r
         truth[b:b + m, 0] = c + 1
@@ -179,7 +179,7 @@ def make_pe_reads(seq, n_chrom, chrom_len, n_pairs, read_len, seed, dev, frag_mi
         base = c * (chrom_len + 1) + off
         left = seq[base[:, None] + ar[None, :]]                          # fragment's leftmost read_len bases
         right = seq[(base + flen - read_len)[:, None] + ar[None, :]]     # and its rightmost
-        rrc = (3 - right).flip(1)
+        rrc = torch.where(right < 4, 3 - right, right).flip(1)
         fwd = (fstrand == 0)[:, None]
         pe1 = torch.where(fwd, left, rrc)   # '+' fragment: PE1 reads the left end forward; '-': revcomp of the right end
         pe2 = torch.where(fwd, rrc, left)   # PE2 = revcomp of the fragment's 3' end
