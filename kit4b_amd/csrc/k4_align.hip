@@ -825,6 +825,9 @@ struct K4Slow {
   bool small;       // first general pass: small tables, overflow defers the read to the pass with big tables
   const uint32_t* sup;  // LDS copy of the coarse exception bitmap (K4_SUP_WORDS words)
   const uint32_t* ent_id;  // entry ids: LDS copy when the entry table is in LDS, the index's array otherwise
+  uint32_t* lhash;   // first general pass over 4-byte suffix elements: the dedupe table in LDS (ids only, cleared per strand pass)
+  uint32_t lcap;     // its slots (power of two); lused: slots taken so far in this strand pass, retracted inserts included
+  uint32_t lused;
 #ifdef K4_SLOW_PROF
   unsigned long long prof[16];
 #endif
@@ -880,7 +883,34 @@ K4_DEV void k4d_revcomp_wave(K4Slow& sc, int len) {  // CSeqTrans::ReverseComple
 // One insert per lane, concurrently: the ids of one batch are distinct (one SA run, one core offset), so the only
 // interaction between lanes is the race for a free slot, which the compare-and-swap settles.  Returns whether the id was
 // new in this strand pass and the slot it occupies (for k4d_hash_retract).
+// The LDS form (K4Slow::lhash): 32-bit slots holding the id itself; TargSeqID = 1 + offset stays below both markers while
+// suffix elements are 4 bytes (offsets < 4 000 000 000).  No generation: k4d_hash_new_pass clears it.  An LDS compare-and-swap
+// costs a few hundred cycles where the HBM table's load + compare-and-swap cost two round trips to L2.
+#define K4_LH_EMPTY 0xFFFFFFFFu
+#define K4_LH_TOMB 0xFFFFFFFEu
+#define K4_LDS_HASH 1024
+K4_DEV void k4d_hash_new_pass(K4Slow& sc) {
+  sc.gen++;
+  if (sc.lhash) {
+    __syncthreads();  // (blocks are one wave)
+    for (uint32_t q = sc.lane; q < sc.lcap; q += 64) sc.lhash[q] = K4_LH_EMPTY;
+    sc.lused = 0;
+    __syncthreads();
+  }
+}
 K4_DEV bool k4d_hash_insert_lane(const K4Slow& sc, uint32_t id, uint32_t& slot) {
+  if (sc.lhash) {
+    uint32_t h = (id * 2654435761u) >> 22 & (sc.lcap - 1);
+    for (;;) {
+      uint32_t v = sc.lhash[h];
+      if (v == K4_LH_EMPTY) {
+        v = atomicCAS(&sc.lhash[h], K4_LH_EMPTY, id);
+        if (v == K4_LH_EMPTY) { slot = h; return true; }
+      }
+      if (v == id) { slot = h; return false; }
+      h = (h + 1) & (sc.lcap - 1);
+    }
+  }
   const unsigned long long key = ((unsigned long long)sc.gen << 32) | id;
   unsigned long long* tab = reinterpret_cast<unsigned long long*>(sc.hash);
   uint32_t h = (id * 2654435761u) & (sc.cap - 1);
@@ -901,6 +931,7 @@ K4_DEV bool k4d_hash_insert_lane(const K4Slow& sc, uint32_t id, uint32_t& slot) 
 // an insert that the reference would not have made (its walk had already stopped): the slot stays occupied for this
 // generation so that probe chains through it stay intact, but holds the impossible id 0 (TargSeqID is 1 + offset)
 K4_DEV void k4d_hash_retract(const K4Slow& sc, uint32_t slot) {
+  if (sc.lhash) { sc.lhash[slot] = K4_LH_TOMB; return; }
   atomicExch(reinterpret_cast<unsigned long long*>(sc.hash) + slot, (unsigned long long)sc.gen << 32);
 }
 
@@ -1163,11 +1194,14 @@ K4_DEV void k4d_exact_run_wave(const K4DevIndex& ix, K4Slow& sc, int o, int cl, 
   const int kk = min((int)ix.k, cl);
   bool acgt = true;
   uint64_t code = 0;
-  for (int j = 0; j < kk; j++) {  // uniform: every lane reads the same LDS bytes
-    const uint32_t b = sc.probe[o + j] & 0x0f;
-    if (b > 3) { acgt = false; break; }
-    code = (code << 2) | b;
-  }
+  if (sc.packed)  // the k-mer straight from the packed probe (two LDS words instead of kk byte reads)
+    code = k4d_probe_chunk(sc, o) >> (64 - 2 * kk);
+  else
+    for (int j = 0; j < kk; j++) {  // uniform: every lane reads the same LDS bytes
+      const uint32_t b = sc.probe[o + j] & 0x0f;
+      if (b > 3) { acgt = false; break; }
+      code = (code << 2) | b;
+    }
   if (acgt) {
     const int sh = 2 * ((int)ix.k - kk);
     lo = (int64_t)k4d_ktab_lb(ix, code << sh);
@@ -1247,10 +1281,10 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
     int cur_delta = core_delta;
     int slides = 0;
     uint32_t n_nodes = 0;
-    sc.gen++;
+    k4d_hash_new_pass(sc);
     // cMaxNumIdentNodes (SfxArray.h:15); additionally bounded by the scratch table so an insert always terminates.
     // A pass that fills a small table before the reference's own limit is redone with a big one (K4_NEED_SLOW).
-    const uint32_t node_cap = min((uint32_t)K4_MAX_IDENT_NODES, sc.cap / 2 - 1);
+    const uint32_t node_cap = min((uint32_t)K4_MAX_IDENT_NODES, sc.lhash ? sc.lcap * 3 / 4 : sc.cap / 2 - 1);
     for (int o = 0; slides < rp.max_slides && o <= len - cl && cur_delta > cl / 3 && n_nodes < node_cap;
          slides++, o += cur_delta) {
       if (o + cl + cur_delta > len) cur_delta = len - (o + cl);
@@ -1298,6 +1332,11 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
           r[k] = left_in_run >= 64 ? 64 : left_in_run > 0 ? (int)left_in_run : 0;
         }
         const bool ended = base + 64 * KB > t_last;
+        // the LDS table must keep room for this step's inserts (slots of retracted inserts count): else the pass with the big tables
+        if (sc.lhash && sc.lused + 64 * KB + 1 > sc.lcap) {
+          if (cur_strand == '-') k4d_revcomp_wave(sc, len);
+          return K4_NEED_SLOW;
+        }
         // 4. filters that precede the dedupe (:6019-6036: before the core offset, on a separator, over the entry end),
         //    then the dedupe insert, all lanes at once
 #pragma unroll
@@ -1317,6 +1356,7 @@ K4_DEV int k4d_lcm_slow(const K4AlignArgs& a, K4Slow& sc, int len, int allow_mm,
           if (clean[k]) k4d_ref_words9(ix, (int64_t)left, 0, len + (int)(left & 15) <= 128, win[k]);
           if (in_bounds) isnew[k] = k4d_hash_insert_lane(sc, (uint32_t)(1 + pos[k] - (uint32_t)o), slot[k]);
           K4_PROF_ADD(10, __popcll(__ballot(in_bounds)));
+          if (sc.lhash) sc.lused += (uint32_t)__popcll(__ballot(isnew[k]));  // (a retracted insert keeps its slot)
         }
         // 5. MaxIter / node limit: both count new in-bounds candidates only; the walk stops before the suffix after the
         //    last one it may take.  Inserts behind that point are retracted.
@@ -1484,8 +1524,8 @@ K4_DEV int k4d_best_slow(const K4AlignArgs& a, K4Slow& sc, int len, int max_tot_
   do {
     int cur_delta = core_delta, slides = 0;
     uint32_t n_nodes = 0;
-    sc.gen++;
-    const uint32_t node_cap = min((uint32_t)K4_MAX_IDENT_NODES, sc.cap / 2 - 1);
+    k4d_hash_new_pass(sc);
+    const uint32_t node_cap = min((uint32_t)K4_MAX_IDENT_NODES, sc.lhash ? sc.lcap * 3 / 4 : sc.cap / 2 - 1);
     for (int o = 0; slides < rp.max_slides && o <= len - cl && cur_delta > cl / 3 && n_nodes < node_cap; slides++, o += cur_delta) {
       if (o + cl + cur_delta > len) cur_delta = len - (o + cl);
       n_lookup++;
@@ -1642,6 +1682,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K
   uint8_t* probe_s = reinterpret_cast<uint8_t*>(pk_s + (max_len / 32 + 2));
   // (chimeric phase only) one mismatch bit vector per lane behind the probe bytes, word w of lane l at mk_s[w * 64 + l]
   uint32_t* mk_s = reinterpret_cast<uint32_t*>(probe_s + ((max_len + 64 + 7) & ~7)) + threadIdx.x;
+  // the pass-0 dedupe table (EL == 4, lean instantiation): behind the probe bytes, where the chimeric masks of the other one go
+  uint32_t* lhash_s = reinterpret_cast<uint32_t*>(probe_s + ((max_len + 64 + 7) & ~7));
   const uint32_t wave = blockIdx.x;
   const int lane = threadIdx.x;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0;
@@ -1658,6 +1700,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K
     K4Slow sc;
     sc.sup = sup_s;
     sc.ent_id = ent_in_lds ? entid_s : a.ix.ent_id;
+    sc.lhash = (EL == 4 && !EXT && pass == 0) ? lhash_s : nullptr;
+    sc.lcap = K4_LDS_HASH;
+    sc.lused = 0;
 #ifdef K4_SLOW_PROF
     for (int q = 0; q < 16; q++) sc.prof[q] = 0;
 #endif
@@ -1955,7 +2000,7 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
   const int slow_len = std::min(std::max(max_len, 1), K4_MAX_READ_LEN);
   const bool chim = a.ext_on && (a.mode == 0 ? a.ap.min_chimeric_len : a.kp.min_chimeric_len) > 0;
   const size_t slow_lds = (size_t)(a.ix.n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES * 8 + K4_LDS_ENTRIES * 4 : 0) + (size_t)K4_SUP_WORDS * 4 + (size_t)(slow_len / 32 + 2) * 8 +
-                          (size_t)((slow_len + 64 + 7) & ~7) + (chim ? (size_t)64 * 4 * ((slow_len + 31) / 32 + 1) : 0) + 16;
+                          (size_t)((slow_len + 64 + 7) & ~7) + std::max<size_t>(chim ? (size_t)64 * 4 * ((slow_len + 31) / 32 + 1) : 0, (size_t)K4_LDS_HASH * 4) + 16;
   if (slow_lds > 48 * 1024) K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_slow<EL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slow_lds));
   // (no more waves than reads: a batch of one -- the facade's AlignReads -- should not pay for 8192 idle blocks)
   const uint32_t sw = (uint32_t)std::min<int64_t>(K4_SLOW_WAVES, std::max<int64_t>(a.n_reads, 1));

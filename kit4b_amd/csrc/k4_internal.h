@@ -32,7 +32,9 @@
 #define K4_MAX_FAST_READ_LEN 512   // longer reads run in the general kernel
 #define K4_MAX_READ_LEN 4096       // cMaxSeqLen is 2000 (KAligner.h:115)
 #define K4_PROF_SLOTS 32          // u64 slots behind k4_counters for builds with -DK4_SLOW_PROF (tools/slow_prof.py)
+#ifndef K4_DEEP_BUCKET
 #define K4_DEEP_BUCKET 24          // k-mer table buckets deeper than this mark repeat families (k4_align.hip: K4_DEFER_BUCKET)
+#endif
 #define K4_DEDUP_CAP 6             // distinct candidates per strand pass kept by the fast kernel
 #define K4_MAX_IDENT_NODES 1024000 // cMaxNumIdentNodes, libkit4b/SfxArray.h:15
 
