@@ -890,12 +890,16 @@ int k4o_pe_insert_size(int pair_min_len, int pair_max_len, int pair_strand, uint
 }
 
 /* AcceptProvPE, KAligner.cpp:2799-2861 (no chromosome filters; hits are untrimmed full-length: Adj* are identities) */
-static int accept_prov_pe(const k4o_pe_params* pe, int nh1, const k4o_hit* h1, int nh2, const k4o_hit* h2) {
+/* AdjStartLoci / AdjEndLoci (KAligner.cpp:1633-1650) on the flat hit: trims live in ext (TrimLeft | TrimRight << 12) */
+static uint32_t hit_adj_start(const k4o_hit* h) { return h->match_loci + (h->strand == '+' ? (h->ext & 0xFFF) : ((h->ext >> 12) & 0xFFF)); }
+static uint32_t hit_adj_end(const k4o_hit* h) {
+  return h->match_loci + (h->match_len - (h->strand == '+' ? ((h->ext >> 12) & 0xFFF) : (h->ext & 0xFFF)) - 1);
+}
+static int accept_prov_pe(const k4o_pe_params* pe, int nh1, const k4o_hit* h1, int nh2, const k4o_hit* h2) { /* :2799-2861 */
   if (!(nh1 == 1 && nh2 == 1)) return 0;
   if (h1->chrom_id != h2->chrom_id) return -2;
-  return k4o_pe_insert_size(pe->pair_min_len, pe->pair_max_len, pe->pair_strand, h1->strand, h1->match_loci,
-                            h1->match_loci + h1->match_len - 1, h2->strand, h2->match_loci,
-                            h2->match_loci + h2->match_len - 1);
+  return k4o_pe_insert_size(pe->pair_min_len, pe->pair_max_len, pe->pair_strand, h1->strand, hit_adj_start(h1), hit_adj_end(h1),
+                            h2->strand, hit_adj_start(h2), hit_adj_end(h2));
 }
 
 /* AdaptiveTrim with MinTrimLen == SeqLen, SfxArray.cpp:5561-5639: mismatch count with the end-flank rule; returns
@@ -995,14 +999,26 @@ static int try_rescue(pe_job* j, const k4o_pe_read* anchor, int anchor_is_pe1, c
     b3 = plus; anti = plus;
     if (pe->pair_strand) { b3 = !b3; anti = !anti; }
   }
-  uint32_t st = anchor->hit.match_loci, en = anchor->hit.match_loci + anchor->hit.match_len - 1;
+  uint32_t st = hit_adj_start(&anchor->hit), en = hit_adj_end(&anchor->hit); /* OrphStartLoci / OrphEndLoci, :3354-3355 */
   uint8_t* seq = (uint8_t*)malloc((size_t)mate_len + 1);
   for (int i = 0; i < mate_len; i++) seq[i] = mate[i] & 0x07;
-  int r = k4o_align_paired_read(j->ix, b3, anti, anchor->hit.chrom_id, st, en, pe->pair_min_len, pe->pair_max_len,
-                                j->kp.max_subs, mate_len, seq, hit);
+  int r;
+  if (j->kp.min_chimeric_len > 0) { /* :3357-3386 the window core the caller derives for this mate */
+    int tot_mm = j->kp.max_subs == 0 ? 0 : (int)(0.5 + ((mate_len - 1) * j->kp.max_subs) / 100.0);
+    if (j->kp.max_subs != 0 && tot_mm < 1) tot_mm = 1;
+    if (tot_mm > 63) tot_mm = 63; /* cMaxTotAllowedSubs */
+    int core_len = mate_len / (j->kp.min_edit_dist == 1 ? tot_mm + 1 : tot_mm + 2);
+    if (core_len < j->mcl) core_len = j->mcl;
+    int core_delta = mate_len / j->spm - 1;
+    if (core_delta < core_len) core_delta = core_len;
+    r = k4o_align_paired_read_x(j->ix, b3, anti, anchor->hit.chrom_id, st, en, pe->pair_min_len, pe->pair_max_len, j->kp.max_subs,
+                                mate_len, j->kp.min_chimeric_len, core_len, core_delta, seq, hit);
+  } else
+    r = k4o_align_paired_read(j->ix, b3, anti, anchor->hit.chrom_id, st, en, pe->pair_min_len, pe->pair_max_len,
+                              j->kp.max_subs, mate_len, seq, hit);
   free(seq);
   if (r == 1) {
-    uint32_t hs = hit->match_loci, he = hit->match_loci + hit->match_len - 1;
+    uint32_t hs = hit_adj_start(hit), he = hit_adj_end(hit); /* :3390, :3492 */
     *frag = anchor_is_pe1 ? k4o_pe_insert_size(pe->pair_min_len, pe->pair_max_len, pe->pair_strand, anchor->hit.strand, st, en, hit->strand, hs, he)
                           : k4o_pe_insert_size(pe->pair_min_len, pe->pair_max_len, pe->pair_strand, hit->strand, hs, he, anchor->hit.strand, st, en);
     if (*frag <= 0) r = 0;
@@ -1017,8 +1033,14 @@ static void process_pair(pe_job* j, int64_t i, uint8_t* scratch) {
   const uint8_t* rd1 = j->r1 + j->o1[i];
   const uint8_t* rd2 = j->r2 + j->o2[i];
   int len1 = (int)j->l1[i], len2 = (int)j->l2[i];
-  int hr1 = align_read_with(j->ix, &j->kp, j->mcl, j->spm, rd1, len1, scratch, &r1, h1, NULL);
-  int hr2 = align_read_with(j->ix, &j->kp, j->mcl, j->spm, rd2, len2, scratch, &r2, h2, NULL);
+  int hr1, hr2;
+  if (j->kp.min_chimeric_len > 0) { /* AlignRead with the chimeric pass of AlignReads behind the standard phases */
+    hr1 = k4oi_align_read_ext(j->ix, &j->kp, j->mcl, j->spm, rd1, len1, scratch, &r1, h1);
+    hr2 = k4oi_align_read_ext(j->ix, &j->kp, j->mcl, j->spm, rd2, len2, scratch, &r2, h2);
+  } else {
+    hr1 = align_read_with(j->ix, &j->kp, j->mcl, j->spm, rd1, len1, scratch, &r1, h1, NULL);
+    hr2 = align_read_with(j->ix, &j->kp, j->mcl, j->spm, rd2, len2, scratch, &r2, h2, NULL);
+  }
   k4o_pe_read* f = &j->out[2 * i];
   k4o_pe_read* r = &j->out[2 * i + 1];
   classify_pe_se(&r1, h1, f);

@@ -229,6 +229,13 @@ int k4o_pe_insert_size(int pair_min_len, int pair_max_len, int pair_strand, uint
 int k4o_align_paired_read(const k4o_index* ix, int b3prime_extend, int antisense, uint32_t chrom_id,
                           uint32_t start_loci, uint32_t end_loci, int min_insert, int max_insert, int max_allowed_mm,
                           int read_len, const uint8_t* read, k4o_hit* out); /* SfxArray.cpp:8571-8767 + AdaptiveTrim :5561-5639 */
+/* ... with MinChimericLen 15..99 (the `-c` mode of paired-end kalign): the placement that keeps the longest flank-trimmed stretch
+ * of the mate (AdaptiveTrim's general rule, :5641-5795), ties by fewer mismatches, then first found; windows below 1000 loci are
+ * scanned (:8731-8766), wider ones are seeded with exact cores of min(core_len, MinPutLen) bases every core_delta bases through
+ * IterateExactsRange (:8685-8726, :3461-3553).  out->ext carries TrimLeft / TrimRight / the chimeric flag. */
+int k4o_align_paired_read_x(const k4o_index* ix, int b3prime_extend, int antisense, uint32_t chrom_id, uint32_t start_loci,
+                            uint32_t end_loci, int min_insert, int max_insert, int max_allowed_mm, int read_len,
+                            int min_chimeric_len, int core_len, int core_delta, const uint8_t* read, k4o_hit* out);
 /* CKAligner PE flow for n_pairs pairs: ProcCoredApprox (KAligner.cpp:10160-10239) then ProcessPairedEnds (:3159-3596).
  * out[2*i] = PE1, out[2*i+1] = PE2. kp->pe_mode / max_ml are forced to the PE values (1, 10). */
 int k4o_kalign_pe_batch(const k4o_index* ix, const k4o_kalign_params* kp, const k4o_pe_params* pe, int64_t n_pairs,

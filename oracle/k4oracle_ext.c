@@ -909,6 +909,105 @@ static void align_read_ext(const xjob* j, const uint8_t* read, int read_len, uin
   else for (int q = IMIN(inst, max_ml); q < max_ml; q++) memset(&hits[q], 0, sizeof(k4o_hit));
 }
 
+int k4oi_align_read_ext(const k4o_index* ix, const k4o_kalign_params* kp, int mcl, int spm, const uint8_t* read, int read_len,
+                        uint8_t* scratch, k4o_read_result* out, k4o_hit* hits) {
+  xjob j;
+  memset(&j, 0, sizeof(j));
+  j.ix = ix; j.kp = kp; j.mcl = mcl; j.spm = spm;
+  j.ext.min_chimeric_len = kp->min_chimeric_len;  /* (two-segment phases are not part of the paired-end build: seg2 is dropped) */
+  k4o_seg2 s2;
+  align_read_ext(&j, read, read_len, scratch, out, hits, &s2, NULL);
+  return out->hit_rslt;
+}
+
+/* ---- AlignPairedRead with chimeric trimming, SfxArray.cpp:8571-8767 --------------------------------------------------------- */
+static void store_rescued(k4o_hit* out, uint32_t chrom_id, uint32_t loci, int read_len, int antisense, uint32_t t5, uint32_t t3,
+                          uint32_t mms, int chimeric) {
+  memset(out, 0, sizeof(*out));
+  out->chrom_id = chrom_id;
+  out->match_loci = loci;
+  out->match_len = (uint16_t)read_len;
+  out->strand = antisense ? '-' : '+';
+  out->mismatches = (uint8_t)mms;
+  const uint32_t tl = antisense ? t3 : t5, tr = antisense ? t5 : t3; /* :8702-8711 */
+  out->ext = (tl & 0xFFF) | ((tr & 0xFFF) << 12) | (chimeric ? K4O_EXT_CHIMERIC : 0);
+}
+
+int k4o_align_paired_read_x(const k4o_index* ix, int b3prime, int antisense, uint32_t chrom_id, uint32_t start_loci,
+                            uint32_t end_loci, int min_insert, int max_insert, int max_allowed_mm, int read_len,
+                            int min_chimeric_len, int core_len, int core_delta, const uint8_t* read, k4o_hit* out) {
+  memset(out, 0, sizeof(*out));
+  if (chrom_id < 1 || chrom_id > ix->n_entries) return -1;
+  const k4o_entry* e = &ix->entries[chrom_id - 1];
+  const uint32_t chrom_len = e->seq_len;
+  if (chrom_len == 0) return -1;
+  if (start_loci >= end_loci || end_loci >= chrom_len) return -1;
+  int min_put_len;
+  if (core_len > 0 && min_chimeric_len >= 15 && min_chimeric_len <= 99) { /* :8610-8621 */
+    min_put_len = ((read_len * min_chimeric_len) + 50) / 100;
+    if (core_len > min_put_len) core_len = min_put_len;
+  } else
+    min_put_len = read_len;
+  if (min_put_len == read_len) { min_chimeric_len = 0; core_len = 0; }
+  if (min_insert > max_insert) return 0;
+  if (min_insert < read_len) { max_insert += read_len - min_insert; min_insert = read_len; }
+  uint32_t sp, ep;
+  if (b3prime) {
+    if ((uint32_t)(start_loci + min_insert) >= chrom_len) return 0;
+    sp = start_loci + min_insert - read_len;
+    const uint32_t a = chrom_len - read_len, b = (uint32_t)(start_loci + max_insert - read_len);
+    ep = a < b ? a : b;
+  } else {
+    if (end_loci < (uint32_t)min_insert) return 0;
+    sp = end_loci <= (uint32_t)max_insert ? 0 : end_loci - max_insert;
+    ep = end_loci - min_insert;
+  }
+  uint8_t* rs = (uint8_t*)malloc((size_t)read_len + 1);
+  memcpy(rs, read, (size_t)read_len);
+  rs[read_len] = K4O_EOS;
+  if (antisense) k4o_revcomp(rs, read_len);
+  const uint8_t* chrom = ix->seq + e->start_ofs;
+  uint32_t prev_best = (uint32_t)max_allowed_mm + 1;
+  if ((ep - sp) >= 1000) { /* :8685-8726; with core_len 0 the reference never returns from here (see k4o_align_paired_read) */
+    if (core_len <= 0 || core_delta <= 0) { free(rs); return -3; }
+    const int64_t n = (int64_t)ix->n;
+    for (uint32_t ofs = 0; (int)ofs + core_len <= read_len; ofs += (uint32_t)core_delta) {
+      int64_t t = k4o_locate_first_exact(ix, rs + ofs, core_len, 0, n - 1, NULL); /* IterateExactsRange, :3461-3553 */
+      if (t == 0) continue;
+      for (t -= 1; t < n; t++) { /* every suffix that starts with the core, in suffix-array order */
+        const int64_t pos = k4o_sa_at(ix, t);
+        if (k4oi_cmp_probe_targ(rs + ofs, ix->seq + pos, core_len) != 0) break;
+        const k4o_entry* he = k4oi_map_chunk_hit2entry(ix, (uint64_t)pos);
+        if (!he || he->entry_id != chrom_id) continue;
+        const uint32_t hit_loci = (uint32_t)((uint64_t)pos - he->start_ofs);
+        if (hit_loci < sp || hit_loci > ep) continue;
+        if (ofs > hit_loci || (hit_loci + (uint32_t)read_len - ofs) >= chrom_len) continue; /* :8693 */
+        uint32_t tl, t5, t3, mms;
+        const int r = k4o_adaptive_trim((uint32_t)read_len, rs, chrom + (hit_loci - ofs), (uint32_t)min_put_len, (uint32_t)max_allowed_mm, 3,
+                                        &tl, &t5, &t3, &mms);
+        if (r > min_put_len || (r == min_put_len && mms < prev_best)) {
+          prev_best = mms;
+          min_put_len = r;
+          store_rescued(out, chrom_id, hit_loci - ofs, read_len, antisense, t5, t3, mms, min_put_len != read_len);
+        }
+      }
+    }
+  } else
+    for (uint32_t loci = sp; loci <= ep; loci++) { /* :8731-8766 */
+      uint32_t tl, t5, t3, mms;
+      const int r = k4o_adaptive_trim((uint32_t)read_len, rs, chrom + loci, (uint32_t)min_put_len, (uint32_t)max_allowed_mm, 3, &tl, &t5, &t3, &mms);
+      if (r > min_put_len || (r == min_put_len && mms < prev_best)) {
+        prev_best = mms;
+        min_put_len = r;
+        store_rescued(out, chrom_id, loci, read_len, antisense, t5, t3, mms, min_put_len != read_len);
+        if (min_put_len == read_len && mms == 0) break;
+      }
+      if (loci == 0xFFFFFFFFu) break;
+    }
+  free(rs);
+  return prev_best <= (uint32_t)max_allowed_mm ? 1 : 0;
+}
+
 static void* xworker(void* arg) {
   xjob* j = (xjob*)arg;
   k4o_counters c = { 0, 0, 0 };

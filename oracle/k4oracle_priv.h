@@ -31,4 +31,7 @@ void k4oi_idset_free(k4oi_idset* s);
 int k4oi_idset_insert(k4oi_idset* s, uint32_t id); /* 1 if new */
 const k4o_entry* k4oi_map_chunk_hit2entry(const k4o_index* ix, uint64_t ofs); /* SfxArray.cpp:2609-2654 */
 int k4oi_cmp_probe_targ(const uint8_t* probe, const uint8_t* targ, int len);   /* SfxArray.cpp:2508-2525 */
+/* CKAligner::AlignRead for one read with kp's optional-phase arguments honoured (k4oracle_ext.c); returns the tHRslt */
+int k4oi_align_read_ext(const k4o_index* ix, const k4o_kalign_params* kp, int mcl, int spm, const uint8_t* read, int read_len,
+                        uint8_t* scratch, k4o_read_result* out, k4o_hit* hits);
 #endif

@@ -177,6 +177,28 @@ int k4ref_align_reads_ext(void* vh, int min_chimeric_len, int micro_indel_len, i
   return rslt;
 }
 
+// CSfxArray::AlignPairedRead with the whole tsHitLoci back (trims and flags of a chimeric placement)
+int k4ref_align_paired_read_x(void* vh, int b3prime_extend, int antisense, uint32_t chrom_id, uint32_t start_loci,
+                              uint32_t end_loci, int min_insert, int max_insert, int max_allowed_mm, int min_hamming, int read_len,
+                              int min_chimeric_len, int core_len, int core_delta, int max_slides, uint8_t* read, k4ref_xhit* o) {
+  k4ref_handle* h = (k4ref_handle*)vh;
+  tsHitLoci hit;
+  memset(&hit, 0, sizeof(hit));
+  int rslt = h->sfx->AlignPairedRead(b3prime_extend != 0, antisense != 0, chrom_id, start_loci, end_loci, min_insert, max_insert,
+                                     max_allowed_mm, min_hamming, read_len, min_chimeric_len, core_len, core_delta, max_slides,
+                                     (etSeqBase*)read, &hit);
+  memset(o, 0, sizeof(*o));
+  o->chrom_id = hit.Seg[0].ChromID;
+  o->match_loci = hit.Seg[0].MatchLoci;
+  o->match_len = hit.Seg[0].MatchLen;
+  o->strand = hit.Seg[0].Strand;
+  o->mismatches = hit.Seg[0].Mismatches;
+  o->trim_left = hit.Seg[0].TrimLeft;
+  o->trim_right = hit.Seg[0].TrimRight;
+  o->flags = (uint8_t)(hit.FlgChimeric | (hit.FlgInDel << 1) | (hit.FlgInsert << 2) | (hit.FlgSplice << 3) | (hit.FlgNonOrphan << 4));
+  return rslt;
+}
+
 // CSfxArray::AdaptiveTrim (SfxArray.cpp:5561) on caller-supplied sequences; out = {TrimSeqLen, TrimStart, TrimEnd, TrimMMs}
 int k4ref_adaptive_trim(void* vh, uint32_t seq_len, uint8_t* probe, uint8_t* targ, uint32_t min_trim_len, uint32_t max_mm,
                         uint32_t min_flank, uint32_t* out4) {

@@ -62,14 +62,39 @@ ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # case names: regener
 PE_CASES = {
     "pe_u2": (["-s2", "-U2", "-d200", "-D600"], dict(seed=99, n_prob=0.02, random_mate_frac=0.03)),
     "pe_u1": (["-s2", "-U1", "-d200", "-D600"], dict(seed=98, n_prob=0.02, random_mate_frac=0.03, sub_lambda=2.0)),
+    # chimeric trimming with paired ends (-c: AlignReads' chimeric pass for both ends, trimmed loci in the pairing, AlignPairedRead's
+    # AdaptiveTrim branch for the rescue): a third of the mates carry foreign flanks.  The second case has an insert window of 1000
+    # loci and more, where the rescue is seeded with exact cores (IterateExactsRange)
+    "pe_c50_u1": (["-s2", "-c50", "-U1", "-d200", "-D600"], dict(seed=97, n_prob=0.02, random_mate_frac=0.03, sub_lambda=1.5, chimeric=0.33)),
+    "pe_c60_u3_wide": (["-s3", "-c60", "-U3", "-d150", "-D1400"], dict(seed=96, n_prob=0.01, random_mate_frac=0.02, sub_lambda=1.5, chimeric=0.33,
+                                                                        frag_min=300, frag_max=1300)),
 }
+
+
+def foreign_flanks(reads, frac, seed):
+    """a share of the reads gets 5..35 % of random sequence at its 5' and / or 3' end (chimeric reads)"""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    for r in reads:
+        if rng.random() >= frac:
+            continue
+        L = len(r)
+        for side in (0, 1):
+            if rng.random() < 0.65:
+                k = int(rng.integers(L * 5 // 100, L * 35 // 100))
+                if side == 0:
+                    r[:k] = rng.integers(0, 4, k)
+                else:
+                    r[L - k:] = rng.integers(0, 4, k)
+    return reads
 
 
 def run(tmp, name, args, files, sfx=os.path.join(HERE, "g1.sfx")):
     sam = os.path.join(tmp, name + ".sam")
     log = os.path.join(tmp, name + ".log")
     cmd = [NGS, "kalign", "-I", sfx, "-o", sam, "-T", "1" if "-r2" in args else "4", "-F", log] + args + files
-    subprocess.run(cmd, check=True, capture_output=True)
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
     hist = {}
     for line in open(log):
         m = re.search(r"\)\s+(\d+) \((\w\w)\) ", line)
@@ -132,7 +157,11 @@ def main():
         for name, (args, kw) in PE_CASES.items():
             if ONLY and name not in ONLY:
                 continue
+            kw = dict(kw)
+            chim = kw.pop("chimeric", 0.0)
             pe1, pe2, _ = synth.make_pe_reads(chroms, 2000, 150, **kw)
+            if chim:
+                pe1, pe2 = foreign_flanks(pe1, chim, kw["seed"] + 1000), foreign_flanks(pe2, chim, kw["seed"] + 2000)
             f1, f2 = os.path.join(tmp, name + "_1.fa"), os.path.join(tmp, name + "_2.fa")
             synth.write_fasta(f1, pe1)
             synth.write_fasta(f2, pe2)

@@ -276,6 +276,18 @@ class Oracle:
                                    threads, None)
         return dict(out=out, hits=hits, seg2=seg2)
 
+    def align_paired_read_x(self, h, b3prime, antisense, chrom_id, start_loci, end_loci, min_insert, max_insert, max_allowed_mm,
+                            read, min_chimeric_len, core_len, core_delta):
+        """CSfxArray::AlignPairedRead in chimeric mode: (rslt, hit record with ext = trims | flags)"""
+        self.L.k4o_align_paired_read_x.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        rd = np.ascontiguousarray(read, dtype=np.uint8)
+        hit = np.zeros(1, dtype=HIT_DTYPE)
+        r = self.L.k4o_align_paired_read_x(h, int(b3prime), int(antisense), chrom_id, start_loci, end_loci, min_insert, max_insert,
+                                           max_allowed_mm, len(rd), min_chimeric_len, core_len, core_delta, rd.ctypes.data,
+                                           hit.ctypes.data)
+        return r, hit[0]
+
     def adaptive_trim(self, probe, targ, min_trim_len, max_mm, min_flank=3):
         """CSfxArray::AdaptiveTrim -> (return value, TrimSeqLen, TrimStart, TrimEnd, TrimMMs)"""
         probe = np.ascontiguousarray(probe, dtype=np.uint8)
@@ -317,7 +329,8 @@ def _kalign_pe(L, fn, h, reads1, reads2, pe_mode, pair_min_len, pair_max_len, pa
     c2, o2, l2 = reads2 if isinstance(reads2, tuple) else flatten_reads(reads2)
     assert len(l1) == len(l2)
     kp = KalignParams(kw.get("max_subs", 5), kw.get("min_edit_dist", 1), kw.get("max_ns", 1), kw.get("pmode", 0),
-                      kw.get("strand", STRAND_BOTH), 10, 1, kw.get("min_core_len", 0), kw.get("max_num_slides", 0))
+                      kw.get("strand", STRAND_BOTH), 10, 1, kw.get("min_core_len", 0), kw.get("max_num_slides", 0),
+                      kw.get("min_chimeric_len", 0), 0, 0)
     pe = PeParams(pe_mode, pair_min_len, pair_max_len, 1 if pair_strand else 0)
     out = np.zeros(2 * len(l1), dtype=PE_READ_DTYPE)
     rc = fn(h, C.byref(kp), C.byref(pe), len(l1), c1.ctypes.data, o1.ctypes.data, l1.ctypes.data, c2.ctypes.data,
@@ -441,6 +454,21 @@ class Ref:
                     seg2[i] = (x.seg1_chrom_id, x.seg1_match_loci & 0xFFFFFFFF, x.seg1_match_len, x.seg1_read_ofs,
                                x.seg1_mismatches, 0, x.score)
         return dict(rslt=rslt, inst=inst, low=low, nxt=nxt, hits=hits, seg2=seg2)
+
+    def align_paired_read_x(self, h, b3prime, antisense, chrom_id, start_loci, end_loci, min_insert, max_insert, max_allowed_mm,
+                            read, min_chimeric_len, core_len, core_delta, max_slides=10, min_hamming=1):
+        """the real CSfxArray::AlignPairedRead; same record as Oracle.align_paired_read_x"""
+        self.L.k4ref_align_paired_read_x.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_int] * 9 + \
+                                                    [C.c_void_p, C.POINTER(_RefXHit)]
+        rd = np.ascontiguousarray(read, dtype=np.uint8).copy()
+        x = _RefXHit()
+        r = self.L.k4ref_align_paired_read_x(h, int(b3prime), int(antisense), chrom_id, start_loci, end_loci, min_insert, max_insert,
+                                             max_allowed_mm, min_hamming, len(rd), min_chimeric_len, core_len, core_delta, max_slides,
+                                             rd.ctypes.data, C.byref(x))
+        hit = np.zeros(1, dtype=HIT_DTYPE)
+        ext = (x.trim_left & 0xFFF) | ((x.trim_right & 0xFFF) << 12) | ((1 << 24) if x.flags & 1 else 0)
+        hit[0] = (x.chrom_id, x.match_loci & 0xFFFFFFFF, x.match_len, x.strand, x.mismatches, ext)
+        return r, hit[0]
 
     def adaptive_trim(self, h, probe, targ, min_trim_len, max_mm, min_flank=3):
         probe = np.ascontiguousarray(probe, dtype=np.uint8).copy()

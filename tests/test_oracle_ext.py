@@ -155,3 +155,65 @@ def test_post_stages_known_answers(oracle, g3_path, golden_dir):
         near = [j for j in idx if j != i and ch[j] == ch[i] and abs(st[j] - st[i]) <= 3 and abs(en[j] - en[i]) <= 3]
         assert near, i
     oracle.close(h)
+
+
+@pytest.mark.parametrize("window,seed", [(400, 1), (900, 2), (1500, 3), (6000, 4)])
+def test_chimeric_mate_rescue_vs_live_reference(oracle, golden_dir, window, seed):
+    """CSfxArray::AlignPairedRead with MinChimericLen (SfxArray.cpp:8571-8767): both branches -- the linear scan below 1000 loci and
+    the exact-core seeds of IterateExactsRange above -- on mates whose flanks are foreign sequence, placed relative to made-up
+    anchors on the golden genome; oracle vs the live reference (oracle/_ref/libk4ref.so; skipped where it is not built)."""
+    from oracle_bindings import Ref, ref_available
+
+    if not ref_available():
+        pytest.skip("oracle/_ref/libk4ref.so is not built here")
+    names, chroms = synth.golden_genome()
+    rng = np.random.default_rng(900 + seed)
+    R = Ref()
+    path = os.path.join(golden_dir, "g1.sfx")
+    hr = R.open(path)
+    ho = oracle.open(path)
+    n_placed = n_chim = 0
+    for t in range(140):
+        c = int(rng.integers(0, 3))
+        g = chroms[c]
+        L = int(rng.choice([100, 125, 150]))
+        b3 = bool(rng.integers(0, 2))
+        anti = bool(rng.integers(0, 2))
+        a_len = 100
+        a_start = int(rng.integers(window + 300, len(g) - window - 400))
+        a_end = a_start + a_len - 1
+        # where the mate really lies: inside the insert window on the proper side
+        frag = int(rng.integers(L + 20, window))
+        m_start = (a_start + frag - L) if b3 else (a_end - frag + 1)
+        if m_start < 0 or m_start + L >= len(g):
+            continue
+        mate = g[m_start:m_start + L].copy()
+        kind = rng.random()
+        if kind < 0.6:  # foreign flanks: a chimeric placement
+            f5 = int(rng.integers(0, L * 35 // 100)) if rng.random() < 0.7 else 0
+            f3 = int(rng.integers(0, L * 35 // 100)) if rng.random() < 0.7 else 0
+            mate[:f5] = rng.integers(0, 4, f5)
+            if f3:
+                mate[L - f3:] = rng.integers(0, 4, f3)
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(0, L))
+            mate[p] = (mate[p] + 1 + rng.integers(0, 3)) % 4
+        if kind > 0.93:
+            mate = rng.integers(0, 4, L).astype(np.uint8)  # nothing to find
+        if anti:
+            mate = (3 - mate)[::-1].copy()
+        mcl = int(rng.choice([50, 60, 75, 99]))
+        max_mm = int(rng.choice([2, 3, 5]))
+        core_len = max(8, L // (max_mm + 1))
+        core_delta = max(L // 10 - 1, core_len)
+        args = (b3, anti, c + 1, a_start, a_end, 50, window + L, max_mm, mate, mcl, core_len, core_delta)
+        r_ref, h_ref = R.align_paired_read_x(hr, *args)
+        r_o, h_o = oracle.align_paired_read_x(ho, *args)
+        assert r_ref == r_o, (t, r_ref, r_o, args[:8])
+        if r_ref == 1:
+            assert h_ref.tobytes() == h_o.tobytes(), (t, h_ref, h_o)
+            n_placed += 1
+            n_chim += int((int(h_o["reserved"]) >> 24) & 1)
+    assert n_placed > 60 and n_chim > 15
+    R.close(hr)
+    oracle.close(ho)
