@@ -369,17 +369,16 @@ class CSfxArray {
   int AlignPairedRead(bool b3primeExtend, bool bAntisense, uint32_t ChromID, uint32_t StartLoci, uint32_t EndLoci, int MinInsertSize,
                       int MaxInsertSize, int MaxAllowedMM, int MinHamming, int ReadLen, int MinChimericLen, int CoreLen,
                       int CoreDelta, int MaxNumCoreSlides, etSeqBase* pRead, tsHitLoci* pAlign) {
-    (void)MinHamming; (void)CoreLen; (void)CoreDelta; (void)MaxNumCoreSlides;  // (used by the seeded branch for windows >= 1000 only)
+    (void)MinHamming; (void)MaxNumCoreSlides;
     if (!m_pIdx) return -1;
-    if (MinChimericLen > 0) {
-      m_Errs.push_back("CSfxArray::AlignPairedRead: chimeric trimming is outside the accelerated path");
-      return K4_ERR_UNSUPPORTED;
-    }
     k4_rescue_task t;
     std::memset(&t, 0, sizeof(t));
     t.chrom_id = ChromID; t.start_loci = StartLoci; t.end_loci = EndLoci; t.read_len = (uint32_t)ReadLen; t.read_off = 0;
     t.b3prime_extend = b3primeExtend ? 1 : 0; t.antisense = bAntisense ? 1 : 0;
     t.min_insert = MinInsertSize; t.max_insert = MaxInsertSize; t.max_allowed_mm = MaxAllowedMM;
+    if (MinChimericLen >= 15 && MinChimericLen <= 99 && CoreLen > 0)  // chimeric mode: CoreLen / CoreDelta seed the wide windows
+      t.chimeric = (uint32_t)MinChimericLen | ((uint32_t)(CoreLen > 4095 ? 4095 : CoreLen) << 8) |
+                   ((uint32_t)(CoreDelta > 4095 ? 4095 : CoreDelta < 0 ? 0 : CoreDelta) << 20);
     int32_t rslt = 0;
     k4_hit h;
     std::lock_guard<std::mutex> lock(m_Mtx);

@@ -299,7 +299,7 @@ typedef struct {        /* one AlignPairedRead call */
   int32_t min_insert;
   int32_t max_insert;
   int32_t max_allowed_mm;
-  int32_t reserved;
+  uint32_t chimeric;    /* 0, or MinChimericLen (15..99) | CoreLen << 8 | CoreDelta << 20: AlignPairedRead's chimeric mode */
 } k4_rescue_task;
 int k4_mate_rescue_batch(k4_index* ix, int64_t n_tasks, const k4_rescue_task* tasks, const uint8_t* reads,
                          uint64_t reads_bytes, int32_t* rslt, k4_hit* hits);

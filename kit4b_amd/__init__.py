@@ -438,12 +438,13 @@ class SfxIndex:
 
     def kalign_pe_batch(self, reads1, reads2, pe_mode=2, pair_min_len=100, pair_max_len=1000, pair_strand=False,
                         max_subs=5, min_edit_dist=1, max_ns=1, pmode=0, strand=STRAND_BOTH, min_core_len=0,
-                        max_num_slides=0):
-        """CKAligner's PE flow (ProcCoredApprox + ProcessPairedEnds); out[2i] = PE1, out[2i+1] = PE2."""
+                        max_num_slides=0, min_chimeric_len=0):
+        """CKAligner's PE flow (ProcCoredApprox + ProcessPairedEnds); out[2i] = PE1, out[2i+1] = PE2.  min_chimeric_len
+        (kalign -c): chimeric trimming of both ends and of rescued mates; the trims come back in hit.ext."""
         c1, o1, l1 = _flatten(reads1)
         c2, o2, l2 = _flatten(reads2)
         assert len(l1) == len(l2)
-        kp = KalignParams(max_subs, min_edit_dist, max_ns, pmode, strand, 10, 1, min_core_len, max_num_slides)
+        kp = KalignParams(max_subs, min_edit_dist, max_ns, pmode, strand, 10, 1, min_core_len, max_num_slides, min_chimeric_len, 0, 0)
         pe = PeParams(pe_mode, pair_min_len, pair_max_len, 1 if pair_strand else 0)
         out = np.zeros(2 * len(l1), dtype=PE_READ_DTYPE)
         self._ck(lib().k4_kalign_pe_batch(self.h, C.byref(kp), C.byref(pe), len(l1), c1.ctypes.data, o1.ctypes.data,

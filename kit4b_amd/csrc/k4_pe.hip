@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <vector>
 #include "k4_device.h"
+#include "k4_trim.h"
 
 // ---- mate rescue: one wave scans every locus of the insert window ------------------------------------------------
 // A locus is acceptable when the full-length mismatch count is <= ((len*rate)+99)/100, no mismatch sits in the first
@@ -23,8 +24,49 @@
 // Wave-cooperative; rs = K4_RESCUE_LDS bytes of LDS owned by this wave (the oriented mate as symbols, then packed).
 // Returns the AlignPairedRead result (1 placed, 0 not, < 0 error), identical in every lane; h is filled when 1.
 #define K4_RESCUE_LDS (K4_MAX_READ_LEN + 8 * (K4_MAX_READ_LEN / 32 + 2))
+// chimeric mode: one mismatch bit vector per lane behind that (AdaptiveTrim takes reads of up to 2048 bases: 64 words per lane)
+#define K4_RESCUE_MK_WORDS 64
+#define K4_RESCUE_LDS_CHIM (K4_RESCUE_LDS + 64 * 4 * K4_RESCUE_MK_WORDS)
+
+// the mate (symbols rs[0, len), packed pk when it holds no N) against the reference at g: mismatch bits into the lane's column
+K4_DEV void k4d_rescue_mm_vector(const K4DevIndex& ix, const uint8_t* rs, const uint64_t* pk, bool packed, int len, uint64_t g, uint32_t* mk) {
+  if (packed && g + (uint64_t)len <= ix.n && !k4d_any_exc(ix, (int64_t)g, (int64_t)g + len)) {
+    const int al = (int)(g & 15);
+    for (int c0 = 0; 32 * c0 < len; c0 += 4) {
+      const int rem = len - 32 * c0;
+      uint64_t rc[4];
+      k4d_ref_chunks4(ix, (int64_t)g, c0, rem + al <= 128, rc);
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (32 * c < rem) mk[(c0 + c) * 64] = k4d_mm_bits((rc[c] ^ pk[c0 + c]) & k4d_range_mask(0, rem - 32 * c));
+    }
+    return;
+  }
+  K4Tb t;
+  t.init(ix);
+  for (int c = 0; 32 * c < len; c++) {
+    uint32_t m = 0;
+    for (int q = 0; q < 32 && 32 * c + q < len; q++)
+      if ((uint32_t)rs[32 * c + q] != t.get((int64_t)g + 32 * c + q)) m |= 1u << q;
+    mk[c * 64] = m;
+  }
+}
+// CmpProbeTarg (SfxArray.cpp:2508-2525) of the core rs[ofs, ofs + cl) against the suffix at pos, on exact symbols
+K4_DEV int k4d_rescue_cmp(const K4DevIndex& ix, const uint8_t* rs, int ofs, int cl, uint64_t pos) {
+  K4Tb t;
+  t.init(ix);
+  for (int j = 0; j < cl; j++) {
+    const uint32_t e2 = t.get((int64_t)pos + j);
+    if (e2 == 7u) return -1;
+    const uint32_t e1 = rs[ofs + j];
+    if (e1 > e2) return 1;
+    if (e1 < e2) return -1;
+  }
+  return 0;
+}
+K4_DEV uint64_t k4d_rescue_sa(const K4DevIndex& ix, uint64_t i) { return ix.el == 4 ? k4d_sa_at<4>(ix, i) : k4d_sa_at<5>(ix, i); }
 K4_DEV int k4d_mate_rescue(const K4DevIndex& ix, const k4_rescue_task& tk, const uint8_t* __restrict__ reads, int lane,
-                           uint8_t* rs, k4_hit& h) {
+                           uint8_t* rs, k4_hit& h, uint32_t* mk = nullptr /* chimeric mode: this lane's column of the mismatch vectors */) {
   int res = 0;
   unsigned long long best = ~0ull;  // (mm << 32) | (locus - sp)
   uint32_t sp = 0, ep = 0;
@@ -54,6 +96,148 @@ K4_DEV int k4d_mate_rescue(const K4DevIndex& ix, const k4_rescue_task& tk, const
       }
       // AdaptiveTrim parameter validation (:5598-5603): failing it means no locus is ever accepted
       if (run && (len < 25 || len > 2048 || (uint32_t)tk.max_allowed_mm > (uint32_t)((15 * len + 99) / 100))) run = false;
+    }
+    // chimeric mode (:8610-8621): the placement may keep only part of the mate
+    int min_put_len = len, core_len = (int)((tk.chimeric >> 8) & 0xFFF), core_delta = (int)(tk.chimeric >> 20);
+    {
+      const int mcl = (int)(tk.chimeric & 0xFF);
+      if (core_len > 0 && mcl >= 15 && mcl <= 99) {
+        min_put_len = (len * mcl + 50) / 100;
+        if (core_len > min_put_len) core_len = min_put_len;
+      }
+      if (min_put_len == len) core_len = 0;
+    }
+    if (run && min_put_len != len) {
+      if (!mk) { res = K4_ERR_PARAMS; run = false; }
+      if (min_put_len < 15) run = false;  // (AdaptiveTrim refuses MinTrimLen below cMinATTrimmedLen: nothing is ever accepted)
+    }
+    if (run && min_put_len != len) {
+      uint64_t* pk = reinterpret_cast<uint64_t*>(rs + K4_MAX_READ_LEN);
+      __syncthreads();
+      const uint8_t* src = reads + tk.read_off;
+      for (int q = lane; q < len; q += 64) {
+        uint8_t b = tk.antisense ? src[len - 1 - q] & 7 : src[q] & 7;
+        if (tk.antisense && b <= 3) b = 3 - b;
+        rs[q] = b;
+      }
+      __syncthreads();
+      const int nw = (len + 31) >> 5;
+      bool has_n = false;
+      for (int w = lane; w < nw; w += 64) {
+        uint64_t acc = 0;
+        for (int q = 0; q < 32; q++) {
+          const int j = 32 * w + q;
+          uint32_t b = j < len ? rs[j] : 0u;
+          if (b > 3) { has_n = true; b = 0; }
+          acc = (acc << 2) | b;
+        }
+        pk[w] = acc;
+      }
+      const bool packed = __ballot(has_n) == 0;
+      __syncthreads();
+      // The reference takes the candidates one after the other and hands AdaptiveTrim the length of the best placement so far
+      // as its minimum (which changes what it returns, not only whether it accepts): 64 candidates are tried against the
+      // current state at once, the first one the state admits is taken, and the ones behind it are tried again.
+      int cur_min = min_put_len;
+      uint32_t prev_best = (uint32_t)tk.max_allowed_mm + 1;
+      uint32_t b_loci = 0, b_t5 = 0, b_t3 = 0, b_mm = 0;
+      bool have = false, done = false;
+      if ((ep - sp) >= 1000) {  // :8685-8726 seeded with exact cores (IterateExactsRange, :3461-3553)
+        for (int ofs = 0; core_len > 0 && core_delta > 0 && ofs + core_len <= len && !done; ofs += core_delta) {
+          // lowest suffix that is not below the core: 64 evenly spaced pivots per round over the whole array
+          int64_t lo = 0, hi = (int64_t)ix.n - 1, first = -1;
+          while (lo <= hi) {
+            const int64_t step = (hi - lo + 1 + 63) / 64;
+            const int64_t pv = lo + (int64_t)lane * step;
+            const bool hv = pv <= hi;
+            int c = 1;
+            if (hv) c = k4d_rescue_cmp(ix, rs, ofs, core_len, k4d_rescue_sa(ix, (uint64_t)pv));
+            const unsigned long long hm = __ballot(hv), le = __ballot(hv && c <= 0);
+            if (!le) { lo = lo + (int64_t)(__popcll(hm) - 1) * step + 1; continue; }
+            const int f = __ffsll((long long)le) - 1;
+            const int64_t pvf = lo + (int64_t)f * step;
+            if (step == 1) { if (__shfl(c, f, 64) == 0) first = pvf; break; }
+            if (f > 0) lo = lo + (int64_t)(f - 1) * step + 1;
+            hi = pvf;
+          }
+          if (first < 0) continue;
+          for (int64_t base = first; base < (int64_t)ix.n;) {
+            const int64_t idx = base + lane;
+            uint64_t pos = 0;
+            bool same = false;
+            if (idx < (int64_t)ix.n) {
+              pos = k4d_rescue_sa(ix, (uint64_t)idx);
+              same = k4d_rescue_cmp(ix, rs, ofs, core_len, pos) == 0;
+            }
+            const unsigned long long stop_m = __ballot(!same);
+            const int n_run = stop_m ? __ffsll((long long)stop_m) - 1 : 64;  // lanes [0, n_run) still start with the core
+            bool acc = false;
+            K4Trim tr = {0, 0, 0, 0};
+            uint32_t loci = 0;
+            if (lane < n_run) {
+              const int e = k4d_map_entry(ix, pos);
+              if (e == (int)tk.chrom_id - 1) {
+                const uint32_t hit_loci = (uint32_t)(pos - cs);
+                if (hit_loci >= sp && hit_loci <= ep && (uint32_t)ofs <= hit_loci && hit_loci + (uint32_t)len - (uint32_t)ofs < chrom_len) {
+                  loci = hit_loci - (uint32_t)ofs;
+                  k4d_rescue_mm_vector(ix, rs, pk, packed, len, cs + loci, mk);
+                  tr = k4d_adaptive_trim(mk, len, cur_min, tk.max_allowed_mm, 3);
+                  acc = tr.len > cur_min || (tr.len == cur_min && (uint32_t)tr.mms < prev_best);
+                }
+              }
+            }
+            const unsigned long long am = __ballot(acc);
+            if (am) {
+              const int c = __ffsll((long long)am) - 1;
+              cur_min = __shfl(tr.len, c, 64); prev_best = (uint32_t)__shfl(tr.mms, c, 64);
+              b_loci = (uint32_t)__shfl((int)loci, c, 64); b_t5 = (uint32_t)__shfl(tr.t5, c, 64); b_t3 = (uint32_t)__shfl(tr.t3, c, 64);
+              b_mm = prev_best;
+              have = true;
+              base += c + 1;
+              continue;
+            }
+            if (n_run < 64) break;
+            base += 64;
+          }
+        }
+      } else {  // :8731-8766 every locus of the window in turn
+        for (uint32_t start = sp; start <= ep && !done;) {
+          const uint32_t loci = start + (uint32_t)lane;
+          bool acc = false;
+          K4Trim tr = {0, 0, 0, 0};
+          if (loci <= ep && loci >= start) {
+            k4d_rescue_mm_vector(ix, rs, pk, packed, len, cs + loci, mk);
+            tr = k4d_adaptive_trim(mk, len, cur_min, tk.max_allowed_mm, 3);
+            acc = tr.len > cur_min || (tr.len == cur_min && (uint32_t)tr.mms < prev_best);
+          }
+          const unsigned long long am = __ballot(acc);
+          if (am) {
+            const int c = __ffsll((long long)am) - 1;
+            cur_min = __shfl(tr.len, c, 64); prev_best = (uint32_t)__shfl(tr.mms, c, 64);
+            b_loci = start + (uint32_t)c; b_t5 = (uint32_t)__shfl(tr.t5, c, 64); b_t3 = (uint32_t)__shfl(tr.t3, c, 64);
+            b_mm = prev_best;
+            have = true;
+            if (cur_min == len && prev_best == 0) done = true;
+            start += (uint32_t)c + 1;
+            if (start == 0) break;  // (wrapped)
+            continue;
+          }
+          if (ep - start < 64) break;
+          start += 64;
+        }
+      }
+      memset(&h, 0, sizeof(h));
+      if (have && prev_best <= (uint32_t)tk.max_allowed_mm) {
+        h.chrom_id = tk.chrom_id;
+        h.match_loci = b_loci;
+        h.match_len = (uint16_t)len;
+        h.strand = tk.antisense ? '-' : '+';
+        h.mismatches = (uint8_t)b_mm;
+        const uint32_t tl = tk.antisense ? b_t3 : b_t5, trr = tk.antisense ? b_t5 : b_t3;  // :8702-8711
+        h.ext = (tl & 0xFFFu) | ((trr & 0xFFFu) << 12) | (cur_min != len ? K4_EXT_CHIMERIC : 0u);
+        return 1;
+      }
+      return 0;
     }
     if (run) {
       uint64_t* pk = reinterpret_cast<uint64_t*>(rs + K4_MAX_READ_LEN);
@@ -136,13 +320,14 @@ K4_DEV int k4d_mate_rescue(const K4DevIndex& ix, const k4_rescue_task& tk, const
 
 __global__ void __launch_bounds__(64) k4k_mate_rescue(K4DevIndex ix, const k4_rescue_task* __restrict__ tasks,
                                                       const uint8_t* __restrict__ reads, int64_t n_tasks,
-                                                      int32_t* __restrict__ rslt, k4_hit* __restrict__ hits) {
-  __shared__ __attribute__((aligned(8))) uint8_t rs[K4_RESCUE_LDS];  // the mate, oriented as it must align ('-': reverse complemented)
+                                                      int32_t* __restrict__ rslt, k4_hit* __restrict__ hits, int chim) {
+  extern __shared__ __attribute__((aligned(8))) uint8_t rs[];  // the mate, oriented as it must align; with `chim`, the mismatch vectors behind it
   const int lane = threadIdx.x;
+  uint32_t* mk = chim ? reinterpret_cast<uint32_t*>(rs + K4_RESCUE_LDS) + lane : nullptr;
   for (int64_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
     const k4_rescue_task tk = tasks[t];
     k4_hit h;
-    const int res = k4d_mate_rescue(ix, tk, reads, lane, rs, h);
+    const int res = k4d_mate_rescue(ix, tk, reads, lane, rs, h, mk);
     if (lane == 0) {
       rslt[t] = res;
       hits[t] = h;
@@ -183,7 +368,9 @@ extern "C" int k4_mate_rescue_batch(k4_index* ix, int64_t n, const k4_rescue_tas
   hipMemcpyAsync(d_t, tasks, (size_t)n * sizeof(k4_rescue_task), hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_r, reads, reads_bytes, hipMemcpyHostToDevice, st);
   unsigned grid = (unsigned)std::min<int64_t>(n, 256 * 32);
-  hipLaunchKernelGGL(k4k_mate_rescue, dim3(grid), dim3(64), 0, st, ix->d, d_t, d_r, n, d_res, d_h);
+  int chim = 0;
+  for (int64_t i = 0; i < n; i++) chim |= tasks[i].chimeric != 0;
+  hipLaunchKernelGGL(k4k_mate_rescue, dim3(grid), dim3(64), chim ? K4_RESCUE_LDS_CHIM : K4_RESCUE_LDS, st, ix->d, d_t, d_r, n, d_res, d_h, chim);
   hipMemcpyAsync(rslt, d_res, (size_t)n * 4, hipMemcpyDeviceToHost, st);
   hipMemcpyAsync(hits, d_h, (size_t)n * sizeof(k4_hit), hipMemcpyDeviceToHost, st);
   int rc = k4_check_hip(ix, hipStreamSynchronize(st), "mate rescue");
@@ -203,12 +390,17 @@ K4_DEV int k4d_pe_insert_size(const k4_pe_params& pe, uint8_t s1, uint32_t st1, 
   if (frag > pe.pair_max_len) return -7;
   return frag;
 }
+// AdjStartLoci / AdjEndLoci (KAligner.cpp:1633-1650): a chimeric hit counts from / to its trimmed ends
+K4_DEV uint32_t k4d_pe_adj_start(const k4_hit& h) { return h.match_loci + (h.strand == '+' ? K4_HIT_TRIM_LEFT(h) : K4_HIT_TRIM_RIGHT(h)); }
+K4_DEV uint32_t k4d_pe_adj_end(const k4_hit& h) {
+  return h.match_loci + ((uint32_t)h.match_len - (h.strand == '+' ? K4_HIT_TRIM_RIGHT(h) : K4_HIT_TRIM_LEFT(h)) - 1);
+}
 K4_DEV int k4d_accept_prov_pe(const k4_pe_params& pe, int nh1, const k4_hit& h1, int nh2, const k4_hit& h2) {  // :2799-2861
   if (!(nh1 == 1 && nh2 == 1)) return 0;
   if (h1.chrom_id != h2.chrom_id) return -2;
-  return k4d_pe_insert_size(pe, h1.strand, h1.match_loci, h1.match_loci + h1.match_len - 1, h2.strand, h2.match_loci,
-                            h2.match_loci + h2.match_len - 1);
+  return k4d_pe_insert_size(pe, h1.strand, k4d_pe_adj_start(h1), k4d_pe_adj_end(h1), h2.strand, k4d_pe_adj_start(h2), k4d_pe_adj_end(h2));
 }
+struct K4PeChim { int min_chimeric_len, min_core_len, slides_per100, min_edit_dist; };  // AlignPairedRead's chimeric mode (0: off)
 K4_DEV bool k4d_pe_unaligned(int nar) { return nar == K4_NAR_NS || nar == K4_NAR_NOHIT || nar == K4_NAR_UNALIGNED; }
 
 // what is left of an orphan pair that could not be accepted as a pair (KAligner.cpp:3538-3585)
@@ -297,9 +489,10 @@ __global__ void __launch_bounds__(256) k4k_pe_pair(k4_pe_params pe, int64_t n_pa
 __global__ void __launch_bounds__(64) k4k_pe_orphans(K4DevIndex ix, k4_pe_params pe, int max_subs, const uint8_t* __restrict__ reads,
                                                      const uint64_t* __restrict__ offs, const uint32_t* __restrict__ lens,
                                                      const uint32_t* __restrict__ orphans, k4_pe_read* __restrict__ out,
-                                                     uint32_t* __restrict__ ctl) {
-  __shared__ __attribute__((aligned(8))) uint8_t rs[K4_RESCUE_LDS];
+                                                     uint32_t* __restrict__ ctl, K4PeChim ch) {
+  extern __shared__ __attribute__((aligned(8))) uint8_t rs[];
   const int lane = threadIdx.x;
+  uint32_t* mk = ch.min_chimeric_len > 0 ? reinterpret_cast<uint32_t*>(rs + K4_RESCUE_LDS) + lane : nullptr;
   const uint32_t n_orph = ctl[0];
   for (uint32_t t = blockIdx.x; t < n_orph; t += gridDim.x) {
     const int64_t i = orphans[t];
@@ -318,19 +511,27 @@ __global__ void __launch_bounds__(64) k4k_pe_orphans(K4DevIndex ix, k4_pe_params
         if (pe.pair_strand) { tk.b3prime_extend = !tk.b3prime_extend; tk.antisense = !tk.antisense; }
       }
       tk.chrom_id = anchor.hit.chrom_id;
-      tk.start_loci = anchor.hit.match_loci;
-      tk.end_loci = anchor.hit.match_loci + anchor.hit.match_len - 1;
+      tk.start_loci = k4d_pe_adj_start(anchor.hit);  // OrphStartLoci / OrphEndLoci (:3354-3355)
+      tk.end_loci = k4d_pe_adj_end(anchor.hit);
       const int64_t mate = round == 0 ? 2 * i + 1 : 2 * i;
       tk.read_len = lens[mate];
       tk.read_off = offs[mate];
       tk.min_insert = pe.pair_min_len;
       tk.max_insert = pe.pair_max_len;
       tk.max_allowed_mm = max_subs;  // the per-100 bp rate, as the reference passes it (KAligner.cpp:3379, Q15)
+      if (ch.min_chimeric_len > 0) {   // the window core CKAligner derives for this mate (:3357-3370)
+        const int pl = (int)tk.read_len;
+        int tot_mm = max_subs == 0 ? 0 : max(1, (int)(0.5 + ((pl - 1) * max_subs) / 100.0));
+        tot_mm = min(tot_mm, 63);
+        const int cl = max(ch.min_core_len, pl / (ch.min_edit_dist == 1 ? tot_mm + 1 : tot_mm + 2));
+        const int cd = max(pl / ch.slides_per100 - 1, cl);
+        tk.chimeric = (uint32_t)ch.min_chimeric_len | ((uint32_t)min(cl, 4095) << 8) | ((uint32_t)min(cd, 4095) << 20);
+      }
       k4_hit h;
-      const int res = k4d_mate_rescue(ix, tk, reads, lane, rs, h);
+      const int res = k4d_mate_rescue(ix, tk, reads, lane, rs, h, mk);
       if (res != 1) continue;
-      const uint32_t hs = h.match_loci, he = h.match_loci + h.match_len - 1;
-      const uint32_t as = anchor.hit.match_loci, ae = anchor.hit.match_loci + anchor.hit.match_len - 1;
+      const uint32_t hs = k4d_pe_adj_start(h), he = k4d_pe_adj_end(h);  // (:3390, :3492)
+      const uint32_t as = tk.start_loci, ae = tk.end_loci;
       const int frag = round == 0 ? k4d_pe_insert_size(pe, anchor.hit.strand, as, ae, h.strand, hs, he)
                                   : k4d_pe_insert_size(pe, h.strand, hs, he, anchor.hit.strand, as, ae);
       if (frag <= 0) continue;
@@ -394,10 +595,20 @@ extern "C" int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, c
   if (rc != K4_OK) return rc;
   hipLaunchKernelGGL(k4k_pe_pair, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, pe, n_pairs, mh, ix->pe_rr,
                      ix->pe_hits, (k4_pe_read*)d_out, ix->pe_list, ix->pe_ctl);
-  if (pe.pe_mode == 1 || pe.pe_mode == 3)
-    hipLaunchKernelGGL(k4k_pe_orphans, dim3((unsigned)std::min<int64_t>(n_pairs, 256 * 32)), dim3(64), 0, st, ix->d, pe, p->max_subs,
+  if (pe.pe_mode == 1 || pe.pe_mode == 3) {
+    K4PeChim ch = {0, 0, 1, p->min_edit_dist};
+    if (p->min_chimeric_len > 0) {
+      int slides = 0;
+      int mcl = k4_min_core_len(ix, p->pmode, &slides);
+      if (p->min_core_len > 0) mcl = p->min_core_len;
+      if (p->max_num_slides > 0) slides = p->max_num_slides;
+      ch.min_chimeric_len = p->min_chimeric_len; ch.min_core_len = mcl; ch.slides_per100 = std::max(slides, 1);
+    }
+    hipLaunchKernelGGL(k4k_pe_orphans, dim3((unsigned)std::min<int64_t>(n_pairs, 256 * 32)), dim3(64),
+                       ch.min_chimeric_len > 0 ? K4_RESCUE_LDS_CHIM : K4_RESCUE_LDS, st, ix->d, pe, p->max_subs,
                        (const uint8_t*)d_reads, (const uint64_t*)d_offs, (const uint32_t*)d_lens, ix->pe_list,
-                       (k4_pe_read*)d_out, ix->pe_ctl);
+                       (k4_pe_read*)d_out, ix->pe_ctl, ch);
+  }
   K4_HIP(ix, hipGetLastError());
   K4_HIP(ix, hipStreamSynchronize(st));  // (the call's contract, include/k4sfx.h: the stream is waited for)
   return K4_OK;

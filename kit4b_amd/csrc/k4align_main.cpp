@@ -1006,7 +1006,6 @@ int main(int argc, char** argv) {
   if (o.splice_junct != 0 && (o.splice_junct < 25 || o.splice_junct > 100000)) { fprintf(stderr, "k4align: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000\n", o.splice_junct); return 1; }
   if (o.min_flank_exacts < 0 || o.min_flank_exacts > 7) { fprintf(stderr, "k4align: max flank trimming '-x%d' specified outside of range 0..7\n", o.min_flank_exacts); return 1; }
   if (pe && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDel '-a' / splice junction '-A' processing not supported in paired end processing\n"); return 1; }
-  if (pe && o.min_chimeric) { fprintf(stderr, "k4align: chimeric trimming '-c' is not supported in paired end processing yet (the mate rescue's trimmed branch, SfxArray.cpp:8616-8766)\n"); return 3; }
   if (o.ml_mode == 5 && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDels / splice junctions not supported when reporting multiloci alignments '-r5'\n"); return 1; }
   if (o.min_chimeric && (o.best || o.ml_mode == 3 || o.ml_mode == 4)) { fprintf(stderr, "k4align: chimeric read processing cannot be combined with -N / -r3 / -r4\n"); return 1; }
   if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830

@@ -17,7 +17,7 @@ CASES = json.load(open(os.path.join(G, "sam_cases.json")))
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/ngskit4b_k4 not built (make -C oracle ngskit4b_k4 needs /root/reference)")
-@pytest.mark.parametrize("case", ["se_s2", "pe_u1", "se_r5_R8_N", "se_c50", "se_a12", "se_A3000", "se_all_120"])
+@pytest.mark.parametrize("case", ["se_s2", "pe_u1", "se_r5_R8_N", "se_c50", "se_a12", "se_A3000", "se_all_120", "pe_c50_u1", "pe_c60_u3_wide"])
 def test_reference_front_end_on_the_gpu_library(tmp_path, case):
     def unxz(name):
         dst = str(tmp_path / name[:-3])

@@ -223,6 +223,7 @@ def _kalign_args(args):
         elif a in ("-r3", "-r4"): kw["pe_mode"] = 1                     # eMLuniq / eMLmulti: multi-aligned reads keep their loci
         elif a == "-X": kw["pe_mode"] = max(kw.get("pe_mode", 0), 3)   # ... reads over the -R limit clamped to it
         elif a == "-N": kw["pe_mode"] = 4                               # ... through LocateBestMatches
+        elif a.startswith("-c"): kw["min_chimeric_len"] = int(a[2:])    # chimeric trimming (paired-end cases; the SE ones: kalign_args)
     return kw, pe
 
 
@@ -327,6 +328,45 @@ def test_mate_rescue_over_windows_of_1000_loci_and_more(k4, oracle, golden_dir, 
     acc = g["nar"] == 1
     assert np.array_equal(g["hit"][acc], o["hit"][acc])
     assert g["rescued"].sum() > 20
+    ix.close()
+    oracle.close(ho)
+
+
+@pytest.mark.parametrize("pe_mode,lo,hi,mcl", [(1, 200, 600, 50), (3, 150, 1400, 60), (1, 100, 2500, 75), (2, 200, 700, 50)])
+def test_pe_chimeric_flow_vs_oracle(k4, oracle, golden_dir, pe_mode, lo, hi, mcl):
+    """kalign -c with paired ends: AlignReads' chimeric pass for both ends, trimmed loci in AcceptProvPE / PEInsertSize, and
+    AlignPairedRead's AdaptiveTrim branch for the rescue -- scanned windows (< 1000 loci) and windows seeded with exact cores
+    (IterateExactsRange); device vs the oracle (itself pinned by the live reference and two reference SAMs)."""
+    names, chroms = synth.golden_genome()
+    pe1, pe2, _ = synth.make_pe_reads(chroms, 2200, 125, seed=640 + hi, sub_lambda=1.6, n_prob=0.02, random_mate_frac=0.04,
+                                      frag_min=max(lo + 20, 260), frag_max=min(hi - 50, 1300))
+    rng = np.random.default_rng(hi)
+    for rd in pe1 + pe2:  # a third of the reads get foreign flanks
+        if rng.random() < 0.33:
+            L = len(rd)
+            for side in (0, 1):
+                if rng.random() < 0.65:
+                    k = int(rng.integers(L * 5 // 100, L * 35 // 100))
+                    if side == 0:
+                        rd[:k] = rng.integers(0, 4, k)
+                    else:
+                        rd[L - k:] = rng.integers(0, 4, k)
+    ix = k4.SfxIndex.open(os.path.join(golden_dir, "g1.sfx"))
+    ho = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    ix.set_max_iter(5000)
+    oracle.set_max_iter(ho, 5000)
+    kw = dict(pe_mode=pe_mode, pair_min_len=lo, pair_max_len=hi, pair_strand=False, max_subs=3, min_chimeric_len=mcl)
+    g = ix.kalign_pe_batch(pe1, pe2, **kw)
+    o = oracle_kalign_pe(oracle, ho, pe1, pe2, threads=8, **kw)
+    for f in ("nar", "num_hits", "inst", "low_mm", "pe_aligned", "rescued"):
+        bad = np.nonzero(g[f] != o[f])[0]
+        assert len(bad) == 0, (f, bad[:6], g[f][bad[:6]], o[f][bad[:6]])
+    acc = g["nar"] == 1
+    assert np.array_equal(g["hit"][acc], o["hit"][acc])
+    chim = (g["hit"]["reserved"][acc] >> 24) & 1
+    assert chim.sum() > 100  # trimmed placements are reported
+    if pe_mode in (1, 3):
+        assert (g["rescued"][acc] & (chim > 0)).sum() > 5  # ... also from the rescue
     ix.close()
     oracle.close(ho)
 
