@@ -72,7 +72,8 @@ ix.close()
 del seq, sa, reads
 torch.cuda.empty_cache()
 
-ref_sam, ref_log = os.path.join(tmp, "ref.sam"), os.path.join(tmp, "ref.log")
+BAM = os.environ.get("K4_REF_BAM") == "1"  # both programs write BAM (+ .bai); the decoded records are compared
+ref_sam, ref_log = os.path.join(tmp, "ref.bam" if BAM else "ref.sam"), os.path.join(tmp, "ref.log")
 t0 = time.time()
 r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log] + subs + extra + in_args, capture_output=True)
 t_ref = time.time() - t0
@@ -81,7 +82,7 @@ log = open(ref_log, errors="replace").read() if os.path.exists(ref_log) else ""
 keep = [ln for ln in log.splitlines() if re.search(r"align|Align|loaded|Loading|core|sort|Sort|SAM|Completed|completed", ln)]
 print("\n".join(keep[-40:]), flush=True)
 
-gpu_sam = os.path.join(tmp, "gpu.sam")
+gpu_sam = os.path.join(tmp, "gpu.bam" if BAM else "gpu.sam")
 t0 = time.time()
 g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam] + subs + extra + k4_extra + in_args, capture_output=True, text=True)
 t_gpu = time.time() - t0
@@ -109,12 +110,21 @@ if dropin_threads > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "n
     print("drop-in rc", d.returncode, "wall %.1fs" % t_di, "\n".join(al), flush=True)
     dropin = (di_sam, t_di, al)
 
+if BAM:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import samutil
+
+    def body(path):  # noqa: F811  (header lines but @PG + the dictionary; one tuple per record, every field)
+        text, refs, recs = samutil.read_bam(path)
+        hdr = [h for h in text.splitlines() if not h.startswith("@PG")] + ["%s:%d" % r for r in refs]
+        return hdr, [(r["ref"], r["pos"], r["bin"], r["mapq"], r["flag"], r["next_ref"], r["next_pos"], r["tlen"], r["name"],
+                      tuple(r["cigar"]), r["seq"], bytes(r["qual"]), bytes(r["aux"])) for r in recs]
 hr, rr = body(ref_sam)
 hg, rg = body(gpu_sam)
 same_hdr = hr == hg
 same_order = rr == rg
 same_set = sorted(rr) == sorted(rg)
-out = {"extra_args": extra, "k4align_extra_args": k4_extra, "repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
+out = {"format": "BAM" if BAM else "SAM", "extra_args": extra, "k4align_extra_args": k4_extra, "repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
        "reference_sam_records": len(rr), "k4align_sam_records": len(rg), "headers_equal": same_hdr,
        "records_equal_as_multiset": same_set, "records_equal_in_order": same_order}
 if dropin:
@@ -126,5 +136,5 @@ if dropin:
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"summary": out, "reference_log_tail": keep[-40:], "k4align_stderr": g.stderr[-3000:]},
-          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep > 0 else "_stress" if n_rep < 0 else "") + ("_" + "".join(extra).replace("-", "") if extra else ""))), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep > 0 else "_stress" if n_rep < 0 else "") + ("_" + "".join(extra).replace("-", "") if extra else "") + ("_bam" if BAM else ""))), "w"), indent=1)
 shutil.rmtree(tmp, ignore_errors=True)
