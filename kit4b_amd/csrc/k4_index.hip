@@ -11,6 +11,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <thread>
+#include <vector>
 #include "k4_device.h"
 
 // ---- errors ---------------------------------------------------------------------------------------------
@@ -451,6 +453,48 @@ static int check_entries(uint64_t n, uint32_t ne, const k4_entry* e) {
   return 1;
 }
 
+// Pageable host memory (the mapped .sfx file, 15 GB at 3 Gbp) -> HBM.  One hipMemcpy from pageable memory is staged by the runtime
+// through its own small pinned buffers by ONE thread, page faults of the mapping included (~6 GB/s).  Here: three pinned pieces,
+// several host threads fill one (touching the file's pages side by side) while the previous piece's copy is on its way.
+static int k4i_upload_pageable(k4_index* ix, void* d_dst, const uint8_t* src, size_t bytes) {
+  const size_t piece = (size_t)128 << 20;
+  if (bytes < 2 * piece) return k4_check_hip(ix, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(index)");
+  const int NB = 3, NT = 8;
+  uint8_t* buf[NB] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[NB] = {nullptr, nullptr, nullptr};
+  bool used[NB] = {false, false, false};
+  hipStream_t st = nullptr;
+  int rc = K4_OK;
+  auto done = [&]() {
+    if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+    for (int b = 0; b < NB; b++) { if (buf[b]) hipHostFree(buf[b]); if (ev[b]) hipEventDestroy(ev[b]); }
+    return rc;
+  };
+  if ((rc = k4_check_hip(ix, hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream")) != K4_OK) return done();
+  for (int b = 0; b < NB; b++) {
+    if ((rc = k4_check_hip(ix, hipHostMalloc((void**)&buf[b], piece, hipHostMallocDefault), "pinned staging")) != K4_OK) return done();
+    if ((rc = k4_check_hip(ix, hipEventCreateWithFlags(&ev[b], hipEventDisableTiming), "event")) != K4_OK) return done();
+  }
+  int k = 0;
+  for (size_t off = 0; off < bytes; off += piece, k++) {
+    const int b = k % NB;
+    const size_t len = std::min(piece, bytes - off);
+    if (used[b] && (rc = k4_check_hip(ix, hipEventSynchronize(ev[b]), "upload")) != K4_OK) return done();
+    std::vector<std::thread> th;
+    for (int t = 0; t < NT; t++)
+      th.emplace_back([=] {
+        const size_t a = len * (size_t)t / NT, z = len * (size_t)(t + 1) / NT;
+        memcpy(buf[b] + a, src + off + a, z - a);
+      });
+    for (std::thread& x : th) x.join();
+    if ((rc = k4_check_hip(ix, hipMemcpyAsync((uint8_t*)d_dst + off, buf[b], len, hipMemcpyHostToDevice, st), "upload")) != K4_OK) return done();
+    if ((rc = k4_check_hip(ix, hipEventRecord(ev[b], st), "upload")) != K4_OK) return done();
+    used[b] = true;
+  }
+  rc = k4_check_hip(ix, hipStreamSynchronize(st), "upload");
+  return done();
+}
+
 static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void* d_seq_in, const uint8_t* h_sa,
                        void* d_sa_in, int adopt_sa, uint32_t ne, const k4_entry* entries, const char* dataset,
                        int device, int kmer_k, k4_index** out) {
@@ -485,16 +529,16 @@ static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void
   } else {
     if ((rc = k4_check_hip(ix, hipMalloc(&ix->sa, n * el + 16), "hipMalloc(sa)")) != K4_OK) return fail(rc);
     ix->device_bytes += n * el + 16;
-    hipError_t e = d_sa_in ? hipMemcpy(ix->sa, d_sa_in, n * el, hipMemcpyDeviceToDevice)
-                           : hipMemcpy(ix->sa, h_sa, n * el, hipMemcpyHostToDevice);
-    if ((rc = k4_check_hip(ix, e, "hipMemcpy(sa)")) != K4_OK) return fail(rc);
+    rc = d_sa_in ? k4_check_hip(ix, hipMemcpy(ix->sa, d_sa_in, n * el, hipMemcpyDeviceToDevice), "hipMemcpy(sa)")
+                 : k4i_upload_pageable(ix, ix->sa, h_sa, (size_t)(n * el));
+    if (rc != K4_OK) return fail(rc);
   }
   // sequence bytes: temporary on the device, only needed to derive the packed form
   uint8_t* d_tmp = nullptr;
   const void* d_seq = d_seq_in;
   if (!d_seq) {
     if ((rc = k4_check_hip(ix, hipMalloc(&d_tmp, n + 64), "hipMalloc(seq)")) != K4_OK) return fail(rc);
-    if ((rc = k4_check_hip(ix, hipMemcpy(d_tmp, h_seq, n, hipMemcpyHostToDevice), "hipMemcpy(seq)")) != K4_OK) {
+    if ((rc = k4i_upload_pageable(ix, d_tmp, h_seq, (size_t)n)) != K4_OK) {
       hipFree(d_tmp);
       return fail(rc);
     }
