@@ -242,6 +242,13 @@ int k4o_kalign_pe_batch(const k4o_index* ix, const k4o_kalign_params* kp, const 
                         const uint8_t* reads1, const uint64_t* offs1, const uint32_t* lens1, const uint8_t* reads2,
                         const uint64_t* offs2, const uint32_t* lens2, k4o_pe_read* out, int nthreads);
 
+/* kalign's SNP calling, main CSV (CKAligner::ProcessSNPs KAligner.cpp:8168-8590 + OutputSNPs :7098-7760; k4oracle_snp.c):
+ * nar / hits[i * hit_stride]: one reported alignment per read.  Returns the CSV text (release with k4o_free). */
+char* k4o_snp_csv(const k4o_index* ix, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride, const uint8_t* reads,
+                  const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
+                  int64_t* n_snps);
+void k4o_free(void* p);
+
 /* CKAligner::AssignMultiMatches (KAligner.cpp:5092-5258) with ProcAssignMultiMatches (:4944-5085) over the results of
  * k4o_align_batch run with pe_mode 1 (a read within the instance limit keeps its inst loci; unique ones are accepted):
  * ml_mode 3 = eMLuniq (`-r3`, cluster with uniquely aligned reads only), 4 = eMLmulti (`-r4`).  A multi-aligned read that

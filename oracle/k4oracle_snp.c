@@ -1,0 +1,182 @@
+/* oracle/k4oracle_snp.c -- TEST INFRASTRUCTURE ONLY (see k4oracle.h): CPU restatement of kalign's SNP calling, main CSV only.
+ *
+ *   CKAligner::ProcessSNPs  ngskit4b/KAligner.cpp:8168-8590  per-locus base counts over the accepted alignments of a chromosome
+ *   CKAligner::OutputSNPs   ngskit4b/KAligner.cpp:7098-7760  background rate in a 51-base window, binomial p-value, Benjamini-
+ *                                                            Hochberg cut, the "SNP_ID",... CSV line
+ *   CStats::Binomial / ProbKeqlk / Calc_nCk  libkit4b/Stats.cpp:489-564
+ *
+ * Not restated (files the reference writes beside the CSV by default or on request): .covsegs.wig, .disnp.csv, .trisnp.csv, marker
+ * sequences, SNP centroids, VCF / BED forms, packed base alleles, SOLiD colourspace.
+ * Ranks: the reference orders the candidates by p-value with a multi-threaded quicksort (equal p-values -- most are 0 -- in no
+ * defined order); here equal p-values keep locus order, which is what the reference produces on inputs small enough for its
+ * sort to stay sequential.  Parity pinned by tests/golden/snp_*.csv (written by `ngskit4b kalign -p -P -S`). */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "k4oracle.h"
+#include "k4oracle_priv.h"
+
+typedef struct { uint32_t ref, nonref, by_base[5]; uint8_t ref_base; } snp_cnts;
+typedef struct {
+  uint32_t loci, rank, num_reads, num_subs, local_reads, local_subs;
+  double pvalue, bkgnd;
+  snp_cnts c;
+} loci_pv;
+
+static double calc_nck(uint32_t n, uint32_t k) { /* Stats.cpp:489-524 (what is left of it after `accum = 1`) */
+  if (k > n) return 0.0;
+  if (k > n / 2) k = n - k;
+  long double accum = 1;
+  for (uint32_t i = 1; i <= k; i++) accum = accum * (n - k + i) / i;
+  return (double)accum;
+}
+static double prob_k_eql_k(uint32_t n, uint32_t k, double p) { /* :530-538 */
+  if (p < 0 || p > 1) return -1;
+  return calc_nck(n, k) * pow(p, (double)(int32_t)k) * pow(1 - p, (double)(int32_t)(n - k));
+}
+static double binomial(int n, int k, double p) { /* :543-564 */
+  if (k > n) return 0.0;
+  if (n > 5000) { k = (int)((1000.0 / n) * k); n = 5000; }
+  double sum = 0;
+  for (int i = 0; i <= k; i++) {
+    sum += prob_k_eql_k((uint32_t)n, (uint32_t)i, p);
+    if (sum >= 1.0) break;
+  }
+  return sum < 1.0 ? sum : 1.0;
+}
+
+static int cmp_pv(const void* a, const void* b) { /* SortLociPValues :11153, ties: locus order (see the header) */
+  const loci_pv* x = (const loci_pv*)a; const loci_pv* y = (const loci_pv*)b;
+  if (x->pvalue < y->pvalue) return -1;
+  if (x->pvalue > y->pvalue) return 1;
+  return x->loci < y->loci ? -1 : x->loci > y->loci;
+}
+static int cmp_loci(const void* a, const void* b) { /* SortPValuesLoci :11165 */
+  const loci_pv* x = (const loci_pv*)a; const loci_pv* y = (const loci_pv*)b;
+  return x->loci < y->loci ? -1 : x->loci > y->loci;
+}
+
+typedef struct { char* p; size_t len, cap; } sbuf;
+static void sb_put(sbuf* b, const char* s, size_t n) {
+  if (b->len + n + 1 > b->cap) { b->cap = (b->len + n + 1) * 2 + 4096; b->p = (char*)realloc(b->p, b->cap); }
+  memcpy(b->p + b->len, s, n); b->len += n; b->p[b->len] = 0;
+}
+
+/* nar / hits: one per read (hits[i * hit_stride] = the reported alignment).  Returns the CSV text (malloc'd; caller frees) and
+ * the number of SNPs through *n_snps; NULL on bad arguments. */
+char* k4o_snp_csv(const k4o_index* ix, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride, const uint8_t* reads,
+                  const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
+                  int64_t* n_snps) {
+  if (!ix || n_reads < 0 || min_snp_reads < 1) return NULL;
+  const double nonref_frac = snp_nonref_pcnt / 100.0; /* m_SNPNonRefPcnt, KAligner.cpp:256 */
+  sbuf out = {0, 0, 0};
+  const char* hdr = "\"SNP_ID\",\"ElType\",\"Species\",\"Chrom\",\"StartLoci\",\"EndLoci\",\"Len\",\"Strand\",\"Rank\",\"PValue\",\"Bases\",\"Mismatches\",\"RefBase\",\"MMBaseA\",\"MMBaseC\",\"MMBaseG\",\"MMBaseT\",\"MMBaseN\",\"BackgroundSubRate\",\"TotWinBases\",\"TotWinMismatches\",\"MarkerID\",\"NumPolymorphicSites\"\n";
+  sb_put(&out, hdr, strlen(hdr));
+  int64_t tot_snps = 0;
+  uint8_t* rs = (uint8_t*)malloc(1 << 16);
+  for (uint32_t chrom = 1; chrom <= ix->n_entries; chrom++) { /* the reads come sorted: one chromosome after the other (:8340-8400) */
+    const k4o_entry* e = &ix->entries[chrom - 1];
+    const uint32_t clen = e->seq_len;
+    snp_cnts* cnt = NULL;
+    uint64_t tot_match = 0, tot_mismatch = 0;
+    for (int64_t i = 0; i < n_reads; i++) {
+      if (nar[i] != K4O_NAR_ACCEPTED) continue;
+      const k4o_hit* h = &hits[i * (int64_t)hit_stride];
+      if (h->chrom_id != chrom) continue;
+      if (h->ext & (K4O_EXT_INDEL | K4O_EXT_SPLICE)) continue; /* :8345 */
+      if (!cnt) cnt = (snp_cnts*)calloc((size_t)clen + 16, sizeof(snp_cnts));
+      const uint32_t tl = h->ext & 0xFFF, tr = (h->ext >> 12) & 0xFFF;
+      uint32_t match_len = (uint32_t)h->match_len - tl - tr;                 /* AdjHitLen */
+      const uint32_t hit_loci = h->match_loci + (h->strand == '+' ? tl : tr); /* AdjStartLoci */
+      if ((uint64_t)hit_loci + match_len > clen) continue; /* GetSeq returns less than asked for: the read is skipped (:8420) */
+      const uint8_t* src = reads + offs[i] + tl; /* pSeg->ReadOfs (0) + TrimLeft */
+      for (uint32_t q = 0; q < match_len; q++) rs[q] = src[q] & 0x07;
+      if (h->strand == '-') k4o_revcomp(rs, (int)match_len);
+      if (hit_loci + match_len > clen) { if ((match_len = clen - hit_loci) < 10) continue; }
+      const uint8_t* ref = ix->seq + e->start_ofs + hit_loci;
+      snp_cnts* s = cnt + hit_loci;
+      for (uint32_t q = 0; q < match_len; q++, s++) { /* :8468-8557, base space */
+        const uint8_t a = ref[q] & 0x07;
+        uint8_t r = rs[q];
+        if (a >= K4O_N || r > K4O_N) continue;
+        s->ref_base = a;
+        if (a == r) { s->ref++; tot_match++; }
+        else {
+          if (r > 3) r = K4O_N;
+          s->by_base[r]++; s->nonref++; tot_mismatch++;
+        }
+      }
+    }
+    if (!cnt) continue;
+    /* ---- OutputSNPs for this chromosome --------------------------------------------------------------------------------- */
+    double global_rate = (double)tot_mismatch / (double)(1 + tot_match + tot_mismatch);
+    if (global_rate < 0.005) global_rate = 0.005; /* cMinSeqErrRate */
+    const uint32_t flank = 51 / 2, win = flank * 2 + 1; /* cSNPBkgndRateWindow */
+    uint32_t loc_mm = 0, loc_m = 0;
+    const snp_cnts* win_r = cnt;
+    const snp_cnts* win_l = cnt;
+    for (uint32_t l = 0; l < (win < clen ? win : clen); l++, win_r++) { loc_mm += win_r->nonref; loc_m += win_r->ref; }
+    loci_pv* pv = NULL;
+    size_t n_pv = 0, cap_pv = 0;
+    for (uint32_t l = 0; l < clen; l++) {
+      const snp_cnts* s = cnt + l;
+      if (l > flank && (l + flank) < clen) { /* :7358-7374 slide the window */
+        loc_mm = loc_mm >= win_l->nonref ? loc_mm - win_l->nonref : 0;
+        loc_m = loc_m >= win_l->ref ? loc_m - win_l->ref : 0;
+        loc_mm += win_r->nonref; loc_m += win_r->ref;
+        win_l++; win_r++;
+      }
+      const int tot_bases = (int)(s->nonref + s->ref);
+      if (tot_bases < min_snp_reads) continue;
+      if (s->nonref < 1) continue; /* cMinSNPreads */
+      const double proportion = (double)s->nonref / tot_bases;
+      if (proportion < nonref_frac) continue;
+      const uint32_t ltmm = s->nonref <= loc_mm ? loc_mm - s->nonref : 0;
+      const uint32_t ltm = s->ref < loc_m ? loc_m - s->ref : 0;
+      double local_rate;
+      if ((ltmm + ltm) == 0) local_rate = global_rate;
+      else {
+        local_rate = (double)ltmm / (double)(ltmm + ltm);
+        if (local_rate < global_rate) local_rate = global_rate;
+      }
+      if (local_rate > 0.20) continue; /* cMaxBkgdNoiseThres */
+      if (n_pv == cap_pv) { cap_pv = cap_pv ? cap_pv * 2 : 1024; pv = (loci_pv*)realloc(pv, cap_pv * sizeof(loci_pv)); }
+      loci_pv* p = &pv[n_pv++];
+      p->pvalue = 1.0 - binomial(tot_bases, (int)s->nonref, local_rate);
+      p->loci = l; p->rank = 0; p->bkgnd = local_rate; p->local_reads = ltmm + ltm; p->local_subs = ltmm;
+      p->num_reads = (uint32_t)tot_bases; p->num_subs = s->nonref; p->c = *s;
+    }
+    if (n_pv) {
+      qsort(pv, n_pv, sizeof(loci_pv), cmp_pv);
+      size_t n_acc = 0;
+      for (size_t k = 0; k < n_pv; k++) { /* Benjamini-Hochberg, :7614-7622 */
+        const double adj = ((k + 1) / (double)n_pv) * qvalue;
+        if (pv[k].pvalue >= adj) break;
+        pv[k].rank = (uint32_t)(k + 1);
+        n_acc++;
+      }
+      qsort(pv, n_acc, sizeof(loci_pv), cmp_loci);
+      for (size_t k = 0; k < n_acc; k++) {
+        loci_pv* p = &pv[k];
+        tot_snps++;
+        int rel = (int)(999 - ((999 * (int64_t)p->rank) / (int64_t)n_acc));
+        if (rel < 1) rel = 1;
+        p->c.by_base[p->c.ref_base] = p->num_reads - p->num_subs; /* :7698 */
+        char line[512];
+        const int n = snprintf(line, sizeof(line), "%d,\"SNP\",\"%s\",\"%s\",%d,%d,1,\"+\",%d,%f,%d,%d,\"%c\",%d,%d,%d,%d,%d,%f,%d,%d,%d,%d\n",
+                               (int)tot_snps, ix->dataset, e->name, (int)p->loci, (int)p->loci, rel, p->pvalue, (int)p->num_reads, (int)p->num_subs,
+                               "ACGTN"[p->c.ref_base > 4 ? 4 : p->c.ref_base], (int)p->c.by_base[0], (int)p->c.by_base[1], (int)p->c.by_base[2],
+                               (int)p->c.by_base[3], (int)p->c.by_base[4], p->bkgnd, (int)p->local_reads, (int)p->local_subs, 0, 0);
+        sb_put(&out, line, (size_t)n);
+      }
+    }
+    free(pv);
+    free(cnt);
+  }
+  free(rs);
+  if (n_snps) *n_snps = tot_snps;
+  return out.p;
+}
+void k4o_free(void* p) { free(p); }
