@@ -376,6 +376,16 @@ int k4_format_bam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, c
                       const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
                       const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes, k4_sam_stats* stats,
                       uint8_t* chrom_hit, void* stream);
+/* k4_snp_csv_dev <- CKAligner::ProcessSNPs + OutputSNPs (KAligner.cpp:8168-8590, 7098-7760; `kalign -p<n> -P<q> -S<file>`): SNP calls
+ * over the accepted alignments of a run, as the text of kalign's main SNP CSV (header line included).  Per chromosome on the
+ * device: base counts per locus, the 51-base background window, the coverage / non-reference tests; on the host, for the loci that
+ * pass: binomial p-value (CStats::Binomial), Benjamini-Hochberg at `qvalue`, ranks, text.  min_snp_reads: kalign -p (1..),
+ * snp_nonref_pcnt: kalign -1 (percent).  *csv is malloc'd: release with k4_free_host.  The files kalign writes beside the CSV
+ * (coverage WIG, DiSNPs, TriSNPs, markers) are not produced. */
+int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml, const void* d_pe,
+                   const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads, double qvalue,
+                   double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream);
+void k4_free_host(void* p);
 /* k4_select_hits_dev <- MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962) after k4_kalign_batch_dev with pe_mode 2: every accepted
  * read keeps ONE instance, hits[choice[i] % NumHits] moved to slot 0, NumHits = 1.  d_choice: uint32 per read, the caller's
  * draws (the reference: rand() once per read within the limit, in load order when it runs one thread). */

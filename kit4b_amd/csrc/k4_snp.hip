@@ -1,0 +1,280 @@
+// kit4b_amd/csrc/k4_snp.hip -- kalign's SNP calling (main CSV) over device-resident alignments.
+//
+//   CKAligner::ProcessSNPs  ngskit4b/KAligner.cpp:8168-8590   per-locus base counts over the accepted alignments of a chromosome
+//   CKAligner::OutputSNPs   ngskit4b/KAligner.cpp:7098-7760   background rate in a 51-base window, binomial p-value, Benjamini-
+//                                                             Hochberg cut, one "SNP_ID",... CSV line per call
+//   CStats::Binomial / ProbKeqlk / Calc_nCk   libkit4b/Stats.cpp:489-564
+//
+// Device: the pile-up (one wave per alignment, lanes over its bases, atomic adds into seven per-locus arrays of the chromosome),
+// two prefix sums and one kernel that evaluates the window sums and the integer / proportion tests at every locus and appends the
+// few loci that pass.  Host (this file, plain C++): error rates, p-values, ranks and text for those loci -- a few hundred per
+// chromosome -- with the reference's own floating-point operations in its order (long double n-choose-k included).
+// Not built: the side files kalign writes with the CSV (.covsegs.wig, .disnp.csv, .trisnp.csv), marker sequences, centroids,
+// VCF / BED forms, packed base alleles.  Equal p-values keep locus order in the ranking (the reference's multi-threaded quicksort
+// leaves them in no defined order).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "k4_device.h"
+
+namespace {
+
+struct SnpArgs {
+  K4DevIndex ix;
+  int pe;
+  int64_t n_reads;
+  const k4_read_result* rr;
+  const k4_hit* hits;
+  int max_ml;
+  const k4_pe_read* pr;
+  const uint8_t* reads;
+  const uint64_t* offs;
+  const uint32_t* lens;
+  uint32_t chrom_id;
+  uint64_t cs;       // concat offset of the chromosome
+  uint32_t clen;
+  uint32_t* cnt;     // seven arrays of clen + 16: ref, nonref, A, C, G, T, N
+  unsigned long long* tot;  // [0] TotMatch [1] TotMismatch [2] reads piled up
+};
+#define K4_SNP_STRIDE(a) ((size_t)(a).clen + 16)
+
+// ProcessSNPs' inner loop (:8468-8557, base space), one wave per accepted alignment on this chromosome
+__global__ void __launch_bounds__(256) k4k_snp_pileup(SnpArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
+  unsigned long long m = 0, mm = 0, nr = 0;
+  for (int64_t i = wave0; i < a.n_reads; i += n_waves) {
+    const int nar = a.pe ? a.pr[i].nar : a.rr[i].nar;
+    if (nar != K4_NAR_ACCEPTED) continue;
+    const k4_hit h = a.pe ? a.pr[i].hit : a.hits[i * a.max_ml];
+    if (h.chrom_id != a.chrom_id || (h.ext & (K4_EXT_INDEL | K4_EXT_SPLICE))) continue;
+    const uint32_t tl = K4_HIT_TRIM_LEFT(h), tr = K4_HIT_TRIM_RIGHT(h);
+    uint32_t match_len = (uint32_t)h.match_len - tl - tr;                 // AdjHitLen
+    const uint32_t loci0 = h.match_loci + (h.strand == '+' ? tl : tr);   // AdjStartLoci
+    if ((uint64_t)loci0 + match_len > a.clen) continue;                  // (GetSeq comes back short: the read is skipped, :8420)
+    const uint8_t* src = a.reads + a.offs[i] + tl;
+    if (lane == 0) nr++;
+    for (uint32_t q = lane; q < match_len; q += 64) {
+      const uint32_t ref = k4d_ref_base(a.ix, a.cs + loci0 + q);
+      uint32_t r = h.strand == '+' ? (src[q] & 7u) : (src[match_len - 1 - q] & 7u);
+      if (h.strand != '+' && r <= 3) r = 3 - r;
+      if (ref >= 4 || r > 4) continue;
+      uint32_t* c = a.cnt + loci0 + q;
+      if (ref == r) { atomicAdd(c, 1u); m++; }
+      else {
+        atomicAdd(c + K4_SNP_STRIDE(a), 1u);
+        atomicAdd(c + (2 + r) * K4_SNP_STRIDE(a), 1u);
+        mm++;
+      }
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) { m += __shfl_down(m, d, 64); mm += __shfl_down(mm, d, 64); }
+  if (lane == 0) {
+    if (m) atomicAdd(&a.tot[0], m);
+    if (mm) atomicAdd(&a.tot[1], mm);
+    if (nr) atomicAdd(&a.tot[2], nr);
+  }
+}
+
+struct Cand { uint32_t loci, n_ref, n_nonref, by_base[5], loc_mm, loc_m, ref_base, pad; };  // 48 bytes
+
+// OutputSNPs' per-locus tests that need no error rate (:7375-7438): coverage, non-reference count and proportion; the window
+// [l - 25, l + 26) clamped into the chromosome as the reference's sliding sums have it
+__global__ void __launch_bounds__(256) k4k_snp_candidates(SnpArgs a, const uint64_t* __restrict__ p_ref, const uint64_t* __restrict__ p_non,
+                                                          int min_snp_reads, double nonref_frac, Cand* __restrict__ out, uint32_t cap,
+                                                          uint32_t* __restrict__ n_out) {
+  const uint32_t l = blockIdx.x * 256u + threadIdx.x;
+  if (l >= a.clen) return;
+  const size_t S = K4_SNP_STRIDE(a);
+  const uint32_t n_ref = a.cnt[l], n_non = a.cnt[S + l];
+  const int tot = (int)(n_ref + n_non);
+  if (tot < min_snp_reads || n_non < 1) return;
+  if ((double)n_non / tot < nonref_frac) return;
+  const uint32_t flank = 25, win = 51;
+  uint32_t lo = 0, hi = min(win, a.clen);
+  if (a.clen > win) {  // slid once for every locus in (flank, clen - flank): it stays where the first / last of them left it
+    lo = l <= flank ? 0u : (l + flank < a.clen ? l - flank : a.clen - win);
+    hi = lo + win;
+  }
+  const uint32_t loc_mm = (uint32_t)(p_non[hi] - p_non[lo]), loc_m = (uint32_t)(p_ref[hi] - p_ref[lo]);
+  const uint32_t slot = atomicAdd(n_out, 1u);
+  if (slot >= cap) return;
+  Cand c;
+  c.loci = l; c.n_ref = n_ref; c.n_nonref = n_non;
+  for (int b = 0; b < 5; b++) c.by_base[b] = a.cnt[(2 + b) * S + l];
+  c.loc_mm = loc_mm; c.loc_m = loc_m;
+  c.ref_base = k4d_ref_base(a.ix, a.cs + l);  // pSNP->RefBase: the target symbol (a covered locus: the reference has set it)
+  c.pad = 0;
+  out[slot] = c;
+}
+
+struct Buf {
+  void* p = nullptr;
+  ~Buf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+// ---- CStats (libkit4b/Stats.cpp:489-564), operation for operation ------------------------------------------------------------
+double calc_nck(uint32_t n, uint32_t k) {
+  if (k > n) return 0.0;
+  if (k > n / 2) k = n - k;
+  long double accum = 1;
+  for (uint32_t i = 1; i <= k; i++) accum = accum * (n - k + i) / i;
+  return (double)accum;
+}
+double prob_k_eql_k(uint32_t n, uint32_t k, double p) {
+  if (p < 0 || p > 1) return -1;
+  const double nck = calc_nck(n, k);
+  const double p2 = pow(p, (int32_t)k);
+  const double q2 = pow(1 - p, (int32_t)(n - k));
+  return nck * p2 * q2;
+}
+double binomial(int n, int k, double p) {
+  if (k > n) return 0.0;
+  if (n > 5000) { k = (int)((1000.0 / n) * k); n = 5000; }
+  double sum = 0;
+  for (int i = 0; i <= k; i++) {
+    sum += prob_k_eql_k((uint32_t)n, (uint32_t)i, p);
+    if (sum >= 1.0) break;
+  }
+  return std::min(sum, 1.0);
+}
+
+struct LociPV {
+  uint32_t loci, rank, num_reads, num_subs, local_reads, local_subs, ref_base;
+  uint32_t by_base[5];
+  double pvalue, bkgnd;
+};
+
+}  // namespace
+
+extern "C" int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                              const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
+                              double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream) {
+  if (!ix || !csv || !csv_bytes) return K4_ERR_PARAMS;
+  *csv = nullptr;
+  *csv_bytes = 0;
+  if (n_snps) *n_snps = 0;
+  if (n_units < 0 || min_snp_reads < 1 || qvalue < 0.0 || snp_nonref_pcnt < 0.0) return k4_fail(ix, K4_ERR_PARAMS, "SNP parameters out of range");
+  if (n_units > 0 && ((pe && !d_pe) || (!pe && (!d_rr || !d_hits || max_ml < 1)) || !d_reads || !d_offs || !d_lens))
+    return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  K4_HIP(ix, hipSetDevice(ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  std::string text =
+      "\"SNP_ID\",\"ElType\",\"Species\",\"Chrom\",\"StartLoci\",\"EndLoci\",\"Len\",\"Strand\",\"Rank\",\"PValue\",\"Bases\",\"Mismatches\",\"RefBase\","
+      "\"MMBaseA\",\"MMBaseC\",\"MMBaseG\",\"MMBaseT\",\"MMBaseN\",\"BackgroundSubRate\",\"TotWinBases\",\"TotWinMismatches\",\"MarkerID\",\"NumPolymorphicSites\"\n";
+  SnpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ix = ix->d; a.pe = pe ? 1 : 0; a.n_reads = pe ? 2 * n_units : n_units;
+  a.rr = (const k4_read_result*)d_rr; a.hits = (const k4_hit*)d_hits; a.max_ml = max_ml; a.pr = (const k4_pe_read*)d_pe;
+  a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
+  uint32_t max_len = 0;
+  for (const k4_entry& e : ix->entries) max_len = std::max(max_len, e.seq_len);
+  const size_t S = (size_t)max_len + 16;
+  Buf cnt, tot, pref, pnon, cands, ncand, tmp;
+  const uint32_t cap = 1u << 22;  // candidate loci per chromosome kept on the device (more: the call fails loudly)
+  K4_HIP(ix, cnt.alloc(7 * S * 4));
+  K4_HIP(ix, tot.alloc(3 * 8));
+  K4_HIP(ix, pref.alloc((S + 1) * 8));
+  K4_HIP(ix, pnon.alloc((S + 1) * 8));
+  K4_HIP(ix, cands.alloc((size_t)cap * sizeof(Cand)));
+  K4_HIP(ix, ncand.alloc(4));
+  size_t tb = 0;
+  K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, cnt.as<uint32_t>(), pref.as<uint64_t>(), (uint64_t)0, S + 1, rocprim::plus<uint64_t>(), st));
+  K4_HIP(ix, tmp.alloc(tb));
+  uint64_t tot_snps = 0;
+  const double nonref_frac = snp_nonref_pcnt / 100.0;  // m_SNPNonRefPcnt, KAligner.cpp:256
+  std::vector<Cand> hc;
+  std::vector<LociPV> pv;
+  for (uint32_t chrom = 1; chrom <= ix->d.n_entries && a.n_reads > 0; chrom++) {  // the sorted reads: one chromosome after the other
+    const k4_entry& e = ix->entries[chrom - 1];
+    a.chrom_id = chrom; a.clen = e.seq_len; a.cnt = cnt.as<uint32_t>(); a.tot = tot.as<unsigned long long>();
+    {
+      uint64_t cs = 0;
+      K4_HIP(ix, hipMemcpy(&cs, ix->ent_start + (chrom - 1), 8, hipMemcpyDeviceToHost));
+      a.cs = cs;
+    }
+    const size_t Sc = K4_SNP_STRIDE(a);
+    K4_HIP(ix, hipMemsetAsync(cnt.p, 0, 7 * Sc * 4, st));
+    K4_HIP(ix, hipMemsetAsync(tot.p, 0, 24, st));
+    K4_HIP(ix, hipMemsetAsync(ncand.p, 0, 4, st));
+    hipLaunchKernelGGL(k4k_snp_pileup, dim3(2048), dim3(256), 0, st, a);
+    unsigned long long t3[3] = {0, 0, 0};
+    K4_HIP(ix, hipMemcpyAsync(t3, tot.p, 24, hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+    if (t3[2] == 0) continue;  // no alignment on this chromosome
+    // prefix sums over [0, clen]: element l = sum of the loci below l (the arrays are zero behind clen)
+    K4_HIP(ix, rocprim::exclusive_scan(tmp.p, tb, a.cnt, pref.as<uint64_t>(), (uint64_t)0, (size_t)a.clen + 1, rocprim::plus<uint64_t>(), st));
+    K4_HIP(ix, rocprim::exclusive_scan(tmp.p, tb, a.cnt + Sc, pnon.as<uint64_t>(), (uint64_t)0, (size_t)a.clen + 1, rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL(k4k_snp_candidates, dim3((a.clen + 255) / 256), dim3(256), 0, st, a, pref.as<uint64_t>(), pnon.as<uint64_t>(), (int)min_snp_reads,
+                       nonref_frac, cands.as<Cand>(), cap, ncand.as<uint32_t>());
+    uint32_t nc = 0;
+    K4_HIP(ix, hipMemcpyAsync(&nc, ncand.p, 4, hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+    if (nc > cap) return k4_fail(ix, K4_ERR_MEM, "more than %u candidate SNP loci on %s", cap, e.name);
+    hc.resize(nc);
+    if (nc) K4_HIP(ix, hipMemcpy(hc.data(), cands.p, (size_t)nc * sizeof(Cand), hipMemcpyDeviceToHost));
+    std::sort(hc.begin(), hc.end(), [](const Cand& x, const Cand& y) { return x.loci < y.loci; });
+    // ---- OutputSNPs from here on (:7320, :7425-7450, :7567-7640) -------------------------------------------------------------
+    double global_rate = (double)t3[1] / (double)(1 + t3[0] + t3[1]);
+    global_rate = std::max(0.005, global_rate);  // cMinSeqErrRate
+    pv.clear();
+    for (const Cand& c : hc) {
+      const uint32_t ltmm = c.n_nonref <= c.loc_mm ? c.loc_mm - c.n_nonref : 0;
+      const uint32_t ltm = c.n_ref < c.loc_m ? c.loc_m - c.n_ref : 0;
+      double local_rate;
+      if ((ltmm + ltm) == 0) local_rate = global_rate;
+      else {
+        local_rate = (double)ltmm / (double)(ltmm + ltm);
+        if (local_rate < global_rate) local_rate = global_rate;
+      }
+      if (local_rate > 0.20) continue;  // cMaxBkgdNoiseThres
+      LociPV p;
+      const int tot_bases = (int)(c.n_ref + c.n_nonref);
+      p.pvalue = 1.0 - binomial(tot_bases, (int)c.n_nonref, local_rate);
+      p.loci = c.loci; p.rank = 0; p.bkgnd = local_rate; p.local_reads = ltmm + ltm; p.local_subs = ltmm;
+      p.num_reads = (uint32_t)tot_bases; p.num_subs = c.n_nonref;
+      for (int b = 0; b < 5; b++) p.by_base[b] = c.by_base[b];
+      p.ref_base = c.ref_base > 4 ? 4 : c.ref_base;
+      pv.push_back(p);
+    }
+    if (pv.empty()) continue;
+    std::stable_sort(pv.begin(), pv.end(), [](const LociPV& x, const LociPV& y) { return x.pvalue < y.pvalue; });
+    size_t n_acc = 0;
+    for (size_t k = 0; k < pv.size(); k++) {  // Benjamini-Hochberg
+      const double adj = ((k + 1) / (double)pv.size()) * qvalue;
+      if (pv[k].pvalue >= adj) break;
+      pv[k].rank = (uint32_t)(k + 1);
+      n_acc++;
+    }
+    pv.resize(n_acc);
+    std::sort(pv.begin(), pv.end(), [](const LociPV& x, const LociPV& y) { return x.loci < y.loci; });
+    for (LociPV& p : pv) {
+      tot_snps++;
+      int rel = (int)(999 - ((999 * (int64_t)p.rank) / (int64_t)n_acc));
+      if (rel < 1) rel = 1;
+      p.by_base[p.ref_base] = p.num_reads - p.num_subs;  // :7698
+      char line[512];
+      const int n = snprintf(line, sizeof(line), "%d,\"SNP\",\"%s\",\"%s\",%d,%d,1,\"+\",%d,%f,%d,%d,\"%c\",%d,%d,%d,%d,%d,%f,%d,%d,%d,%d\n", (int)tot_snps,
+                             ix->dataset.c_str(), e.name, (int)p.loci, (int)p.loci, rel, p.pvalue, (int)p.num_reads, (int)p.num_subs, "ACGTN"[p.ref_base],
+                             (int)p.by_base[0], (int)p.by_base[1], (int)p.by_base[2], (int)p.by_base[3], (int)p.by_base[4], p.bkgnd, (int)p.local_reads,
+                             (int)p.local_subs, 0, 0);
+      text.append(line, (size_t)n);
+    }
+  }
+  char* out = (char*)malloc(text.size() + 1);
+  if (!out) return k4_fail(ix, K4_ERR_MEM, "out of memory");
+  memcpy(out, text.c_str(), text.size() + 1);
+  *csv = out;
+  *csv_bytes = text.size();
+  if (n_snps) *n_snps = tot_snps;
+  return K4_OK;
+}
+extern "C" void k4_free_host(void* p) { free(p); }

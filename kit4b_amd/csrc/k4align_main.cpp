@@ -54,6 +54,9 @@ struct Opts {
   bool legacy = false;              // -Z: the serial whole-input path of round 1 (one batch, no overlap), kept for comparison
   int chunk_mb = 256;               // -B <MB>: size of one pinned upload buffer of the pipeline
   int io_threads = 8;               // -t <n>: concurrent pread / pwrite calls per buffer; BAM: deflate threads
+  int min_snp_reads = 0;            // -p <n> (0: no SNP calling), -P <qvalue>, -1 <pct>, -S <file> (KAlignerCL.cpp:259,284-291,877-932)
+  double qvalue = 0.0, snp_nonref_pcnt = 25.0;
+  std::string snp_file;
   int bam_level = 6;                // -z <0..9>: BGZF deflate level of a .bam output (WriteBAMReadHits is called with 6, KAligner.cpp:759)
 };
 
@@ -376,7 +379,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam|out.bam [-z bgzf level=6] [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
 }  // namespace
@@ -670,6 +673,20 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     s_parse = secs(tr, now()) - s_read;  // what the device side added behind the reading
     auto tg = now();
     CK(global_stages(v.n_units, v.max_read_len, v.d_rr, v.d_hits, v.d_seg2, v.d_pe, v.d_reads, v.d_offs, v.d_lens));
+    if (o.min_snp_reads > 0) {  // ProcessSNPs (KAligner.cpp:768-790 calls it behind the alignment report): the main SNP CSV
+      char* csv = nullptr;
+      uint64_t nb = 0, ns = 0;
+      auto ts = now();
+      CK(k4_snp_csv_dev(ix, pe ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_reads, v.d_offs, v.d_lens, o.min_snp_reads, o.qvalue,
+                        o.snp_nonref_pcnt, &csv, &nb, &ns, nullptr));
+      FILE* sf = fopen(o.snp_file.c_str(), "wb");
+      const bool okw = sf && fwrite(csv, 1, nb, sf) == nb;
+      if (sf && fclose(sf) != 0) { k4_free_host(csv); fprintf(stderr, "k4align: write to %s failed\n", o.snp_file.c_str()); return 5; }
+      k4_free_host(csv);
+      if (!okw) { fprintf(stderr, "k4align: unable to write %s\n", o.snp_file.c_str()); return 5; }
+      if (chatty) fprintf(stderr, "k4align: SNP processing completed with %llu putative SNPs discovered, written to %s in %.2fs\n", (unsigned long long)ns,
+                          o.snp_file.c_str(), secs(ts, now()));
+    }
     if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= 10000 ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
     else CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     s_align = secs(tg, now());
@@ -953,9 +970,20 @@ int main(int argc, char** argv) {
       case 'a': o.micro_indel = atoi(val().c_str()); break;
       case 'A': o.splice_junct = atoi(val().c_str()); break;
       case 'x': o.min_flank_exacts = atoi(val().c_str()); break;
+      case 'p': o.min_snp_reads = atoi(val().c_str()); break;
+      case 'P': o.qvalue = atof(val().c_str()); break;
+      case '1': o.snp_nonref_pcnt = atof(val().c_str()); break;
       case 'X': o.clamp = true; break;
       case 'N': o.best = true; break;
-      case 'S': { std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2) { usage(); return 1; } break; }
+      case 'S': {  // "i/N": this process's slice of the reads; anything else: kalign's -S, the SNP file
+        std::string v = val();
+        int sa = 0, sb = 0;
+        char tail = 0;
+        if (sscanf(v.c_str(), "%d/%d%c", &sa, &sb, &tail) == 2) { o.shard = sa; o.n_shards = sb; }
+        else if (v.empty()) { usage(); return 1; }
+        else o.snp_file = v;
+        break;
+      }
       case 'g': o.gpu = atoi(val().c_str()); break;
       case 'G': { std::string v = val(); for (size_t q = 0; q < v.size();) { size_t e = v.find(',', q); if (e == std::string::npos) e = v.size(); o.gpus.push_back(atoi(v.substr(q, e - q).c_str())); q = e + 1; } break; }
       case 'b': o.batch_mb = atof(val().c_str()); break;
@@ -1008,6 +1036,17 @@ int main(int argc, char** argv) {
   if (pe && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDel '-a' / splice junction '-A' processing not supported in paired end processing\n"); return 1; }
   if (o.ml_mode == 5 && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDels / splice junctions not supported when reporting multiloci alignments '-r5'\n"); return 1; }
   if (o.min_chimeric && (o.best || o.ml_mode == 3 || o.ml_mode == 4)) { fprintf(stderr, "k4align: chimeric read processing cannot be combined with -N / -r3 / -r4\n"); return 1; }
+  // SNP calling (KAlignerCL.cpp:877-945): -S alone means -p20; -p alone writes <out>.snp; -P defaults to 0.05
+  if (!o.snp_file.empty() && o.min_snp_reads == 0) o.min_snp_reads = 20;
+  if (o.min_snp_reads != 0 && (o.min_snp_reads < 1 || o.min_snp_reads > 100)) { fprintf(stderr, "k4align: minimum read coverage at any loci '-p%d' must be in range 1..100\n", o.min_snp_reads); return 1; }
+  if (o.min_snp_reads > 0) {
+    if (o.snp_file.empty()) o.snp_file = o.out + ".snp";
+    if (o.qvalue < 0.0 || o.qvalue > 0.40) { fprintf(stderr, "k4align: QValue '-P%1.5f' for controlling SNP FDR (Benjamini-Hochberg) must be in range 0.0 to 0.4\n", o.qvalue); return 1; }
+    if (o.qvalue == 0.0) o.qvalue = 0.05;
+    if (o.snp_nonref_pcnt < 0.1 || o.snp_nonref_pcnt > 35.0) { fprintf(stderr, "k4align: SNP minimum non-ref '-1%f' must be in range 0.1 to 35.0\n", o.snp_nonref_pcnt); return 1; }
+    if (o.ml_mode == 5) { fprintf(stderr, "k4align: SNP processing is not supported when reporting all multiloci alignments '-r5'\n"); return 1; }
+    if (o.batch_mb > 0 || o.n_shards > 1 || !o.gpus.empty() || o.legacy) { fprintf(stderr, "k4align: SNP calling runs over the whole run's alignments: not with -b, -S i/N, -G, -Z\n"); return 3; }
+  }
   if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830
   if (o.min_flank_exacts > 7) o.min_flank_exacts = 7;
   if (pe && o.pe_mode == 0) o.pe_mode = 1;  // kalign: -u without -U defaults to orphan recovery
