@@ -72,10 +72,12 @@ ix.close()
 del seq, sa, reads
 torch.cuda.empty_cache()
 
+SNP = os.environ.get("K4_REF_SNP") == "1"  # both programs also call SNPs (-S): the CSV files are compared
 BAM = os.environ.get("K4_REF_BAM") == "1"  # both programs write BAM (+ .bai); the decoded records are compared
 ref_sam, ref_log = os.path.join(tmp, "ref.bam" if BAM else "ref.sam"), os.path.join(tmp, "ref.log")
 t0 = time.time()
-r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log] + subs + extra + in_args, capture_output=True)
+ref_snp, gpu_snp = os.path.join(tmp, "ref.snp.csv"), os.path.join(tmp, "gpu.snp.csv")
+r = subprocess.run([NGS, "kalign", "-I", sfx, "-o", ref_sam, "-T", str(threads), "-F", ref_log] + subs + extra + (["-S", ref_snp] if SNP else []) + in_args, capture_output=True)
 t_ref = time.time() - t0
 print("reference rc", r.returncode, "wall %.1fs" % t_ref, flush=True)
 log = open(ref_log, errors="replace").read() if os.path.exists(ref_log) else ""
@@ -84,7 +86,7 @@ print("\n".join(keep[-40:]), flush=True)
 
 gpu_sam = os.path.join(tmp, "gpu.bam" if BAM else "gpu.sam")
 t0 = time.time()
-g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam] + subs + extra + k4_extra + in_args, capture_output=True, text=True)
+g = subprocess.run([K4ALIGN, "-I", sfx, "-o", gpu_sam] + subs + extra + k4_extra + (["-S", gpu_snp] if SNP else []) + in_args, capture_output=True, text=True)
 t_gpu = time.time() - t0
 print("k4align rc", g.returncode, "wall %.1fs" % t_gpu)
 print(g.stderr[-1500:], flush=True)
@@ -127,6 +129,13 @@ same_set = sorted(rr) == sorted(rg)
 out = {"format": "BAM" if BAM else "SAM", "extra_args": extra, "k4align_extra_args": k4_extra, "repeat_copies": n_rep, "reads": n_reads * (2 if pe_mode else 1), "pe_mode": pe_mode, "read_len": L, "genome_bp": n_chrom * chrom_len, "threads": threads, "reference_wall_s": t_ref, "k4align_wall_s": t_gpu,
        "reference_sam_records": len(rr), "k4align_sam_records": len(rg), "headers_equal": same_hdr,
        "records_equal_as_multiset": same_set, "records_equal_in_order": same_order}
+if SNP:
+    a, b = open(ref_snp).read().splitlines(), open(gpu_snp).read().splitlines()
+    strip = lambda ln: ",".join(f for k, f in enumerate(ln.split(",")) if k != 8)  # noqa: E731  (column 8 = Rank)
+    out["snp_lines_reference"] = len(a) - 1
+    out["snp_lines_k4align"] = len(b) - 1
+    out["snp_files_identical"] = a == b
+    out["snp_files_identical_but_rank"] = [strip(x) for x in a] == [strip(x) for x in b]
 if dropin:
     hd, rd = body(dropin[0])
     out["dropin_threads"] = dropin_threads
@@ -136,5 +145,5 @@ if dropin:
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"summary": out, "reference_log_tail": keep[-40:], "k4align_stderr": g.stderr[-3000:]},
-          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep > 0 else "_stress" if n_rep < 0 else "") + ("_" + "".join(extra).replace("-", "") if extra else "") + ("_bam" if BAM else ""))), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep > 0 else "_stress" if n_rep < 0 else "") + ("_" + "".join(extra).replace("-", "") if extra else "") + ("_bam" if BAM else "") + ("_snp" if SNP else ""))), "w"), indent=1)
 shutil.rmtree(tmp, ignore_errors=True)
