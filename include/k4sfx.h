@@ -385,6 +385,11 @@ int k4_format_bam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, c
 int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml, const void* d_pe,
                    const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads, double qvalue,
                    double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream);
+/* ... as VCF 4.1 (what kalign writes when the SNP file's name ends in .vcf): ALT = the alleles with at least a tenth of the strongest
+ * one's count, AF per allele, QUAL = phred of the p-value capped at 100, DP = coverage */
+int k4_snp_vcf_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml, const void* d_pe,
+                   const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads, double qvalue,
+                   double snp_nonref_pcnt, char** vcf, uint64_t* vcf_bytes, uint64_t* n_snps, void* stream);
 void k4_free_host(void* p);
 /* k4_select_hits_dev <- MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962) after k4_kalign_batch_dev with pe_mode 2: every accepted
  * read keeps ONE instance, hits[choice[i] % NumHits] moved to slot 0, NumHits = 1.  d_choice: uint32 per read, the caller's

@@ -155,9 +155,25 @@ struct LociPV {
 
 }  // namespace
 
+static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                        const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
+                        double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream);
 extern "C" int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                               const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
                               double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream) {
+  return snp_text_dev(ix, 0, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, min_snp_reads, qvalue, snp_nonref_pcnt, csv, csv_bytes,
+                      n_snps, stream);
+}
+// the VCF form (kalign: a SNP file name ending in .vcf, KAligner.cpp:186-187; header :8196-8199, records :7650-7696)
+extern "C" int k4_snp_vcf_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                              const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
+                              double qvalue, double snp_nonref_pcnt, char** vcf, uint64_t* vcf_bytes, uint64_t* n_snps, void* stream) {
+  return snp_text_dev(ix, 1, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, min_snp_reads, qvalue, snp_nonref_pcnt, vcf, vcf_bytes,
+                      n_snps, stream);
+}
+static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                        const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
+                        double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream) {
   if (!ix || !csv || !csv_bytes) return K4_ERR_PARAMS;
   *csv = nullptr;
   *csv_bytes = 0;
@@ -170,6 +186,10 @@ extern "C" int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void*
   std::string text =
       "\"SNP_ID\",\"ElType\",\"Species\",\"Chrom\",\"StartLoci\",\"EndLoci\",\"Len\",\"Strand\",\"Rank\",\"PValue\",\"Bases\",\"Mismatches\",\"RefBase\","
       "\"MMBaseA\",\"MMBaseC\",\"MMBaseG\",\"MMBaseT\",\"MMBaseN\",\"BackgroundSubRate\",\"TotWinBases\",\"TotWinMismatches\",\"MarkerID\",\"NumPolymorphicSites\"\n";
+  if (vcf)
+    text = "##fileformat=VCFv4.1\n##source=k4align1.0\n##reference=" + ix->dataset +
+           "\n##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele Frequency\">\n##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Read Depth\">\n"
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
   SnpArgs a;
   memset(&a, 0, sizeof(a));
   a.ix = ix->d; a.pe = pe ? 1 : 0; a.n_reads = pe ? 2 * n_units : n_units;
@@ -193,6 +213,7 @@ extern "C" int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void*
   const double nonref_frac = snp_nonref_pcnt / 100.0;  // m_SNPNonRefPcnt, KAligner.cpp:256
   std::vector<Cand> hc;
   std::vector<LociPV> pv;
+  char alts[100] = "", freq[100] = "";  // VCF: ALT and AF of the last SNP that had any (see below)
   for (uint32_t chrom = 1; chrom <= ix->d.n_entries && a.n_reads > 0; chrom++) {  // the sorted reads: one chromosome after the other
     const k4_entry& e = ix->entries[chrom - 1];
     a.chrom_id = chrom; a.clen = e.seq_len; a.cnt = cnt.as<uint32_t>(); a.tot = tot.as<unsigned long long>();
@@ -260,8 +281,27 @@ extern "C" int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void*
       tot_snps++;
       int rel = (int)(999 - ((999 * (int64_t)p.rank) / (int64_t)n_acc));
       if (rel < 1) rel = 1;
-      p.by_base[p.ref_base] = p.num_reads - p.num_subs;  // :7698
       char line[512];
+      if (vcf) {  // alternative alleles with at least a tenth of the strongest one's count, their frequencies, phred of the p-value
+        uint32_t thres = 0;
+        for (uint32_t b = 0; b < 4; b++)
+          if (b != p.ref_base && p.by_base[b] > thres) thres = p.by_base[b];
+        thres = std::max((thres + 5) / 10, 1u);
+        // (the reference never clears its two strings: a SNP whose mismatches are all N prints what the SNP before it left there)
+        int ao = 0, fo = 0;
+        for (uint32_t b = 0; b < 4; b++) {
+          if (b == p.ref_base || p.by_base[b] < thres) continue;
+          if (ao > 0) { alts[ao++] = ','; freq[fo++] = ','; }
+          alts[ao++] = "ACGT"[b]; alts[ao] = 0;
+          fo += sprintf(&freq[fo], "%1.4f", (double)p.by_base[b] / p.num_reads);
+        }
+        const int phred = p.pvalue < 0.0000000001 ? 100 : (int)(0.5 + (10.0 * log10(1.0 / p.pvalue)));
+        const int n = snprintf(line, sizeof(line), "%s\t%u\tSNP%d\t%c\t%s\t%d\tPASS\tAF=%s;DP=%d\n", e.name, p.loci + 1, (int)tot_snps, "ACGTN"[p.ref_base],
+                               alts, phred, freq, (int)p.num_reads);
+        text.append(line, (size_t)n);
+        continue;
+      }
+      p.by_base[p.ref_base] = p.num_reads - p.num_subs;  // :7698
       const int n = snprintf(line, sizeof(line), "%d,\"SNP\",\"%s\",\"%s\",%d,%d,1,\"+\",%d,%f,%d,%d,\"%c\",%d,%d,%d,%d,%d,%f,%d,%d,%d,%d\n", (int)tot_snps,
                              ix->dataset.c_str(), e.name, (int)p.loci, (int)p.loci, rel, p.pvalue, (int)p.num_reads, (int)p.num_subs, "ACGTN"[p.ref_base],
                              (int)p.by_base[0], (int)p.by_base[1], (int)p.by_base[2], (int)p.by_base[3], (int)p.by_base[4], p.bkgnd, (int)p.local_reads,

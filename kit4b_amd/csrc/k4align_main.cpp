@@ -677,8 +677,10 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       char* csv = nullptr;
       uint64_t nb = 0, ns = 0;
       auto ts = now();
-      CK(k4_snp_csv_dev(ix, pe ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_reads, v.d_offs, v.d_lens, o.min_snp_reads, o.qvalue,
-                        o.snp_nonref_pcnt, &csv, &nb, &ns, nullptr));
+      // a file name ending in .vcf: VCF instead of the CSV (KAligner.cpp:186-187)
+      const bool vcf = o.snp_file.size() >= 4 && strcasecmp(o.snp_file.c_str() + o.snp_file.size() - 4, ".vcf") == 0;
+      CK((vcf ? k4_snp_vcf_dev : k4_snp_csv_dev)(ix, pe ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_reads, v.d_offs, v.d_lens,
+                                                 o.min_snp_reads, o.qvalue, o.snp_nonref_pcnt, &csv, &nb, &ns, nullptr));
       FILE* sf = fopen(o.snp_file.c_str(), "wb");
       const bool okw = sf && fwrite(csv, 1, nb, sf) == nb;
       if (sf && fclose(sf) != 0) { k4_free_host(csv); fprintf(stderr, "k4align: write to %s failed\n", o.snp_file.c_str()); return 5; }

@@ -66,15 +66,27 @@ static void sb_put(sbuf* b, const char* s, size_t n) {
 
 /* nar / hits: one per read (hits[i * hit_stride] = the reported alignment).  Returns the CSV text (malloc'd; caller frees) and
  * the number of SNPs through *n_snps; NULL on bad arguments. */
+char* k4o_snp_text(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
+                   const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
+                   int64_t* n_snps);
 char* k4o_snp_csv(const k4o_index* ix, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride, const uint8_t* reads,
                   const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
                   int64_t* n_snps) {
+  return k4o_snp_text(ix, 0, n_reads, nar, hits, hit_stride, reads, offs, lens, min_snp_reads, qvalue, snp_nonref_pcnt, n_snps);
+}
+/* vcf: the VCF form (file name ending in .vcf, KAligner.cpp:186-187; lines :7650-7696) -- the records only: the reference's header
+ * names its own version and the path of the index file */
+char* k4o_snp_text(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
+                   const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
+                   int64_t* n_snps) {
   if (!ix || n_reads < 0 || min_snp_reads < 1) return NULL;
   const double nonref_frac = snp_nonref_pcnt / 100.0; /* m_SNPNonRefPcnt, KAligner.cpp:256 */
   sbuf out = {0, 0, 0};
   const char* hdr = "\"SNP_ID\",\"ElType\",\"Species\",\"Chrom\",\"StartLoci\",\"EndLoci\",\"Len\",\"Strand\",\"Rank\",\"PValue\",\"Bases\",\"Mismatches\",\"RefBase\",\"MMBaseA\",\"MMBaseC\",\"MMBaseG\",\"MMBaseT\",\"MMBaseN\",\"BackgroundSubRate\",\"TotWinBases\",\"TotWinMismatches\",\"MarkerID\",\"NumPolymorphicSites\"\n";
-  sb_put(&out, hdr, strlen(hdr));
+  if (!vcf) sb_put(&out, hdr, strlen(hdr));
+  else sb_put(&out, "", 0);
   int64_t tot_snps = 0;
+  char alts[100] = "", freq[100] = "";
   uint8_t* rs = (uint8_t*)malloc(1 << 16);
   for (uint32_t chrom = 1; chrom <= ix->n_entries; chrom++) { /* the reads come sorted: one chromosome after the other (:8340-8400) */
     const k4o_entry* e = &ix->entries[chrom - 1];
@@ -163,8 +175,29 @@ char* k4o_snp_csv(const k4o_index* ix, int64_t n_reads, const int32_t* nar, cons
         tot_snps++;
         int rel = (int)(999 - ((999 * (int64_t)p->rank) / (int64_t)n_acc));
         if (rel < 1) rel = 1;
-        p->c.by_base[p->c.ref_base] = p->num_reads - p->num_subs; /* :7698 */
         char line[512];
+        if (vcf) { /* :7650-7696 */
+          uint32_t thres = 0;
+          for (int b = 0; b < 4; b++)
+            if (b != p->c.ref_base && p->c.by_base[b] > thres) thres = p->c.by_base[b];
+          thres = (thres + 5) / 10;
+          if (thres < 1) thres = 1;
+          /* (szALTs / szAltFreq are locals of the loop body that nothing clears: a SNP whose mismatches are all N -- no allele
+           * reaches the threshold -- prints what the SNP before it left there; kept, :7652-7683) */
+          int ao = 0, fo = 0;
+          for (int b = 0; b < 4; b++) {
+            if (b == p->c.ref_base || p->c.by_base[b] < thres) continue;
+            if (ao > 0) { alts[ao++] = ','; freq[fo++] = ','; }
+            alts[ao++] = "ACGT"[b]; alts[ao] = 0;
+            fo += sprintf(&freq[fo], "%1.4f", (double)p->c.by_base[b] / p->num_reads);
+          }
+          const int phred = p->pvalue < 0.0000000001 ? 100 : (int)(0.5 + (10.0 * log10(1.0 / p->pvalue)));
+          const int n = snprintf(line, sizeof(line), "%s\t%u\tSNP%d\t%c\t%s\t%d\tPASS\tAF=%s;DP=%d\n", e->name, p->loci + 1, (int)tot_snps,
+                                 "ACGTN"[p->c.ref_base > 4 ? 4 : p->c.ref_base], alts, phred, freq, (int)p->num_reads);
+          sb_put(&out, line, (size_t)n);
+          continue;
+        }
+        p->c.by_base[p->c.ref_base] = p->num_reads - p->num_subs; /* :7698 */
         const int n = snprintf(line, sizeof(line), "%d,\"SNP\",\"%s\",\"%s\",%d,%d,1,\"+\",%d,%f,%d,%d,\"%c\",%d,%d,%d,%d,%d,%f,%d,%d,%d,%d\n",
                                (int)tot_snps, ix->dataset, e->name, (int)p->loci, (int)p->loci, rel, p->pvalue, (int)p->num_reads, (int)p->num_subs,
                                "ACGTN"[p->c.ref_base > 4 ? 4 : p->c.ref_base], (int)p->c.by_base[0], (int)p->c.by_base[1], (int)p->c.by_base[2],

@@ -66,6 +66,11 @@ def main():
                 g.write(f.read())
             text = open(csv).read()
             open(os.path.join(HERE, name + ".csv"), "w").write(text)
+            if name != "snp_se":  # the same calls as VCF (a SNP file name ending in .vcf)
+                vcf = os.path.join(tmp, name + ".vcf")
+                subprocess.run([NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", sam, "-T", "4", "-F", os.path.join(tmp, name + ".log"),
+                                "-S", vcf] + c["args"] + files, check=True, capture_output=True, timeout=600)
+                open(os.path.join(HERE, name + ".vcf"), "w").write(open(vcf).read())
             meta[name] = dict(args=c["args"], snps=len(text.splitlines()) - 1)
             print(name, meta[name])
     json.dump(meta, open(os.path.join(HERE, "snp_cases.json"), "w"), indent=1, sort_keys=True)

@@ -288,19 +288,20 @@ class Oracle:
                                            hit.ctypes.data)
         return r, hit[0]
 
-    def snp_csv(self, h, reads, nar, hits, min_snp_reads=5, qvalue=0.05, snp_nonref_pcnt=25.0):
-        """kalign's SNP calling over one reported alignment per read (hits: [n] or [n, max_ml] records): (CSV text, number of SNPs)"""
+    def snp_csv(self, h, reads, nar, hits, min_snp_reads=5, qvalue=0.05, snp_nonref_pcnt=25.0, vcf=False):
+        """kalign's SNP calling over one reported alignment per read (hits: [n] or [n, max_ml] records): (CSV text, number of SNPs);
+        vcf=True: the records of the VCF form"""
         cat, offs, lens = reads if isinstance(reads, tuple) else flatten_reads(reads)
         hits = np.ascontiguousarray(hits)
         stride = 1 if hits.ndim == 1 else hits.shape[1]
         nar = np.ascontiguousarray(nar, dtype=np.int32)
-        self.L.k4o_snp_csv.restype = C.c_void_p
-        self.L.k4o_snp_csv.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                       C.c_double, C.c_double, C.POINTER(C.c_int64)]
+        self.L.k4o_snp_text.restype = C.c_void_p
+        self.L.k4o_snp_text.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int64)]
         self.L.k4o_free.argtypes = [C.c_void_p]
         n = C.c_int64(0)
-        p = self.L.k4o_snp_csv(h, len(lens), nar.ctypes.data, hits.ctypes.data, stride, cat.ctypes.data, offs.ctypes.data, lens.ctypes.data,
-                               min_snp_reads, qvalue, snp_nonref_pcnt, C.byref(n))
+        p = self.L.k4o_snp_text(h, 1 if vcf else 0, len(lens), nar.ctypes.data, hits.ctypes.data, stride, cat.ctypes.data, offs.ctypes.data,
+                                lens.ctypes.data, min_snp_reads, qvalue, snp_nonref_pcnt, C.byref(n))
         if not p:
             raise RuntimeError("k4o_snp_csv failed")
         text = C.string_at(p).decode()

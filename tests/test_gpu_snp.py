@@ -82,3 +82,20 @@ def test_snp_option_rules(golden_dir, tmp_path):
     p = subprocess.run(base + ["-p5"], capture_output=True, text=True, timeout=120)  # no alignment, no SNP: header only, default name
     assert p.returncode == 0, p.stderr
     assert open(str(tmp_path / "o.sam") + ".snp").read().count("\n") == 1
+
+
+@pytest.mark.parametrize("case", ["snp_se_c50_p8", "snp_pe_u1"])
+def test_k4align_writes_the_reference_vcf(golden_dir, tmp_path, case):
+    """`-S x.vcf`: the VCF form -- records identical to the reference's, header lines but ##source / ##reference too"""
+    def unxz(name):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        return dst
+
+    files = ["-i", unxz(case + "_1.fa.xz"), "-u", unxz(case + "_2.fa.xz")] if case.startswith("snp_pe") else ["-i", unxz(case + ".fa.xz")]
+    vcf = str(tmp_path / "o.VCF")
+    p = subprocess.run([os.path.join(ROOT, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", str(tmp_path / "o.sam"), "-S", vcf]
+                       + SNP_CASES[case]["args"] + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    keep = lambda t: [l for l in t.splitlines() if not l.startswith(("##source", "##reference"))]  # noqa: E731
+    assert keep(open(vcf).read()) == keep(open(os.path.join(golden_dir, case + ".vcf")).read())

@@ -76,3 +76,15 @@ def test_snp_csv_matches_the_reference(oracle, golden_dir, case):
     # ranks: identical where p-values are distinct; within a group of equal printed p-values the same multiset
     assert sorted(got_ranks) == sorted(want_ranks)
     oracle.close(h)
+
+
+@pytest.mark.parametrize("case", ["snp_se_c50_p8", "snp_pe_u1"])
+def test_snp_vcf_records_match_the_reference(oracle, golden_dir, case):
+    """the same calls in kalign's VCF form (`-S x.vcf`): records identical; the header lines name the writer's version and the index"""
+    h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    oracle.set_max_iter(h, 5000)
+    reads, nar, hits = aligned_inputs(oracle, h, case)
+    text, n = oracle.snp_csv(h, reads, nar, hits, vcf=True, **snp_args(SNP_CASES[case]["args"]))
+    want = [l for l in open(os.path.join(golden_dir, case + ".vcf")).read().splitlines() if not l.startswith("#")]
+    assert text.splitlines() == want and n == len(want) == SNP_CASES[case]["snps"]
+    oracle.close(h)
