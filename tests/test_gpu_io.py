@@ -526,3 +526,23 @@ def test_k4align_writes_the_reference_bam(golden_dir, tmp_path, case, level):
     p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", sfx, "-o", out, "-b", "1"] + cases[case]["args"] + files,
                        capture_output=True, text=True, timeout=60)
     assert p.returncode == 3 and "BAM output" in p.stderr
+
+
+def test_k4align_bam_and_snp_outputs_of_a_run_without_alignments(golden_dir, tmp_path):
+    """nothing aligns: the BAM holds header, dictionary and the end-of-file block, the .bai lists empty references, the SNP file its header"""
+    import subprocess
+
+    import samutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa = tmp_path / "r.fa"
+    rng = np.random.default_rng(3)
+    fa.write_text("".join(">x%d\n%s\n" % (i, "".join("ACGT"[b] for b in rng.integers(0, 4, 100))) for i in range(40)))
+    out = str(tmp_path / "o.bam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-s0", "-p5", "-i", str(fa)],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    text, refs, recs = samutil.read_bam(out)
+    assert recs == [] and len(refs) == 5 and text.startswith("@HD")
+    assert len(samutil.read_bai(out + ".bai")) == 5
+    assert open(out + ".snp").read().count("\n") == 1

@@ -765,7 +765,7 @@ def test_c5_scale_15gbp_se_and_pe_truth(k4):
         ix.close()
 
 
-@pytest.mark.parametrize("case", ["se_s2", "pe_u1", "se_r5_R8_N", "se_r5_R6_X"])
+@pytest.mark.parametrize("case", ["se_s2", "pe_u1", "se_r5_R8_N", "se_r5_R6_X", "pe_c50_u1", "pe_c60_u3_wide"])
 def test_reference_sam_on_5byte_index_with_64bit_table(k4, golden_dir, g1_el5_path, monkeypatch, case):
     """The same golden SAMs through the layouts a >= 2^32-symbol block uses: 5-byte suffix elements and (forced) 64-bit
     k-mer table fields -- the EL=5 / 64-bit instantiations of the step, general, pairing and rescue kernels."""

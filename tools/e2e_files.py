@@ -58,7 +58,7 @@ print("reads written (%.1f GB) in %.1fs" % (os.path.getsize(fq) / 1e9, time.time
 res = {"workload": "C2: %d x 100 bp FASTQ reads (%.1f GB) vs 3 Gbp .sfx (%.1f GB), files in tmpfs, kalign -s2" % (n_reads, os.path.getsize(fq) / 1e9, os.path.getsize(sfx) / 1e9)}
 exe = os.path.join(ROOT, "kit4b_amd", "k4align")
 sams = {}
-for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r01", ["-Z"]), ("bam_z6_t16", ["-t", "16"]), ("bam_z1_t16", ["-t", "16", "-z", "1"])):
+for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r01", ["-Z"]), ("bam_z6_t16", ["-t", "16"]), ("bam_z1_t16", ["-t", "16", "-z", "1"]), ("snp_p5", ["-p", "5"])):
     sam = os.path.join(tmp, tag + (".bam" if tag.startswith("bam") else ".sam"))
     t0 = time.time()
     p = subprocess.run([exe, "-I", sfx, "-i", fq, "-o", sam, "-s2"] + extra, capture_output=True, text=True)
@@ -71,7 +71,13 @@ for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r0
         res[tag]["Mreads_s_excl_index_load"] = n_reads / (wall - float(m.group(1))) / 1e6
         res[tag]["Mreads_s_wall"] = n_reads / wall / 1e6
     print(tag, json.dumps(res[tag]), flush=True)
-    if tag.startswith("bam"):
+    if tag.startswith("snp"):
+        snp_line = [l for l in p.stderr.splitlines() if "putative SNPs" in l]
+        res[tag]["snp_report"] = snp_line[-1] if snp_line else None
+        for f in (sam, sam + ".snp"):
+            if os.path.exists(f):
+                os.remove(f)
+    elif tag.startswith("bam"):
         res[tag]["bai_MB"] = os.path.getsize(sam + ".bai") / 1e6 if os.path.exists(sam + ".bai") else None
         for f in (sam, sam + ".bai"):
             if os.path.exists(f):
