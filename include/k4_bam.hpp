@@ -77,6 +77,11 @@ class Writer {
     fp_ = fopen(path.c_str(), "wb");
     if (!fp_) return fail("cannot create " + path);
     idx_.assign(refs.size(), RefIndex());
+    // BAI bins address 2^29 bases per sequence (the reference switches to a CSI index above that, SAMfile.cpp:1697-1712: not
+    // built here): such a dictionary gets the BAM without an index file
+    index_ok_ = true;
+    for (const RefSeq& r : refs)
+      if (r.len >= (1u << 29)) index_ok_ = false;
     std::vector<uint8_t> h;
     const char magic[4] = {'B', 'A', 'M', 1};
     h.insert(h.end(), magic, magic + 4);
@@ -105,9 +110,10 @@ class Writer {
     if (fclose(fp_) != 0) { fp_ = nullptr; return fail("close failed: " + path_); }
     fp_ = nullptr;
     if (carry_.size() || need_) return fail("truncated record at the end of the BAM stream");
-    return write_index();
+    return index_ok_ ? write_index() : true;
   }
   uint64_t n_records() const { return n_rec_; }
+  bool indexed() const { return index_ok_; }  // false: a sequence of 512 Mbp or more (no .bai written)
   const std::string& path() const { return path_; }
   uint64_t compressed_bytes() const { return coff_; }
 
@@ -234,6 +240,7 @@ class Writer {
   }
 
   void add_to_index(const Rec& r) {
+    if (!index_ok_) return;
     if (r.ref < 0 || (size_t)r.ref >= idx_.size() || r.pos < 0) return;
     RefIndex& x = idx_[(size_t)r.ref];
     const uint64_t vb = voffset(r.ubeg), ve = voffset(r.uend);
@@ -284,6 +291,7 @@ class Writer {
   std::string path_, err_;
   FILE* fp_ = nullptr;
   int level_ = 6, threads_ = 1;
+  bool index_ok_ = true;
   std::vector<RefSeq> refs_;
   std::vector<RefIndex> idx_;
   std::vector<uint8_t> pend_;                 // uncompressed bytes not yet in a block

@@ -774,6 +774,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       if (!bw.write(ptr, (size_t)len)) { fprintf(stderr, "k4align: %s\n", bw.error().c_str()); return 5; }
     }
     if (!bw.close()) { fprintf(stderr, "k4align: %s\n", bw.error().c_str()); return 5; }
+    if (!bw.indexed() && chatty) fprintf(stderr, "k4align: a sequence of 512 Mbp or more: no .bai written (the reference writes a CSI index there)\n");
     if (bw.n_records() != my_lines) { fprintf(stderr, "k4align: internal error: %llu BAM records for %llu alignments\n", (unsigned long long)bw.n_records(), (unsigned long long)my_lines); return 5; }
     k4_pipeline_close(pl);
     const double s_write_bam = secs(tw, now());
