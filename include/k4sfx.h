@@ -390,6 +390,13 @@ int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, cons
 int k4_snp_vcf_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml, const void* d_pe,
                    const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads, double qvalue,
                    double snp_nonref_pcnt, char** vcf, uint64_t* vcf_bytes, uint64_t* n_snps, void* stream);
+/* both files of a kalign SNP run: the SNP file (vcf == 0: CSV) and the coverage WIG kalign writes beside it (<snp file minus its
+ * extension>.covsegs.wig: variableStep spans of roughly equal coverage, AccumWIGCnts / CompleteWIGSpan KAligner.cpp:6993-7085;
+ * walked on host threads, one per chromosome, while the device piles up the next ones) */
+int k4_snp_files_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                     const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads, double qvalue,
+                     double snp_nonref_pcnt, char** snp, uint64_t* snp_bytes, uint64_t* n_snps, char** wig, uint64_t* wig_bytes,
+                     void* stream);
 void k4_free_host(void* p);
 /* k4_select_hits_dev <- MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962) after k4_kalign_batch_dev with pe_mode 2: every accepted
  * read keeps ONE instance, hits[choice[i] % NumHits] moved to slot 0, NumHits = 1.  d_choice: uint32 per read, the caller's

@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <future>
+#include <memory>
 #include <string>
 #include <vector>
 #include <hip/hip_runtime.h>
@@ -114,6 +116,56 @@ __global__ void __launch_bounds__(256) k4k_snp_candidates(SnpArgs a, const uint6
   out[slot] = c;
 }
 
+// coverage per locus (TotBases) for the WIG: ref + nonref
+__global__ void __launch_bounds__(256) k4k_snp_coverage(const uint32_t* __restrict__ ref, const uint32_t* __restrict__ non, uint32_t n,
+                                                        uint32_t* __restrict__ cov) {
+  const uint32_t l = blockIdx.x * 256u + threadIdx.x;
+  if (l < n) cov[l] = ref[l] + non[l];
+}
+
+// The coverage WIG kalign writes beside the SNP file: variableStep spans of roughly equal coverage (AccumWIGCnts / CompleteWIGSpan,
+// KAligner.cpp:6993-7085), fed with the locus counted from 0 (:7375) -- so a span that starts at locus 0 is never written.  The
+// walk is sequential by nature (where a span ends depends on its running mean): one host thread per chromosome, running while the
+// device piles up the next chromosomes.  Returns the text of the chromosome's closed spans; `tail` = what closing the last open
+// span adds (the reference does that only for chromosomes with at least one candidate locus, :7582-7608 / :8135).
+struct WigOut { std::string body, tail; };
+static WigOut wig_chromosome(std::unique_ptr<uint32_t[]> cov, uint32_t clen, std::string name) {
+  WigOut o;
+  uint32_t loci = 0, len = 0, rptd_len = 0;
+  bool started = false, rptd = false;  // m_WIGChromID != 0, m_WIGRptdChromID == this chromosome
+  uint64_t cnts = 0;
+  char line[160];
+  auto complete = [&](std::string& dst) {
+    if (started && len > 0 && loci > 0 && cnts > 0) {
+      if (!rptd || len != rptd_len) {
+        dst.append(line, (size_t)snprintf(line, sizeof(line), "variableStep chrom=%s span=%d\n", name.c_str(), (int)len));
+        rptd = true; rptd_len = len;
+      }
+      dst.append(line, (size_t)snprintf(line, sizeof(line), "%d %d\n", (int)loci, (int)(uint32_t)((cnts + len - 1) / len)));
+    }
+    loci = 0; len = 0; cnts = 0;
+  };
+  for (uint32_t l = 0; l < clen; l++) {
+    const uint32_t c = cov[l];
+    if (!started || len >= 100000u || c == 0) {
+      if (started) complete(o.body);
+      if (c > 0) { started = true; loci = l; len = 1; cnts = c; }
+      continue;
+    }
+    if (len == 0 || cnts == 0) { loci = l; len = 1; cnts = c; continue; }
+    const uint32_t mean100 = 100u * (uint32_t)(cnts / (uint64_t)len);
+    if ((c <= 5 && (c * 100) != mean100) || (mean100 < (c * 75) || mean100 >= (c * 125))) {
+      complete(o.body);
+      loci = l; len = 1; cnts = c;
+      continue;
+    }
+    cnts += c;
+    len = l - loci + 1;
+  }
+  complete(o.tail);
+  return o;
+}
+
 struct Buf {
   void* p = nullptr;
   ~Buf() { if (p) hipFree(p); }
@@ -157,7 +209,17 @@ struct LociPV {
 
 static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                         const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
-                        double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream);
+                        double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream,
+                        char** wig = nullptr, uint64_t* wig_bytes = nullptr);
+// both files of a kalign SNP run: the SNP file (CSV, or VCF when vcf != 0) and the coverage WIG (<snp file>.covsegs.wig)
+extern "C" int k4_snp_files_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                                const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
+                                double qvalue, double snp_nonref_pcnt, char** snp, uint64_t* snp_bytes, uint64_t* n_snps, char** wig,
+                                uint64_t* wig_bytes, void* stream) {
+  if (!wig || !wig_bytes) return K4_ERR_PARAMS;
+  return snp_text_dev(ix, vcf, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, min_snp_reads, qvalue, snp_nonref_pcnt, snp, snp_bytes,
+                      n_snps, stream, wig, wig_bytes);
+}
 extern "C" int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                               const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
                               double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream) {
@@ -173,10 +235,15 @@ extern "C" int k4_snp_vcf_dev(k4_index* ix, int pe, int64_t n_units, const void*
 }
 static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                         const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
-                        double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream) {
+                        double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream,
+                        char** wig, uint64_t* wig_bytes) {
   if (!ix || !csv || !csv_bytes) return K4_ERR_PARAMS;
   *csv = nullptr;
   *csv_bytes = 0;
+  if (wig) { *wig = nullptr; *wig_bytes = 0; }
+  struct WigJob { std::future<WigOut> f; bool close_tail; };
+  std::vector<WigJob> wig_jobs;  // one per chromosome with alignments, in chromosome order
+  Buf covb;
   if (n_snps) *n_snps = 0;
   if (n_units < 0 || min_snp_reads < 1 || qvalue < 0.0 || snp_nonref_pcnt < 0.0) return k4_fail(ix, K4_ERR_PARAMS, "SNP parameters out of range");
   if (n_units > 0 && ((pe && !d_pe) || (!pe && (!d_rr || !d_hits || max_ml < 1)) || !d_reads || !d_offs || !d_lens))
@@ -231,6 +298,17 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
     K4_HIP(ix, hipMemcpyAsync(t3, tot.p, 24, hipMemcpyDeviceToHost, st));
     K4_HIP(ix, hipStreamSynchronize(st));
     if (t3[2] == 0) continue;  // no alignment on this chromosome
+    size_t wig_slot = 0;
+    if (wig) {  // coverage down to the host, its walk on a thread of its own (at most four chromosomes in flight: 4 bytes per locus each)
+      if (!covb.p) K4_HIP(ix, covb.alloc(S * 4));
+      hipLaunchKernelGGL(k4k_snp_coverage, dim3((a.clen + 255) / 256), dim3(256), 0, st, a.cnt, a.cnt + K4_SNP_STRIDE(a), a.clen, covb.as<uint32_t>());
+      std::unique_ptr<uint32_t[]> cov(new uint32_t[(size_t)a.clen + 1]);
+      K4_HIP(ix, hipMemcpyAsync(cov.get(), covb.p, (size_t)a.clen * 4, hipMemcpyDeviceToHost, st));
+      K4_HIP(ix, hipStreamSynchronize(st));
+      if (wig_jobs.size() >= 4) wig_jobs[wig_jobs.size() - 4].f.wait();
+      wig_slot = wig_jobs.size();
+      wig_jobs.push_back({std::async(std::launch::async, wig_chromosome, std::move(cov), a.clen, std::string(e.name)), false});
+    }
     // prefix sums over [0, clen]: element l = sum of the loci below l (the arrays are zero behind clen)
     K4_HIP(ix, rocprim::exclusive_scan(tmp.p, tb, a.cnt, pref.as<uint64_t>(), (uint64_t)0, (size_t)a.clen + 1, rocprim::plus<uint64_t>(), st));
     K4_HIP(ix, rocprim::exclusive_scan(tmp.p, tb, a.cnt + Sc, pnon.as<uint64_t>(), (uint64_t)0, (size_t)a.clen + 1, rocprim::plus<uint64_t>(), st));
@@ -266,6 +344,7 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
       p.ref_base = c.ref_base > 4 ? 4 : c.ref_base;
       pv.push_back(p);
     }
+    if (wig && !pv.empty()) wig_jobs[wig_slot].close_tail = true;  // (a chromosome without a candidate never closes its last span)
     if (pv.empty()) continue;
     std::stable_sort(pv.begin(), pv.end(), [](const LociPV& x, const LociPV& y) { return x.pvalue < y.pvalue; });
     size_t n_acc = 0;
@@ -308,6 +387,19 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
                              (int)p.local_subs, 0, 0);
       text.append(line, (size_t)n);
     }
+  }
+  if (wig) {
+    std::string w = "track type=wiggle_0 name=\"Coverage\" description=\"Alignment Segment Coverage\" useScore=1\n";  // :8235
+    for (WigJob& j : wig_jobs) {
+      WigOut o = j.f.get();
+      w += o.body;
+      if (j.close_tail) w += o.tail;
+    }
+    char* wo = (char*)malloc(w.size() + 1);
+    if (!wo) return k4_fail(ix, K4_ERR_MEM, "out of memory");
+    memcpy(wo, w.c_str(), w.size() + 1);
+    *wig = wo;
+    *wig_bytes = w.size();
   }
   char* out = (char*)malloc(text.size() + 1);
   if (!out) return k4_fail(ix, K4_ERR_MEM, "out of memory");

@@ -679,8 +679,23 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       auto ts = now();
       // a file name ending in .vcf: VCF instead of the CSV (KAligner.cpp:186-187)
       const bool vcf = o.snp_file.size() >= 4 && strcasecmp(o.snp_file.c_str() + o.snp_file.size() - 4, ".vcf") == 0;
-      CK((vcf ? k4_snp_vcf_dev : k4_snp_csv_dev)(ix, pe ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_reads, v.d_offs, v.d_lens,
-                                                 o.min_snp_reads, o.qvalue, o.snp_nonref_pcnt, &csv, &nb, &ns, nullptr));
+      char* wig = nullptr;
+      uint64_t wb = 0;
+      CK(k4_snp_files_dev(ix, vcf ? 1 : 0, pe ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_reads, v.d_offs, v.d_lens, o.min_snp_reads,
+                          o.qvalue, o.snp_nonref_pcnt, &csv, &nb, &ns, &wig, &wb, nullptr));
+      {  // <snp file cut at its last '.'>.covsegs.wig (CUtility::AppendFileNameSuffix, KAligner.cpp:4512)
+        std::string wname = o.snp_file;
+        for (size_t q = wname.size(); q > 0; q--) {
+          if (wname[q - 1] == '.') { wname.resize(q - 1); break; }
+          if (wname[q - 1] == '/' || wname[q - 1] == '\\') break;
+        }
+        wname += ".covsegs.wig";
+        FILE* wf = fopen(wname.c_str(), "wb");
+        const bool okw2 = wf && fwrite(wig, 1, wb, wf) == wb;
+        if (wf) fclose(wf);
+        k4_free_host(wig);
+        if (!okw2) { k4_free_host(csv); fprintf(stderr, "k4align: unable to write %s\n", wname.c_str()); return 5; }
+      }
       FILE* sf = fopen(o.snp_file.c_str(), "wb");
       const bool okw = sf && fwrite(csv, 1, nb, sf) == nb;
       if (sf && fclose(sf) != 0) { k4_free_host(csv); fprintf(stderr, "k4align: write to %s failed\n", o.snp_file.c_str()); return 5; }

@@ -59,6 +59,41 @@ static int cmp_loci(const void* a, const void* b) { /* SortPValuesLoci :11165 */
 }
 
 typedef struct { char* p; size_t len, cap; } sbuf;
+static void sb_put(sbuf* b, const char* s, size_t n);
+/* the coverage WIG kalign writes beside the SNP file (<snp file minus extension>.covsegs.wig): variableStep spans of roughly equal
+ * coverage (AccumWIGCnts / CompleteWIGSpan, KAligner.cpp:6993-7085), fed with the LOCUS AS COUNTED FROM 0 (:7375), so a span that
+ * starts at locus 0 is never written (CompleteWIGSpan wants a start above 0) */
+typedef struct { uint32_t chrom, rptd_chrom, loci, len, rptd_len; uint64_t cnts; sbuf* out; const char* name; } wig_state;
+static void wig_complete(wig_state* w) {
+  if (w->chrom != 0 && w->len > 0 && w->loci > 0 && w->cnts > 0) {
+    char line[256];
+    if (w->chrom != w->rptd_chrom || w->len != w->rptd_len) {
+      const int n = snprintf(line, sizeof(line), "variableStep chrom=%s span=%d\n", w->name, (int)w->len);
+      sb_put(w->out, line, (size_t)n);
+      w->rptd_chrom = w->chrom; w->rptd_len = w->len;
+    }
+    const int n = snprintf(line, sizeof(line), "%d %d\n", (int)w->loci, (int)(uint32_t)((w->cnts + w->len - 1) / w->len));
+    sb_put(w->out, line, (size_t)n);
+  }
+  w->loci = 0; w->len = 0; w->cnts = 0;
+}
+static void wig_accum(wig_state* w, uint32_t chrom, uint32_t loci, uint32_t cnts) {
+  const uint32_t max_span = 100000;
+  if (chrom != w->chrom || w->len >= max_span || cnts == 0) {
+    if (w->chrom != 0) wig_complete(w);
+    if (cnts > 0) { w->chrom = chrom; w->loci = loci; w->len = 1; w->cnts = cnts; }
+    return;
+  }
+  if (w->len == 0 || w->cnts == 0) { w->loci = loci; w->len = 1; w->cnts = cnts; return; }
+  const uint32_t mean100 = 100 * (uint32_t)(w->cnts / (uint64_t)w->len);
+  if ((cnts <= 5 && (cnts * 100) != mean100) || (mean100 < (cnts * 75) || mean100 >= (cnts * 125))) {
+    wig_complete(w);
+    w->loci = loci; w->len = 1; w->cnts = cnts;
+    return;
+  }
+  w->cnts += cnts;
+  w->len = loci - w->loci + 1;
+}
 static void sb_put(sbuf* b, const char* s, size_t n) {
   if (b->len + n + 1 > b->cap) { b->cap = (b->len + n + 1) * 2 + 4096; b->p = (char*)realloc(b->p, b->cap); }
   memcpy(b->p + b->len, s, n); b->len += n; b->p[b->len] = 0;
@@ -76,9 +111,28 @@ char* k4o_snp_csv(const k4o_index* ix, int64_t n_reads, const int32_t* nar, cons
 }
 /* vcf: the VCF form (file name ending in .vcf, KAligner.cpp:186-187; lines :7650-7696) -- the records only: the reference's header
  * names its own version and the path of the index file */
+static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
+                     const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
+                     int64_t* n_snps, sbuf* wig);
 char* k4o_snp_text(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
                    const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
                    int64_t* n_snps) {
+  return snp_run(ix, vcf, n_reads, nar, hits, hit_stride, reads, offs, lens, min_snp_reads, qvalue, snp_nonref_pcnt, n_snps, NULL);
+}
+/* the coverage WIG of the same run (see wig_state above); release with k4o_free */
+char* k4o_snp_wig(const k4o_index* ix, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride, const uint8_t* reads,
+                  const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt) {
+  sbuf wig = {0, 0, 0};
+  const char* hdr = "track type=wiggle_0 name=\"Coverage\" description=\"Alignment Segment Coverage\" useScore=1\n"; /* :8235 */
+  sb_put(&wig, hdr, strlen(hdr));
+  char* t = snp_run(ix, 0, n_reads, nar, hits, hit_stride, reads, offs, lens, min_snp_reads, qvalue, snp_nonref_pcnt, NULL, &wig);
+  if (!t) { free(wig.p); return NULL; }
+  free(t);
+  return wig.p;
+}
+static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
+                     const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
+                     int64_t* n_snps, sbuf* wig) {
   if (!ix || n_reads < 0 || min_snp_reads < 1) return NULL;
   const double nonref_frac = snp_nonref_pcnt / 100.0; /* m_SNPNonRefPcnt, KAligner.cpp:256 */
   sbuf out = {0, 0, 0};
@@ -132,8 +186,10 @@ char* k4o_snp_text(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t*
     for (uint32_t l = 0; l < (win < clen ? win : clen); l++, win_r++) { loc_mm += win_r->nonref; loc_m += win_r->ref; }
     loci_pv* pv = NULL;
     size_t n_pv = 0, cap_pv = 0;
+    wig_state ws = {0, 0, 0, 0, 0, 0, wig, e->name}; /* InitialiseWIGSpan, :7347 */
     for (uint32_t l = 0; l < clen; l++) {
       const snp_cnts* s = cnt + l;
+      if (wig) wig_accum(&ws, chrom, l, s->nonref + s->ref); /* :7375, before any test */
       if (l > flank && (l + flank) < clen) { /* :7358-7374 slide the window */
         loc_mm = loc_mm >= win_l->nonref ? loc_mm - win_l->nonref : 0;
         loc_m = loc_m >= win_l->ref ? loc_m - win_l->ref : 0;
@@ -160,6 +216,8 @@ char* k4o_snp_text(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t*
       p->loci = l; p->rank = 0; p->bkgnd = local_rate; p->local_reads = ltmm + ltm; p->local_subs = ltmm;
       p->num_reads = (uint32_t)tot_bases; p->num_subs = s->nonref; p->c = *s;
     }
+    /* a chromosome without a single candidate returns early (:7582-7608): its last open span is never closed -- lost */
+    if (wig && n_pv) wig_complete(&ws); /* CompleteWIGSpan(true), :8135 */
     if (n_pv) {
       qsort(pv, n_pv, sizeof(loci_pv), cmp_pv);
       size_t n_acc = 0;

@@ -66,6 +66,8 @@ def main():
                 g.write(f.read())
             text = open(csv).read()
             open(os.path.join(HERE, name + ".csv"), "w").write(text)
+            with open(os.path.join(tmp, name + ".covsegs.wig"), "rb") as f, lzma.open(os.path.join(HERE, name + ".covsegs.wig.xz"), "wb", preset=9) as g:
+                g.write(f.read())  # the coverage WIG kalign writes beside the SNP file
             if name != "snp_se":  # the same calls as VCF (a SNP file name ending in .vcf)
                 vcf = os.path.join(tmp, name + ".vcf")
                 subprocess.run([NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", sam, "-T", "4", "-F", os.path.join(tmp, name + ".log"),

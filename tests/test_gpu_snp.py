@@ -61,6 +61,8 @@ def test_k4align_writes_the_reference_snp_file(golden_dir, tmp_path, case):
     assert p.returncode == 0, p.stderr
     assert open(snp).read() == open(os.path.join(golden_dir, case + ".csv")).read()
     assert ("with %d putative SNPs discovered" % SNP_CASES[case]["snps"]) in p.stderr
+    # the coverage WIG beside it (<snp file minus extension>.covsegs.wig), spans walked on host threads
+    assert open(str(tmp_path / "o.covsegs.wig")).read() == lzma.open(os.path.join(golden_dir, case + ".covsegs.wig.xz")).read().decode()
     got = [l for l in open(out).read().splitlines() if not l.startswith("@")]
     want = [l for l in lzma.open(os.path.join(golden_dir, case + ".sam.xz")).read().decode().splitlines() if not l.startswith("@")]
     assert sorted(got) == sorted(want)

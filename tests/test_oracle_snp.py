@@ -88,3 +88,18 @@ def test_snp_vcf_records_match_the_reference(oracle, golden_dir, case):
     want = [l for l in open(os.path.join(golden_dir, case + ".vcf")).read().splitlines() if not l.startswith("#")]
     assert text.splitlines() == want and n == len(want) == SNP_CASES[case]["snps"]
     oracle.close(h)
+
+
+@pytest.mark.parametrize("case", sorted(SNP_CASES))
+def test_coverage_wig_matches_the_reference(oracle, golden_dir, case):
+    """<snp file>.covsegs.wig: variableStep spans of roughly equal coverage (AccumWIGCnts / CompleteWIGSpan, KAligner.cpp:6993-7085),
+    incl. what the reference loses: a span that starts at locus 0, and the last span of a chromosome without a candidate locus"""
+    import lzma
+
+    h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    oracle.set_max_iter(h, 5000)
+    reads, nar, hits = aligned_inputs(oracle, h, case)
+    text = oracle.snp_wig(h, reads, nar, hits, **snp_args(SNP_CASES[case]["args"]))
+    want = lzma.open(os.path.join(golden_dir, case + ".covsegs.wig.xz")).read().decode()
+    assert text == want
+    oracle.close(h)
