@@ -136,6 +136,10 @@ if SNP:
     out["snp_lines_k4align"] = len(b) - 1
     out["snp_files_identical"] = a == b
     out["snp_files_identical_but_rank"] = [strip(x) for x in a] == [strip(x) for x in b]
+    wr, wg = ref_snp[:-4] + ".covsegs.wig", gpu_snp[:-4] + ".covsegs.wig"
+    if os.path.exists(wr) and os.path.exists(wg):
+        out["coverage_wig_bytes"] = os.path.getsize(wr)
+        out["coverage_wig_identical"] = open(wr, "rb").read() == open(wg, "rb").read()
 if dropin:
     hd, rd = body(dropin[0])
     out["dropin_threads"] = dropin_threads
