@@ -254,6 +254,10 @@ char* k4o_snp_text(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t*
 /* the coverage WIG kalign writes beside the SNP file (.covsegs.wig; AccumWIGCnts / CompleteWIGSpan, KAligner.cpp:6993-7085) */
 char* k4o_snp_wig(const k4o_index* ix, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride, const uint8_t* reads,
                   const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt);
+/* the haplotype files kalign writes beside the SNP file (n_loci 2: .disnp.csv, 3: .trisnp.csv; KAligner.cpp:7767-8101) */
+char* k4o_snp_haplotypes(const k4o_index* ix, int n_loci, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
+                         const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue,
+                         double snp_nonref_pcnt);
 void k4o_free(void* p);
 
 /* CKAligner::AssignMultiMatches (KAligner.cpp:5092-5258) with ProcAssignMultiMatches (:4944-5085) over the results of

@@ -5,7 +5,7 @@
  *                                                            Hochberg cut, the "SNP_ID",... CSV line
  *   CStats::Binomial / ProbKeqlk / Calc_nCk  libkit4b/Stats.cpp:489-564
  *
- * Not restated (files the reference writes beside the CSV by default or on request): .covsegs.wig, .disnp.csv, .trisnp.csv, marker
+ * Not restated (files the reference writes on request): marker
  * sequences, SNP centroids, VCF / BED forms, packed base alleles, SOLiD colourspace.
  * Ranks: the reference orders the candidates by p-value with a multi-threaded quicksort (equal p-values -- most are 0 -- in no
  * defined order); here equal p-values keep locus order, which is what the reference produces on inputs small enough for its
@@ -99,6 +99,75 @@ static void sb_put(sbuf* b, const char* s, size_t n) {
   memcpy(b->p + b->len, s, n); b->len += n; b->p[b->len] = 0;
 }
 
+/* ---- DiSNPs / TriSNPs: the haplotype files kalign writes beside the SNP file (<snp file minus extension>.disnp.csv / .trisnp.csv,
+ * KAligner.cpp:4553-4554; headers :8252-8330; lines :7767-8101) --------------------------------------------------------------------
+ * For two (three) called SNP loci following each other within min(300, mean aligned length) bases: the reads that cover all of them,
+ * the base each shows at each locus, and how many reads carry each of the 16 (64) combinations. */
+typedef struct { uint32_t start, end, hit_len, match_loci, match_len; int64_t read; char strand; } hap_read;
+static int cmp_hap_read(const void* a, const void* b) { /* SortHitMatch :10969-11014 within one chromosome: AdjStartLoci, AdjHitLen, strand */
+  const hap_read* x = (const hap_read*)a; const hap_read* y = (const hap_read*)b;
+  if (x->start != y->start) return x->start < y->start ? -1 : 1;
+  if (x->hit_len != y->hit_len) return x->hit_len < y->hit_len ? -1 : 1;
+  if (x->strand != y->strand) return x->strand < y->strand ? -1 : 1;
+  return x->read < y->read ? -1 : x->read > y->read;
+}
+static int adj_align_snp_base(const hap_read* r, const uint8_t* bases, uint32_t loci) { /* AdjAlignSNPBase :1581-1632 */
+  if (r->start > loci || r->end < loci) return 7;
+  if (r->strand == '+') return bases[loci - r->match_loci] & 0x07;
+  int b = bases[r->match_loci + r->match_len - loci - 1] & 0x07;
+  return b <= 3 ? 3 - b : b;
+}
+/* IterateReadsOverlapping (:10475-10546) over the chromosome's sorted alignments: every accepted alignment without InDel / splice
+ * that starts at or before the first locus and ends at or after the last one; the walk stops at the first that starts behind the
+ * first locus.  (The reference resumes later walks from where an earlier one found its first read; the reads it skips that way can
+ * neither cover the new loci nor stop the walk, so the walk from the chromosome's first read sees the same reads.) */
+static void hap_counts(const hap_read* rd, size_t n_rd, const uint8_t* reads, const uint64_t* offs, const uint32_t* loci, int n_loci,
+                       int* cnts, int by_base[3][4], int* depth, int* antisense) {
+  memset(cnts, 0, 64 * sizeof(int)); memset(by_base, 0, 12 * sizeof(int));
+  *depth = 0; *antisense = 0;
+  for (size_t q = 0; q < n_rd; q++) {
+    const hap_read* r = &rd[q];
+    if (!(r->start <= loci[0] && r->end >= loci[n_loci - 1])) {
+      if (r->start > loci[0]) break;
+      continue;
+    }
+    int b[3], ok = 1;
+    for (int k = 0; k < n_loci && ok; k++) { b[k] = adj_align_snp_base(r, reads + offs[r->read], loci[k]); ok = b[k] <= 3; }
+    if (!ok) continue; /* an N in the read at one of the loci (:7801-7805, :7950-7957) */
+    int idx = 0;
+    for (int k = 0; k < n_loci; k++) { by_base[k][b[k]]++; idx = (idx << 2) | b[k]; }
+    cnts[idx]++; (*depth)++;
+    if (r->strand == '-') (*antisense)++;
+  }
+}
+static void hap_line(sbuf* out, const char* type, int id, const char* species, const char* chrom, const uint32_t* loci, const uint8_t* ref,
+                     int n_loci, int by_base[3][4], int depth, int antisense, int n_hap, const int* cnts) {
+  char line[1200];
+  int n = snprintf(line, sizeof(line), "%d,\"%s\",\"%s\",\"%s\",", id, type, species, chrom);
+  for (int k = 0; k < n_loci; k++)
+    n += snprintf(line + n, sizeof(line) - n, "%d,\"%c\",%d,%d,%d,%d,0,", (int)loci[k], "acgtn"[ref[k] > 4 ? 4 : ref[k]], by_base[k][0], by_base[k][1],
+                  by_base[k][2], by_base[k][3]);
+  n += snprintf(line + n, sizeof(line) - n, "%d,%d,%d", depth, antisense, n_hap);
+  for (int k = 0; k < (n_loci == 2 ? 16 : 64); k++) n += snprintf(line + n, sizeof(line) - n, ",%d", cnts[k]);
+  line[n++] = '\n';
+  sb_put(out, line, (size_t)n);
+}
+static void hap_header(sbuf* out, int n_loci) { /* :8252-8330 */
+  char line[1600];
+  int n = snprintf(line, sizeof(line), "\"%s_ID\",\"ElType\",\"Species\",\"Chrom\"", n_loci == 2 ? "DiSNPs" : "TriSNPs");
+  for (int k = 1; k <= n_loci; k++)
+    n += snprintf(line + n, sizeof(line) - n, ",\"SNP%dLoci\",\"SNP%dRefBase\",\"SNP%dBaseAcnt\",\"SNP%dBaseCcnt\",\"SNP%dBaseGcnt\",\"SNP%dBaseTcnt\",\"SNP%dBaseNcnt\"",
+                  k, k, k, k, k, k, k);
+  n += snprintf(line + n, sizeof(line) - n, ",\"Depth\",\"Antisense\",\"Haplotypes\"");
+  for (int k = 0; k < (n_loci == 2 ? 16 : 64); k++) {
+    line[n++] = ','; line[n++] = '"';
+    for (int j = n_loci - 1; j >= 0; j--) line[n++] = "acgt"[(k >> (2 * j)) & 3];
+    line[n++] = '"';
+  }
+  line[n++] = '\n';
+  sb_put(out, line, (size_t)n);
+}
+
 /* nar / hits: one per read (hits[i * hit_stride] = the reported alignment).  Returns the CSV text (malloc'd; caller frees) and
  * the number of SNPs through *n_snps; NULL on bad arguments. */
 char* k4o_snp_text(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
@@ -113,11 +182,11 @@ char* k4o_snp_csv(const k4o_index* ix, int64_t n_reads, const int32_t* nar, cons
  * names its own version and the path of the index file */
 static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
                      const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
-                     int64_t* n_snps, sbuf* wig);
+                     int64_t* n_snps, sbuf* wig, sbuf* di, sbuf* tri);
 char* k4o_snp_text(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
                    const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
                    int64_t* n_snps) {
-  return snp_run(ix, vcf, n_reads, nar, hits, hit_stride, reads, offs, lens, min_snp_reads, qvalue, snp_nonref_pcnt, n_snps, NULL);
+  return snp_run(ix, vcf, n_reads, nar, hits, hit_stride, reads, offs, lens, min_snp_reads, qvalue, snp_nonref_pcnt, n_snps, NULL, NULL, NULL);
 }
 /* the coverage WIG of the same run (see wig_state above); release with k4o_free */
 char* k4o_snp_wig(const k4o_index* ix, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride, const uint8_t* reads,
@@ -125,14 +194,27 @@ char* k4o_snp_wig(const k4o_index* ix, int64_t n_reads, const int32_t* nar, cons
   sbuf wig = {0, 0, 0};
   const char* hdr = "track type=wiggle_0 name=\"Coverage\" description=\"Alignment Segment Coverage\" useScore=1\n"; /* :8235 */
   sb_put(&wig, hdr, strlen(hdr));
-  char* t = snp_run(ix, 0, n_reads, nar, hits, hit_stride, reads, offs, lens, min_snp_reads, qvalue, snp_nonref_pcnt, NULL, &wig);
+  char* t = snp_run(ix, 0, n_reads, nar, hits, hit_stride, reads, offs, lens, min_snp_reads, qvalue, snp_nonref_pcnt, NULL, &wig, NULL, NULL);
   if (!t) { free(wig.p); return NULL; }
   free(t);
   return wig.p;
 }
+/* the haplotype file of the same run: n_loci 2 = .disnp.csv, 3 = .trisnp.csv; release with k4o_free */
+char* k4o_snp_haplotypes(const k4o_index* ix, int n_loci, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
+                         const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue,
+                         double snp_nonref_pcnt) {
+  if (n_loci != 2 && n_loci != 3) return NULL;
+  sbuf hap = {0, 0, 0};
+  hap_header(&hap, n_loci);
+  char* t = snp_run(ix, 0, n_reads, nar, hits, hit_stride, reads, offs, lens, min_snp_reads, qvalue, snp_nonref_pcnt, NULL, NULL,
+                    n_loci == 2 ? &hap : NULL, n_loci == 3 ? &hap : NULL);
+  if (!t) { free(hap.p); return NULL; }
+  free(t);
+  return hap.p;
+}
 static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_t* nar, const k4o_hit* hits, int hit_stride,
                      const uint8_t* reads, const uint64_t* offs, const uint32_t* lens, int min_snp_reads, double qvalue, double snp_nonref_pcnt,
-                     int64_t* n_snps, sbuf* wig) {
+                     int64_t* n_snps, sbuf* wig, sbuf* di, sbuf* tri) {
   if (!ix || n_reads < 0 || min_snp_reads < 1) return NULL;
   const double nonref_frac = snp_nonref_pcnt / 100.0; /* m_SNPNonRefPcnt, KAligner.cpp:256 */
   sbuf out = {0, 0, 0};
@@ -146,7 +228,9 @@ static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_
     const k4o_entry* e = &ix->entries[chrom - 1];
     const uint32_t clen = e->seq_len;
     snp_cnts* cnt = NULL;
-    uint64_t tot_match = 0, tot_mismatch = 0;
+    uint64_t tot_match = 0, tot_mismatch = 0, tot_read_len = 0, num_reads = 0;
+    hap_read* hr = NULL; /* the chromosome's alignments as IterateReadsOverlapping sees them (DiSNPs / TriSNPs only) */
+    size_t n_hr = 0, cap_hr = 0;
     for (int64_t i = 0; i < n_reads; i++) {
       if (nar[i] != K4O_NAR_ACCEPTED) continue;
       const k4o_hit* h = &hits[i * (int64_t)hit_stride];
@@ -161,6 +245,13 @@ static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_
       for (uint32_t q = 0; q < match_len; q++) rs[q] = src[q] & 0x07;
       if (h->strand == '-') k4o_revcomp(rs, (int)match_len);
       if (hit_loci + match_len > clen) { if ((match_len = clen - hit_loci) < 10) continue; }
+      tot_read_len += match_len; num_reads++; /* :8466-8467 */
+      if (di || tri) {
+        if (n_hr == cap_hr) { cap_hr = cap_hr ? cap_hr * 2 : 4096; hr = (hap_read*)realloc(hr, cap_hr * sizeof(hap_read)); }
+        hap_read* r = &hr[n_hr++];
+        r->start = hit_loci; r->end = hit_loci + match_len - 1; r->hit_len = match_len; /* AdjStartLoci / AdjEndLoci / AdjHitLen */
+        r->match_loci = h->match_loci; r->match_len = (uint32_t)h->match_len; r->read = i; r->strand = (char)h->strand;
+      }
       const uint8_t* ref = ix->seq + e->start_ofs + hit_loci;
       snp_cnts* s = cnt + hit_loci;
       for (uint32_t q = 0; q < match_len; q++, s++) { /* :8468-8557, base space */
@@ -175,7 +266,8 @@ static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_
         }
       }
     }
-    if (!cnt) continue;
+    if (!cnt) { free(hr); continue; }
+    if (hr) qsort(hr, n_hr, sizeof(hap_read), cmp_hap_read);
     /* ---- OutputSNPs for this chromosome --------------------------------------------------------------------------------- */
     double global_rate = (double)tot_mismatch / (double)(1 + tot_match + tot_mismatch);
     if (global_rate < 0.005) global_rate = 0.005; /* cMinSeqErrRate */
@@ -228,9 +320,39 @@ static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_
         n_acc++;
       }
       qsort(pv, n_acc, sizeof(loci_pv), cmp_loci);
+      const int mean_len = (int)(uint32_t)((tot_read_len + num_reads - 1) / num_reads);
+      const int max_sep = mean_len < 300 ? mean_len : 300; /* m_MaxDiSNPSep = min(cDfltMaxDiSNPSep, MeanReadLen), :7346 */
+      int prev_di = -1, prev_tri = -1, first_tri = -1, tot_di = 0, tot_tri = 0; /* :7627-7635: the ids restart with every chromosome */
       for (size_t k = 0; k < n_acc; k++) {
         loci_pv* p = &pv[k];
         tot_snps++;
+        if (di || tri) { /* :7767-8101; after the SNP's own line in the reference, but into files of their own */
+          const int cur = (int)p->loci;
+          int cnts[64], by_base[3][4], depth, anti, n_hap;
+          if (di && prev_di != -1 && cur > 0 && (cur - prev_di) <= max_sep) {
+            const uint32_t l2[2] = {(uint32_t)prev_di, (uint32_t)cur};
+            const uint8_t r2[2] = {cnt[prev_di].ref_base, cnt[cur].ref_base};
+            hap_counts(hr, n_hr, reads, offs, l2, 2, cnts, by_base, &depth, &anti);
+            n_hap = 0;
+            if (depth >= min_snp_reads) {
+              const int thres = (depth + 5) / 10 > 5 ? (depth + 5) / 10 : 5;
+              for (int q = 0; q < 16; q++) { if (cnts[q] >= thres) n_hap++; else cnts[q] = 0; }
+            }
+            if (n_hap >= 2) hap_line(di, "DiSNPs", ++tot_di, ix->dataset, e->name, l2, r2, 2, by_base, depth, anti, n_hap, cnts);
+          }
+          if (tri && first_tri != -1 && prev_tri > 0 && cur > 0 && (cur - first_tri) <= max_sep) {
+            const uint32_t l3[3] = {(uint32_t)first_tri, (uint32_t)prev_tri, (uint32_t)cur};
+            const uint8_t r3[3] = {cnt[first_tri].ref_base, cnt[prev_tri].ref_base, cnt[cur].ref_base};
+            hap_counts(hr, n_hr, reads, offs, l3, 3, cnts, by_base, &depth, &anti);
+            n_hap = 0;
+            if (depth >= min_snp_reads) {
+              const int thres = (depth + 5) / 10 > 5 ? (depth + 5) / 10 : 5;
+              for (int q = 0; q < 64; q++) { if (cnts[q] >= thres) n_hap++; else cnts[q] = 0; }
+            }
+            if (n_hap >= 3) hap_line(tri, "TriSNPs", ++tot_tri, ix->dataset, e->name, l3, r3, 3, by_base, depth, anti, n_hap, cnts);
+          }
+          prev_di = cur; first_tri = prev_tri; prev_tri = cur;
+        }
         int rel = (int)(999 - ((999 * (int64_t)p->rank) / (int64_t)n_acc));
         if (rel < 1) rel = 1;
         char line[512];
@@ -265,6 +387,7 @@ static char* snp_run(const k4o_index* ix, int vcf, int64_t n_reads, const int32_
     }
     free(pv);
     free(cnt);
+    free(hr);
   }
   free(rs);
   if (n_snps) *n_snps = tot_snps;

@@ -326,6 +326,24 @@ class Oracle:
         self.L.k4o_free(p)
         return text
 
+    def snp_haplotypes(self, h, n_loci, reads, nar, hits, min_snp_reads=5, qvalue=0.05, snp_nonref_pcnt=25.0):
+        """the haplotype file kalign writes beside the SNP file: n_loci 2 = .disnp.csv, 3 = .trisnp.csv (text)"""
+        cat, offs, lens = reads if isinstance(reads, tuple) else flatten_reads(reads)
+        hits = np.ascontiguousarray(hits)
+        stride = 1 if hits.ndim == 1 else hits.shape[1]
+        nar = np.ascontiguousarray(nar, dtype=np.int32)
+        self.L.k4o_snp_haplotypes.restype = C.c_void_p
+        self.L.k4o_snp_haplotypes.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_double, C.c_double]
+        self.L.k4o_free.argtypes = [C.c_void_p]
+        p = self.L.k4o_snp_haplotypes(h, n_loci, len(lens), nar.ctypes.data, hits.ctypes.data, stride, cat.ctypes.data, offs.ctypes.data,
+                                      lens.ctypes.data, min_snp_reads, qvalue, snp_nonref_pcnt)
+        if not p:
+            raise RuntimeError("k4o_snp_haplotypes failed")
+        text = C.string_at(p).decode()
+        self.L.k4o_free(p)
+        return text
+
     def adaptive_trim(self, probe, targ, min_trim_len, max_mm, min_flank=3):
         """CSfxArray::AdaptiveTrim -> (return value, TrimSeqLen, TrimStart, TrimEnd, TrimMMs)"""
         probe = np.ascontiguousarray(probe, dtype=np.uint8)

@@ -103,3 +103,20 @@ def test_coverage_wig_matches_the_reference(oracle, golden_dir, case):
     want = lzma.open(os.path.join(golden_dir, case + ".covsegs.wig.xz")).read().decode()
     assert text == want
     oracle.close(h)
+
+
+@pytest.mark.parametrize("case", sorted(SNP_CASES))
+@pytest.mark.parametrize("n_loci", [2, 3])
+def test_haplotype_files_match_the_reference(oracle, golden_dir, case, n_loci):
+    """<snp file>.disnp.csv / .trisnp.csv (KAligner.cpp:7767-8101): two / three called SNP loci within min(300, mean aligned length)
+    bases, the reads covering all of them and the count of each base combination -- byte for byte (the *_hap cases fill them; the
+    others hold the header alone)"""
+    h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    oracle.set_max_iter(h, 5000)
+    reads, nar, hits = aligned_inputs(oracle, h, case)
+    text = oracle.snp_haplotypes(h, n_loci, reads, nar, hits, **snp_args(SNP_CASES[case]["args"]))
+    want = open(os.path.join(golden_dir, case + (".disnp.csv" if n_loci == 2 else ".trisnp.csv"))).read()
+    assert text == want
+    if case.endswith("_hap") or "_hap_" in case:
+        assert len(want.splitlines()) > 50
+    oracle.close(h)
