@@ -397,6 +397,19 @@ int k4_snp_files_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void*
                      const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads, double qvalue,
                      double snp_nonref_pcnt, char** snp, uint64_t* snp_bytes, uint64_t* n_snps, char** wig, uint64_t* wig_bytes,
                      void* stream);
+/* every file of a kalign SNP run: the two above and the haplotype files kalign writes beside them (<snp file minus its extension>
+ * .disnp.csv / .trisnp.csv, KAligner.cpp:4553-4554, header :8252-8330, lines :7767-8101: two / three called loci following each
+ * other within min(300, mean aligned length) bases, the alignments covering all of them (IterateReadsOverlapping :10475-10546)
+ * and how many show each base combination (AdjAlignSNPBase :1581-1632)).  Each text is malloc'd: release with k4_free_host. */
+typedef struct k4_snp_files {
+  char* snp;    uint64_t snp_bytes;  uint64_t n_snps;
+  char* wig;    uint64_t wig_bytes;
+  char* disnp;  uint64_t disnp_bytes;
+  char* trisnp; uint64_t trisnp_bytes;
+} k4_snp_files;
+int k4_snp_run_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                   const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads, double qvalue,
+                   double snp_nonref_pcnt, k4_snp_files* out, void* stream);
 void k4_free_host(void* p);
 /* k4_select_hits_dev <- MLMode eMLrand (`-r2`, KAligner.cpp:9945-9962) after k4_kalign_batch_dev with pe_mode 2: every accepted
  * read keeps ONE instance, hits[choice[i] % NumHits] moved to slot 0, NumHits = 1.  d_choice: uint32 per read, the caller's

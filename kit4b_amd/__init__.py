@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
-    "k4_get_kernel_times", "k4_snp_csv_dev", "k4_snp_vcf_dev", "k4_snp_files_dev", "k4_free_host", "k4_format_bam_dev", "k4_pipeline_format_bam", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
+    "k4_get_kernel_times", "k4_snp_csv_dev", "k4_snp_vcf_dev", "k4_snp_files_dev", "k4_snp_run_dev", "k4_free_host", "k4_format_bam_dev", "k4_pipeline_format_bam", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
     "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
     "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",
@@ -576,6 +576,40 @@ class SfxIndex:
         text = C.string_at(csv.value, nb.value).decode()
         L.k4_free_host(csv)
         return text, ns.value
+
+    def snp_files(self, reads, out=None, hits=None, pe_recs=None, min_snp_reads=5, qvalue=0.05, snp_nonref_pcnt=25.0, vcf=False):
+        """every file of a kalign SNP run (k4_snp_run_dev) over host-side results, as a dict of texts: "snp" (CSV, or VCF), "wig"
+        (.covsegs.wig), "disnp" (.disnp.csv), "trisnp" (.trisnp.csv), and "n_snps"."""
+        import torch
+
+        class SnpFiles(C.Structure):
+            _fields_ = [("snp", C.c_void_p), ("snp_bytes", C.c_uint64), ("n_snps", C.c_uint64), ("wig", C.c_void_p), ("wig_bytes", C.c_uint64),
+                        ("disnp", C.c_void_p), ("disnp_bytes", C.c_uint64), ("trisnp", C.c_void_p), ("trisnp_bytes", C.c_uint64)]
+
+        dev = torch.device("cuda", self.info()["device"])
+        cat, offs, lens = _flatten(reads)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
+        d_reads = torch.from_numpy(np.concatenate([cat, np.zeros(16, np.uint8)])).to(dev)
+        d_offs, d_lens = t(offs), t(lens)
+        L = lib()
+        L.k4_snp_run_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_double, C.c_double, C.POINTER(SnpFiles), C.c_void_p]
+        L.k4_free_host.argtypes = [C.c_void_p]
+        f = SnpFiles()
+        if pe_recs is not None:
+            d_pe = t(pe_recs)
+            self._ck(L.k4_snp_run_dev(self.h, 1 if vcf else 0, 1, len(lens) // 2, None, None, 1, d_pe.data_ptr(), d_reads.data_ptr(), d_offs.data_ptr(),
+                                      d_lens.data_ptr(), min_snp_reads, qvalue, snp_nonref_pcnt, C.byref(f), 0))
+        else:
+            d_rr, d_hits = t(out), t(hits)
+            max_ml = 1 if hits.ndim == 1 else hits.shape[1]
+            self._ck(L.k4_snp_run_dev(self.h, 1 if vcf else 0, 0, len(lens), d_rr.data_ptr(), d_hits.data_ptr(), max_ml, None, d_reads.data_ptr(),
+                                      d_offs.data_ptr(), d_lens.data_ptr(), min_snp_reads, qvalue, snp_nonref_pcnt, C.byref(f), 0))
+        res = {"n_snps": f.n_snps}
+        for k in ("snp", "wig", "disnp", "trisnp"):
+            res[k] = C.string_at(getattr(f, k), getattr(f, k + "_bytes")).decode()
+            L.k4_free_host(getattr(f, k))
+        return res
 
     def post_stages(self, reads, out, hits, seg2, min_flank_exacts=0, orphan_splice=False, orphan_indel=False):
         """AutoTrimFlanks / RemoveOrphanSpliceJuncts / RemoveOrphanMicroInDels (KAligner.cpp:653-686) over host arrays of SE

@@ -375,8 +375,6 @@ extern "C" int k4_mate_rescue_batch(k4_index* ix, int64_t n, const k4_rescue_tas
   hipMemcpyAsync(hits, d_h, (size_t)n * sizeof(k4_hit), hipMemcpyDeviceToHost, st);
   int rc = k4_check_hip(ix, hipStreamSynchronize(st), "mate rescue");
   if (rc != K4_OK) return rc;
-  for (int64_t i = 0; i < n; i++)
-
   return K4_OK;
 }
 

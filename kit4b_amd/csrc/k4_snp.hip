@@ -9,8 +9,9 @@
 // two prefix sums and one kernel that evaluates the window sums and the integer / proportion tests at every locus and appends the
 // few loci that pass.  Host (this file, plain C++): error rates, p-values, ranks and text for those loci -- a few hundred per
 // chromosome -- with the reference's own floating-point operations in its order (long double n-choose-k included).
-// Not built: the side files kalign writes with the CSV (.covsegs.wig, .disnp.csv, .trisnp.csv), marker sequences, centroids,
-// VCF / BED forms, packed base alleles.  Equal p-values keep locus order in the ranking (the reference's multi-threaded quicksort
+// The files kalign writes beside it: the coverage WIG (host threads, one per chromosome) and the DiSNP / TriSNP haplotype files
+// (:7767-8101; one thread per alignment finds the called loci it covers and counts its base combination for every run of two /
+// three of them).  Not built: marker sequences, centroids, the BED form, packed base alleles.  Equal p-values keep locus order in the ranking (the reference's multi-threaded quicksort
 // leaves them in no defined order).
 #include <math.h>
 #include <stdint.h>
@@ -42,7 +43,7 @@ struct SnpArgs {
   uint64_t cs;       // concat offset of the chromosome
   uint32_t clen;
   uint32_t* cnt;     // seven arrays of clen + 16: ref, nonref, A, C, G, T, N
-  unsigned long long* tot;  // [0] TotMatch [1] TotMismatch [2] reads piled up
+  unsigned long long* tot;  // [0] TotMatch [1] TotMismatch [2] reads piled up [3] their aligned bases
 };
 #define K4_SNP_STRIDE(a) ((size_t)(a).clen + 16)
 
@@ -50,7 +51,7 @@ struct SnpArgs {
 __global__ void __launch_bounds__(256) k4k_snp_pileup(SnpArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
-  unsigned long long m = 0, mm = 0, nr = 0;
+  unsigned long long m = 0, mm = 0, nr = 0, nb = 0;
   for (int64_t i = wave0; i < a.n_reads; i += n_waves) {
     const int nar = a.pe ? a.pr[i].nar : a.rr[i].nar;
     if (nar != K4_NAR_ACCEPTED) continue;
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(256) k4k_snp_pileup(SnpArgs a) {
     const uint32_t loci0 = h.match_loci + (h.strand == '+' ? tl : tr);   // AdjStartLoci
     if ((uint64_t)loci0 + match_len > a.clen) continue;                  // (GetSeq comes back short: the read is skipped, :8420)
     const uint8_t* src = a.reads + a.offs[i] + tl;
-    if (lane == 0) nr++;
+    if (lane == 0) { nr++; nb += match_len; }
     for (uint32_t q = lane; q < match_len; q += 64) {
       const uint32_t ref = k4d_ref_base(a.ix, a.cs + loci0 + q);
       uint32_t r = h.strand == '+' ? (src[q] & 7u) : (src[match_len - 1 - q] & 7u);
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) k4k_snp_pileup(SnpArgs a) {
   if (lane == 0) {
     if (m) atomicAdd(&a.tot[0], m);
     if (mm) atomicAdd(&a.tot[1], mm);
-    if (nr) atomicAdd(&a.tot[2], nr);
+    if (nr) { atomicAdd(&a.tot[2], nr); atomicAdd(&a.tot[3], nb); }
   }
 }
 
@@ -121,6 +122,105 @@ __global__ void __launch_bounds__(256) k4k_snp_coverage(const uint32_t* __restri
                                                         uint32_t* __restrict__ cov) {
   const uint32_t l = blockIdx.x * 256u + threadIdx.x;
   if (l < n) cov[l] = ref[l] + non[l];
+}
+
+// DiSNPs / TriSNPs (OutputSNPs :7767-8101 with IterateReadsOverlapping :10475-10546 and AdjAlignSNPBase :1581-1632): for two / three
+// called loci following each other closely, the alignments that cover all of them and the bases they show there.  The reference
+// walks the sorted alignments once per locus pair; here every alignment looks up the called loci inside its span (they are sorted)
+// and adds itself to the pair ending at each of them (slot from the host: -1 = loci too far apart) -- 16 combination counters + the
+// antisense count per pair, 64 + 1 per triple.
+struct HapArgs {
+  const uint32_t* loci;     // called SNP loci of the chromosome, ascending
+  const int32_t* di_slot;   // per locus k: slot of the pair (k-1, k), or -1
+  const int32_t* tri_slot;  // per locus k: slot of the triple (k-2, k-1, k), or -1
+  uint32_t n_loci;
+  uint32_t* di;             // [n_di][17]
+  uint32_t* tri;            // [n_tri][65]
+};
+__global__ void __launch_bounds__(256) k4k_snp_haplotypes(SnpArgs a, HapArgs hp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_reads; i += (int64_t)gridDim.x * 256) {
+    const int nar = a.pe ? a.pr[i].nar : a.rr[i].nar;
+    if (nar != K4_NAR_ACCEPTED) continue;
+    const k4_hit h = a.pe ? a.pr[i].hit : a.hits[i * a.max_ml];
+    if (h.chrom_id != a.chrom_id || (h.ext & (K4_EXT_INDEL | K4_EXT_SPLICE))) continue;
+    const uint32_t tl = K4_HIT_TRIM_LEFT(h), tr = K4_HIT_TRIM_RIGHT(h);
+    const uint32_t match_len = (uint32_t)h.match_len - tl - tr;
+    const uint32_t start = h.match_loci + (h.strand == '+' ? tl : tr);  // AdjStartLoci .. AdjEndLoci
+    if (match_len == 0 || (uint64_t)start + match_len > a.clen) continue;
+    const uint32_t end = start + match_len - 1;
+    uint32_t lo = 0, hi = hp.n_loci;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (hp.loci[mid] < start) lo = mid + 1; else hi = mid;
+    }
+    const uint8_t* bases = a.reads + a.offs[i];
+    const bool anti = h.strand != '+';
+    uint32_t b1 = 7, b2 = 7;  // the read's bases at the two loci before this one
+    for (uint32_t k = lo; k < hp.n_loci; k++) {
+      const uint32_t l = hp.loci[k];
+      if (l > end) break;
+      uint32_t b = anti ? (bases[h.match_loci + (uint32_t)h.match_len - l - 1] & 7u) : (bases[l - h.match_loci] & 7u);
+      if (anti && b <= 3) b = 3 - b;
+      if (k >= lo + 1 && b <= 3 && b1 <= 3) {
+        const int32_t sd = hp.di_slot[k];
+        if (sd >= 0) {
+          atomicAdd(&hp.di[(size_t)sd * 17 + ((b1 << 2) | b)], 1u);
+          if (anti) atomicAdd(&hp.di[(size_t)sd * 17 + 16], 1u);
+        }
+        if (k >= lo + 2 && b2 <= 3) {
+          const int32_t st = hp.tri_slot[k];
+          if (st >= 0) {
+            atomicAdd(&hp.tri[(size_t)st * 65 + ((b2 << 4) | (b1 << 2) | b)], 1u);
+            if (anti) atomicAdd(&hp.tri[(size_t)st * 65 + 64], 1u);
+          }
+        }
+      }
+      b2 = b1; b1 = b;
+    }
+  }
+}
+
+// one line of the .disnp.csv / .trisnp.csv file (:7836-7916, :7997-8089) from a slot's counters; false = not reported (too few
+// reads or haplotypes).  A combination counts as a haplotype from max(5, a tenth of the covering reads) reads on.
+static bool hap_line(std::string& out, const char* type, int id, const std::string& species, const char* chrom, const uint32_t* loci,
+                     const uint32_t* ref, int n, const uint32_t* c, int min_snp_reads) {
+  const int nc = n == 2 ? 16 : 64;
+  int by_base[3][4] = {{0}}, depth = 0, cnts[64];
+  for (int q = 0; q < nc; q++) {
+    cnts[q] = (int)c[q];
+    depth += cnts[q];
+    for (int k = 0; k < n; k++) by_base[k][(q >> (2 * (n - 1 - k))) & 3] += cnts[q];
+  }
+  if (depth < min_snp_reads) return false;
+  const int thres = std::max(5, (depth + 5) / 10);
+  int n_hap = 0;
+  for (int q = 0; q < nc; q++) { if (cnts[q] >= thres) n_hap++; else cnts[q] = 0; }
+  if (n_hap < n) return false;
+  char line[1200];
+  int m = snprintf(line, sizeof(line), "%d,\"%s\",\"%s\",\"%s\",", id, type, species.c_str(), chrom);
+  for (int k = 0; k < n; k++)
+    m += snprintf(line + m, sizeof(line) - m, "%d,\"%c\",%d,%d,%d,%d,0,", (int)loci[k], "acgtn"[ref[k] > 4 ? 4 : ref[k]], by_base[k][0], by_base[k][1],
+                  by_base[k][2], by_base[k][3]);
+  m += snprintf(line + m, sizeof(line) - m, "%d,%d,%d", depth, (int)c[nc], n_hap);
+  for (int q = 0; q < nc; q++) m += snprintf(line + m, sizeof(line) - m, ",%d", cnts[q]);
+  line[m++] = '\n';
+  out.append(line, (size_t)m);
+  return true;
+}
+static std::string hap_header(int n) {  // :8252-8330
+  std::string s = n == 2 ? "\"DiSNPs_ID\"" : "\"TriSNPs_ID\"";
+  s += ",\"ElType\",\"Species\",\"Chrom\"";
+  for (int k = 1; k <= n; k++) {
+    const std::string p = "\"SNP" + std::to_string(k);
+    s += "," + p + "Loci\"," + p + "RefBase\"," + p + "BaseAcnt\"," + p + "BaseCcnt\"," + p + "BaseGcnt\"," + p + "BaseTcnt\"," + p + "BaseNcnt\"";
+  }
+  s += ",\"Depth\",\"Antisense\",\"Haplotypes\"";
+  for (int q = 0; q < (n == 2 ? 16 : 64); q++) {
+    s += ",\"";
+    for (int j = n - 1; j >= 0; j--) s += "acgt"[(q >> (2 * j)) & 3];
+    s += "\"";
+  }
+  return s + "\n";
 }
 
 // The coverage WIG kalign writes beside the SNP file: variableStep spans of roughly equal coverage (AccumWIGCnts / CompleteWIGSpan,
@@ -210,7 +310,7 @@ struct LociPV {
 static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                         const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
                         double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream,
-                        char** wig = nullptr, uint64_t* wig_bytes = nullptr);
+                        char** wig = nullptr, uint64_t* wig_bytes = nullptr, std::string* di_text = nullptr, std::string* tri_text = nullptr);
 // both files of a kalign SNP run: the SNP file (CSV, or VCF when vcf != 0) and the coverage WIG (<snp file>.covsegs.wig)
 extern "C" int k4_snp_files_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                                 const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
@@ -219,6 +319,30 @@ extern "C" int k4_snp_files_dev(k4_index* ix, int vcf, int pe, int64_t n_units, 
   if (!wig || !wig_bytes) return K4_ERR_PARAMS;
   return snp_text_dev(ix, vcf, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, min_snp_reads, qvalue, snp_nonref_pcnt, snp, snp_bytes,
                       n_snps, stream, wig, wig_bytes);
+}
+// every file of a kalign SNP run: the SNP file, the coverage WIG and the two haplotype files (.disnp.csv, .trisnp.csv)
+extern "C" int k4_snp_run_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                              const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
+                              double qvalue, double snp_nonref_pcnt, k4_snp_files* out, void* stream) {
+  if (!out) return K4_ERR_PARAMS;
+  memset(out, 0, sizeof(*out));
+  std::string di = hap_header(2), tri = hap_header(3);
+  int rc = snp_text_dev(ix, vcf, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_reads, d_offs, d_lens, min_snp_reads, qvalue, snp_nonref_pcnt, &out->snp,
+                        &out->snp_bytes, &out->n_snps, stream, &out->wig, &out->wig_bytes, &di, &tri);
+  if (rc == K4_OK) {
+    out->disnp = (char*)malloc(di.size() + 1);
+    out->trisnp = (char*)malloc(tri.size() + 1);
+    if (!out->disnp || !out->trisnp) rc = k4_fail(ix, K4_ERR_MEM, "out of memory");
+    else {
+      memcpy(out->disnp, di.c_str(), di.size() + 1); out->disnp_bytes = di.size();
+      memcpy(out->trisnp, tri.c_str(), tri.size() + 1); out->trisnp_bytes = tri.size();
+    }
+  }
+  if (rc != K4_OK) {
+    free(out->snp); free(out->wig); free(out->disnp); free(out->trisnp);
+    memset(out, 0, sizeof(*out));
+  }
+  return rc;
 }
 extern "C" int k4_snp_csv_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                               const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
@@ -236,7 +360,7 @@ extern "C" int k4_snp_vcf_dev(k4_index* ix, int pe, int64_t n_units, const void*
 static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                         const void* d_pe, const void* d_reads, const void* d_offs, const void* d_lens, int32_t min_snp_reads,
                         double qvalue, double snp_nonref_pcnt, char** csv, uint64_t* csv_bytes, uint64_t* n_snps, void* stream,
-                        char** wig, uint64_t* wig_bytes) {
+                        char** wig, uint64_t* wig_bytes, std::string* di_text, std::string* tri_text) {
   if (!ix || !csv || !csv_bytes) return K4_ERR_PARAMS;
   *csv = nullptr;
   *csv_bytes = 0;
@@ -268,7 +392,7 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
   Buf cnt, tot, pref, pnon, cands, ncand, tmp;
   const uint32_t cap = 1u << 22;  // candidate loci per chromosome kept on the device (more: the call fails loudly)
   K4_HIP(ix, cnt.alloc(7 * S * 4));
-  K4_HIP(ix, tot.alloc(3 * 8));
+  K4_HIP(ix, tot.alloc(4 * 8));
   K4_HIP(ix, pref.alloc((S + 1) * 8));
   K4_HIP(ix, pnon.alloc((S + 1) * 8));
   K4_HIP(ix, cands.alloc((size_t)cap * sizeof(Cand)));
@@ -291,11 +415,11 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
     }
     const size_t Sc = K4_SNP_STRIDE(a);
     K4_HIP(ix, hipMemsetAsync(cnt.p, 0, 7 * Sc * 4, st));
-    K4_HIP(ix, hipMemsetAsync(tot.p, 0, 24, st));
+    K4_HIP(ix, hipMemsetAsync(tot.p, 0, 32, st));
     K4_HIP(ix, hipMemsetAsync(ncand.p, 0, 4, st));
     hipLaunchKernelGGL(k4k_snp_pileup, dim3(2048), dim3(256), 0, st, a);
-    unsigned long long t3[3] = {0, 0, 0};
-    K4_HIP(ix, hipMemcpyAsync(t3, tot.p, 24, hipMemcpyDeviceToHost, st));
+    unsigned long long t3[4] = {0, 0, 0, 0};
+    K4_HIP(ix, hipMemcpyAsync(t3, tot.p, 32, hipMemcpyDeviceToHost, st));
     K4_HIP(ix, hipStreamSynchronize(st));
     if (t3[2] == 0) continue;  // no alignment on this chromosome
     size_t wig_slot = 0;
@@ -356,6 +480,50 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
     }
     pv.resize(n_acc);
     std::sort(pv.begin(), pv.end(), [](const LociPV& x, const LociPV& y) { return x.loci < y.loci; });
+    if ((di_text || tri_text) && n_acc >= 2) {  // ---- DiSNPs / TriSNPs of this chromosome (:7767-8101) ------------------------------
+      const int mean_len = (int)(uint32_t)((t3[3] + t3[2] - 1) / t3[2]);
+      const int max_sep = std::min(300, mean_len);  // m_MaxDiSNPSep = min(cDfltMaxDiSNPSep, MeanReadLen), :7346
+      std::vector<uint32_t> loci(n_acc);
+      std::vector<int32_t> slot(2 * n_acc, -1);  // [0, n_acc): pair ending at k, [n_acc, 2 n_acc): triple ending at k
+      uint32_t n_di = 0, n_tri = 0;
+      for (size_t k = 0; k < n_acc; k++) {
+        loci[k] = pv[k].loci;
+        const int cur = (int)pv[k].loci;
+        if (k >= 1 && cur > 0 && cur - (int)pv[k - 1].loci <= max_sep) slot[k] = (int32_t)n_di++;
+        if (k >= 2 && pv[k - 1].loci > 0 && cur > 0 && cur - (int)pv[k - 2].loci <= max_sep) slot[n_acc + k] = (int32_t)n_tri++;
+      }
+      if (n_di) {  // (a triple holds two pairs: no pair, no triple)
+        Buf dl, ds, dd, dt;
+        K4_HIP(ix, dl.alloc(n_acc * 4));
+        K4_HIP(ix, ds.alloc(2 * n_acc * 4));
+        K4_HIP(ix, dd.alloc((size_t)n_di * 17 * 4));
+        K4_HIP(ix, dt.alloc((size_t)n_tri * 65 * 4));
+        K4_HIP(ix, hipMemcpyAsync(dl.p, loci.data(), n_acc * 4, hipMemcpyHostToDevice, st));
+        K4_HIP(ix, hipMemcpyAsync(ds.p, slot.data(), 2 * n_acc * 4, hipMemcpyHostToDevice, st));
+        K4_HIP(ix, hipMemsetAsync(dd.p, 0, (size_t)n_di * 17 * 4, st));
+        if (n_tri) K4_HIP(ix, hipMemsetAsync(dt.p, 0, (size_t)n_tri * 65 * 4, st));
+        HapArgs hp;
+        hp.loci = dl.as<uint32_t>(); hp.di_slot = ds.as<int32_t>(); hp.tri_slot = ds.as<int32_t>() + n_acc; hp.n_loci = (uint32_t)n_acc;
+        hp.di = dd.as<uint32_t>(); hp.tri = dt.as<uint32_t>();
+        const int64_t nb = std::min<int64_t>((a.n_reads + 255) / 256, 8192);
+        hipLaunchKernelGGL(k4k_snp_haplotypes, dim3((unsigned)nb), dim3(256), 0, st, a, hp);
+        std::vector<uint32_t> hd((size_t)n_di * 17), ht((size_t)n_tri * 65);
+        K4_HIP(ix, hipMemcpyAsync(hd.data(), dd.p, hd.size() * 4, hipMemcpyDeviceToHost, st));
+        if (n_tri) K4_HIP(ix, hipMemcpyAsync(ht.data(), dt.p, ht.size() * 4, hipMemcpyDeviceToHost, st));
+        K4_HIP(ix, hipStreamSynchronize(st));
+        int tot_di = 0, tot_tri = 0;  // (the ids restart with every chromosome, :7634-7635)
+        for (size_t k = 1; k < n_acc; k++) {
+          if (di_text && slot[k] >= 0) {
+            const uint32_t l2[2] = {pv[k - 1].loci, pv[k].loci}, r2[2] = {pv[k - 1].ref_base, pv[k].ref_base};
+            if (hap_line(*di_text, "DiSNPs", tot_di + 1, ix->dataset, e.name, l2, r2, 2, &hd[(size_t)slot[k] * 17], min_snp_reads)) tot_di++;
+          }
+          if (tri_text && k >= 2 && slot[n_acc + k] >= 0) {
+            const uint32_t l3[3] = {pv[k - 2].loci, pv[k - 1].loci, pv[k].loci}, r3[3] = {pv[k - 2].ref_base, pv[k - 1].ref_base, pv[k].ref_base};
+            if (hap_line(*tri_text, "TriSNPs", tot_tri + 1, ix->dataset, e.name, l3, r3, 3, &ht[(size_t)slot[n_acc + k] * 65], min_snp_reads)) tot_tri++;
+          }
+        }
+      }
+    }
     for (LociPV& p : pv) {
       tot_snps++;
       int rel = (int)(999 - ((999 * (int64_t)p.rank) / (int64_t)n_acc));

@@ -673,36 +673,34 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     s_parse = secs(tr, now()) - s_read;  // what the device side added behind the reading
     auto tg = now();
     CK(global_stages(v.n_units, v.max_read_len, v.d_rr, v.d_hits, v.d_seg2, v.d_pe, v.d_reads, v.d_offs, v.d_lens));
-    if (o.min_snp_reads > 0) {  // ProcessSNPs (KAligner.cpp:768-790 calls it behind the alignment report): the main SNP CSV
-      char* csv = nullptr;
-      uint64_t nb = 0, ns = 0;
+    if (o.min_snp_reads > 0) {  // ProcessSNPs (KAligner.cpp:768-790 calls it behind the alignment report): the SNP file and its side files
       auto ts = now();
       // a file name ending in .vcf: VCF instead of the CSV (KAligner.cpp:186-187)
       const bool vcf = o.snp_file.size() >= 4 && strcasecmp(o.snp_file.c_str() + o.snp_file.size() - 4, ".vcf") == 0;
-      char* wig = nullptr;
-      uint64_t wb = 0;
-      CK(k4_snp_files_dev(ix, vcf ? 1 : 0, pe ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_reads, v.d_offs, v.d_lens, o.min_snp_reads,
-                          o.qvalue, o.snp_nonref_pcnt, &csv, &nb, &ns, &wig, &wb, nullptr));
-      {  // <snp file cut at its last '.'>.covsegs.wig (CUtility::AppendFileNameSuffix, KAligner.cpp:4512)
-        std::string wname = o.snp_file;
-        for (size_t q = wname.size(); q > 0; q--) {
-          if (wname[q - 1] == '.') { wname.resize(q - 1); break; }
-          if (wname[q - 1] == '/' || wname[q - 1] == '\\') break;
-        }
-        wname += ".covsegs.wig";
-        FILE* wf = fopen(wname.c_str(), "wb");
-        const bool okw2 = wf && fwrite(wig, 1, wb, wf) == wb;
-        if (wf) fclose(wf);
-        k4_free_host(wig);
-        if (!okw2) { k4_free_host(csv); fprintf(stderr, "k4align: unable to write %s\n", wname.c_str()); return 5; }
+      k4_snp_files sf;
+      CK(k4_snp_run_dev(ix, vcf ? 1 : 0, pe ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_reads, v.d_offs, v.d_lens, o.min_snp_reads,
+                        o.qvalue, o.snp_nonref_pcnt, &sf, nullptr));
+      // side files: <snp file cut at its last '.'> + suffix (CUtility::AppendFileNameSuffix, KAligner.cpp:4512, 4553-4554)
+      std::string stem = o.snp_file;
+      for (size_t q = stem.size(); q > 0; q--) {
+        if (stem[q - 1] == '.') { stem.resize(q - 1); break; }
+        if (stem[q - 1] == '/' || stem[q - 1] == '\\') break;
       }
-      FILE* sf = fopen(o.snp_file.c_str(), "wb");
-      const bool okw = sf && fwrite(csv, 1, nb, sf) == nb;
-      if (sf && fclose(sf) != 0) { k4_free_host(csv); fprintf(stderr, "k4align: write to %s failed\n", o.snp_file.c_str()); return 5; }
-      k4_free_host(csv);
-      if (!okw) { fprintf(stderr, "k4align: unable to write %s\n", o.snp_file.c_str()); return 5; }
-      if (chatty) fprintf(stderr, "k4align: SNP processing completed with %llu putative SNPs discovered, written to %s in %.2fs\n", (unsigned long long)ns,
-                          o.snp_file.c_str(), secs(ts, now()));
+      const struct { std::string name; const char* p; uint64_t n; } files[4] = {{stem + ".covsegs.wig", sf.wig, sf.wig_bytes},
+                                                                                {stem + ".disnp.csv", sf.disnp, sf.disnp_bytes},
+                                                                                {stem + ".trisnp.csv", sf.trisnp, sf.trisnp_bytes},
+                                                                                {o.snp_file, sf.snp, sf.snp_bytes}};
+      std::string failed;
+      for (const auto& f : files) {
+        FILE* fp = fopen(f.name.c_str(), "wb");
+        bool ok = fp && fwrite(f.p, 1, f.n, fp) == f.n;
+        if (fp && fclose(fp) != 0) ok = false;
+        if (!ok && failed.empty()) failed = f.name;
+      }
+      k4_free_host(sf.snp); k4_free_host(sf.wig); k4_free_host(sf.disnp); k4_free_host(sf.trisnp);
+      if (!failed.empty()) { fprintf(stderr, "k4align: unable to write %s\n", failed.c_str()); return 5; }
+      if (chatty) fprintf(stderr, "k4align: SNP processing completed with %llu putative SNPs discovered, written to %s in %.2fs\n",
+                          (unsigned long long)sf.n_snps, o.snp_file.c_str(), secs(ts, now()));
     }
     if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= 10000 ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
     else CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));

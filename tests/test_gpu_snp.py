@@ -37,13 +37,20 @@ def test_snp_csv_through_the_api(k4, golden_dir, case):
         out = ix.kalign_pe_batch(r1, r2, **pe, **kw)
         reads = [x for p in zip(r1, r2) for x in p]
         text, n = ix.snp_csv(reads, pe_recs=out, **snp_args(SNP_CASES[case]["args"]))
+        files = ix.snp_files(reads, pe_recs=out, **snp_args(SNP_CASES[case]["args"]))
     else:
         _, reads = samutil.read_fasta_xz(os.path.join(golden_dir, case + ".fa.xz"))
         r = ix.kalign_ext_batch(reads, **kw) if "min_chimeric_len" in kw else ix.kalign_batch(reads, **kw)
         text, n = ix.snp_csv(reads, out=r["out"], hits=r["hits"], **snp_args(SNP_CASES[case]["args"]))
+        files = ix.snp_files(reads, out=r["out"], hits=r["hits"], **snp_args(SNP_CASES[case]["args"]))
     want = open(os.path.join(golden_dir, case + ".csv")).read()
     assert n == SNP_CASES[case]["snps"]
     assert text == want
+    # every file of the run through k4_snp_run_dev: the same CSV, the coverage WIG and the DiSNP / TriSNP haplotype files
+    assert files["snp"] == want and files["n_snps"] == n
+    assert files["wig"] == lzma.open(os.path.join(golden_dir, case + ".covsegs.wig.xz")).read().decode()
+    assert files["disnp"] == open(os.path.join(golden_dir, case + ".disnp.csv")).read()
+    assert files["trisnp"] == open(os.path.join(golden_dir, case + ".trisnp.csv")).read()
     ix.close()
 
 
@@ -63,6 +70,9 @@ def test_k4align_writes_the_reference_snp_file(golden_dir, tmp_path, case):
     assert ("with %d putative SNPs discovered" % SNP_CASES[case]["snps"]) in p.stderr
     # the coverage WIG beside it (<snp file minus extension>.covsegs.wig), spans walked on host threads
     assert open(str(tmp_path / "o.covsegs.wig")).read() == lzma.open(os.path.join(golden_dir, case + ".covsegs.wig.xz")).read().decode()
+    # and the haplotype files (<snp file minus extension>.disnp.csv / .trisnp.csv)
+    for ext in (".disnp.csv", ".trisnp.csv"):
+        assert open(str(tmp_path / ("o" + ext))).read() == open(os.path.join(golden_dir, case + ext)).read()
     got = [l for l in open(out).read().splitlines() if not l.startswith("@")]
     want = [l for l in lzma.open(os.path.join(golden_dir, case + ".sam.xz")).read().decode().splitlines() if not l.startswith("@")]
     assert sorted(got) == sorted(want)
@@ -86,7 +96,7 @@ def test_snp_option_rules(golden_dir, tmp_path):
     assert open(str(tmp_path / "o.sam") + ".snp").read().count("\n") == 1
 
 
-@pytest.mark.parametrize("case", ["snp_se_c50_p8", "snp_pe_u1"])
+@pytest.mark.parametrize("case", ["snp_se_c50_p8", "snp_pe_u1", "snp_pe_hap_c60"])
 def test_k4align_writes_the_reference_vcf(golden_dir, tmp_path, case):
     """`-S x.vcf`: the VCF form -- records identical to the reference's, header lines but ##source / ##reference too"""
     def unxz(name):

@@ -78,7 +78,7 @@ def test_snp_csv_matches_the_reference(oracle, golden_dir, case):
     oracle.close(h)
 
 
-@pytest.mark.parametrize("case", ["snp_se_c50_p8", "snp_pe_u1"])
+@pytest.mark.parametrize("case", ["snp_se_c50_p8", "snp_pe_u1", "snp_pe_hap_c60"])
 def test_snp_vcf_records_match_the_reference(oracle, golden_dir, case):
     """the same calls in kalign's VCF form (`-S x.vcf`): records identical; the header lines name the writer's version and the index"""
     h = oracle.open(os.path.join(golden_dir, "g1.sfx"))

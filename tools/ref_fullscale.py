@@ -63,6 +63,26 @@ if pe_mode:
     bench.write_fasta(reads[0::2], fa, dev)
     bench.write_fasta(reads[1::2], fa2, dev)
     in_args = ["-i", fa, "-u", fa2, "-U%d" % pe_mode, "-d200", "-D600"]
+elif os.environ.get("K4_REF_HAP") == "1":  # three haplotypes (the genome, one with a substitution every ~80 bases, one with those and
+    # half as many again), a third of the reads from each: called SNP loci close enough for the DiSNP / TriSNP files to fill
+    def haplotype(src, seed, every):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        h = src.clone()
+        pos = torch.randint(0, n, (n // every,), device=dev, generator=g)
+        pos = pos[h[pos] < 4]
+        h[pos] = ((h[pos].long() + 1 + torch.randint(0, 3, (pos.numel(),), device=dev, generator=g)) % 4).to(torch.uint8)
+        return h
+    h1 = haplotype(seq, 9001, 80)
+    h2 = haplotype(h1, 9002, 160)
+    parts = [bench.make_reads(g_, n_chrom, chrom_len, n_reads // 3, L, bench.READS_SEED + k, dev)[0] for k, g_ in enumerate((seq, h1, h2))]
+    reads = torch.cat(parts)
+    reads = reads[torch.randperm(reads.shape[0], device=dev, generator=torch.Generator(device=dev).manual_seed(77))]
+    n_reads = reads.shape[0]
+    del h1, h2, parts
+    fa = os.path.join(tmp, "reads.fa")
+    bench.write_fasta(reads, fa, dev)
+    in_args = ["-i", fa]
 else:
     reads, truth = bench.make_reads(seq, n_chrom, chrom_len, n_reads, L, bench.READS_SEED, dev)
     fa = os.path.join(tmp, "reads.fa")
@@ -140,6 +160,11 @@ if SNP:
     if os.path.exists(wr) and os.path.exists(wg):
         out["coverage_wig_bytes"] = os.path.getsize(wr)
         out["coverage_wig_identical"] = open(wr, "rb").read() == open(wg, "rb").read()
+    for key, ext in (("disnp", ".disnp.csv"), ("trisnp", ".trisnp.csv")):  # the haplotype files beside the SNP file
+        hr_, hg_ = ref_snp[:-4] + ext, gpu_snp[:-4] + ext
+        if os.path.exists(hr_) and os.path.exists(hg_):
+            out[key + "_lines_reference"] = open(hr_).read().count("\n") - 1
+            out[key + "_identical"] = open(hr_, "rb").read() == open(hg_, "rb").read()
 if dropin:
     hd, rd = body(dropin[0])
     out["dropin_threads"] = dropin_threads
@@ -149,5 +174,5 @@ if dropin:
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"summary": out, "reference_log_tail": keep[-40:], "k4align_stderr": g.stderr[-3000:]},
-          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep > 0 else "_stress" if n_rep < 0 else "") + ("_" + "".join(extra).replace("-", "") if extra else "") + ("_bam" if BAM else "") + ("_snp" if SNP else ""))), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", "ref_fullscale%s%s.json" % ("_pe%d" % pe_mode if pe_mode else "", ("_rep" if n_rep > 0 else "_stress" if n_rep < 0 else "") + ("_" + "".join(extra).replace("-", "") if extra else "") + ("_bam" if BAM else "") + ("_snp" if SNP else "") + ("_hap" if os.environ.get("K4_REF_HAP") == "1" else ""))), "w"), indent=1)
 shutil.rmtree(tmp, ignore_errors=True)
