@@ -14,6 +14,7 @@
 #include <thread>
 #include <vector>
 #include "k4_device.h"
+#include "k4_pool.h"
 
 // ---- errors ---------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -692,6 +693,7 @@ extern "C" void k4_close(k4_index* ix) {
   for (void* p : {(void*)ix->pe_rr, (void*)ix->pe_hits, (void*)ix->pe_list, (void*)ix->pe_ctl, ix->rs_tasks, ix->rs_reads, ix->rs_res, ix->rs_hits})
     if (p) hipFree(p);
   if (ix->stream) hipStreamDestroy(ix->stream);
+  k4_pool_trim_current_device();  // the ingest / emit stages' cached scratch (k4_pool.h)
   for (hipEvent_t e : ix->ev0) hipEventDestroy(e);
   for (hipEvent_t e : ix->ev1) hipEventDestroy(e);
   delete ix;

@@ -14,6 +14,8 @@
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "k4_device.h"
+#include "k4_pool.h"
+#include "k4_stages.h"
 
 namespace {
 
@@ -219,11 +221,16 @@ struct IsHeaderLine {  // FASTA: the line starts with '>'
   __device__ bool operator()(uint32_t j) const { return text[j == 0 ? 0u : nl[j - 1] + 1] == '>'; }
 };
 
-struct Buf {
-  void* p = nullptr;
-  ~Buf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-  template <typename T> T* as() { return (T*)p; }
+// scratch of one stage call, from the device's caching pool (k4_pool.h: no hipFree, which would wait for every stream of the
+// device -- the copy streams of the overlapped pipeline included); PoolStream names the stream the call works on
+thread_local hipStream_t tl_pool_stream = nullptr;
+struct PoolStream {
+  hipStream_t prev;
+  explicit PoolStream(hipStream_t s) : prev(tl_pool_stream) { tl_pool_stream = s; }
+  ~PoolStream() { tl_pool_stream = prev; }
+};
+struct Buf : K4PoolBuf {
+  hipError_t alloc(size_t bytes) { return K4PoolBuf::alloc(bytes, tl_pool_stream); }
 };
 
 }  // namespace
@@ -238,6 +245,7 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
   if (text_bytes >= 0xFFFFFF00ull) return k4_fail(ix, K4_ERR_PARAMS, "text chunks are limited to 2^32-256 bytes");
   K4_HIP(ix, hipSetDevice(ix->device));
   hipStream_t st = (hipStream_t)stream;
+  PoolStream pool_scope(st);
   const uint8_t* text = (const uint8_t*)d_text_v;
   if (format == 0) {  // first byte decides, as CFasta does
     uint8_t c = 0;
@@ -417,6 +425,7 @@ extern "C" int k4_prepare_reads_dev(k4_index* ix, int pe, int64_t n, int32_t min
   if (!d_offs1 || !d_lens1 || !d_offs_out || !d_lens_out || (pe && (!d_offs2 || !d_lens2))) return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
   K4_HIP(ix, hipSetDevice(ix->device));
   hipStream_t st = (hipStream_t)stream;
+  PoolStream pool_scope(st);
   Buf tot;
   K4_HIP(ix, tot.alloc(24));
   K4_HIP(ix, hipMemsetAsync(tot.p, 0, 24, st));
@@ -864,29 +873,26 @@ extern "C" int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const vo
   return k4_format_sam_ext_dev(ix, pe, n_units, d_rr, d_hits, max_ml, d_pe, nullptr, d_reads, d_offs, d_lens, names, d_sam, sam_bytes,
                                stats, chrom_hit, stream);
 }
-static int format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
-                          const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
-                          const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
-                          k4_sam_stats* stats, uint8_t* chrom_hit, void* stream);
 extern "C" int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                                      const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
                                      const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
                                      k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
-  return format_records(ix, 0, 0, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_sam, sam_bytes, stats,
-                        chrom_hit, stream);
+  return k4i_format_records(ix, 0, 0, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_sam, sam_bytes, stats,
+                            chrom_hit, stream, nullptr, nullptr);
 }
 extern "C" int k4_format_bam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                                  const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
                                  const void* d_lens, const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes,
                                  k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
-  return format_records(ix, 1, sq_all, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_bam, bam_bytes, stats,
-                        chrom_hit, stream);
+  return k4i_format_records(ix, 1, sq_all, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_bam, bam_bytes, stats,
+                            chrom_hit, stream, nullptr, nullptr);
 }
-static int format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
-                          const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
-                          const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
-                          k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
+int k4i_format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                       const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
+                       const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
+                       k4_sam_stats* stats, uint8_t* chrom_hit, void* stream, K4SamSlices* slices, K4PoolBuf* out_buf) {
   if (!ix || !names || !d_sam || !sam_bytes) return K4_ERR_PARAMS;
+  if (slices) slices->clear();
   *d_sam = nullptr;
   *sam_bytes = 0;
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -901,6 +907,7 @@ static int format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_u
     return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
   K4_HIP(ix, hipSetDevice(ix->device));
   hipStream_t st = (hipStream_t)stream;
+  PoolStream pool_scope(st);
   // chromosome names on the device
   const uint32_t ne = ix->d.n_entries;
   Buf cn, cl;
@@ -1015,29 +1022,61 @@ static int format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_u
                                        rocprim::plus<uint64_t>(), st));
     K4_HIP(ix, hipStreamSynchronize(st));
   }
-  uint64_t total = 0;
-  K4_HIP(ix, hipMemcpy(&total, lo.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost));
+  // slices of consecutive lines (one when the caller waits for the whole body anyway): their byte bounds come down with the total
+  const int n_sl = slices ? (int)std::min<uint64_t>(16, std::max<uint64_t>(m >> 16, 1)) : 1;
+  std::vector<uint64_t> line_end((size_t)n_sl), byte_end((size_t)n_sl);
+  for (int k = 0; k < n_sl; k++) {
+    line_end[(size_t)k] = k + 1 == n_sl ? m : m * (uint64_t)(k + 1) / (uint64_t)n_sl;
+    K4_HIP(ix, hipMemcpyAsync(&byte_end[(size_t)k], lo.as<uint64_t>() + line_end[(size_t)k], 8, hipMemcpyDeviceToHost, st));
+  }
+  K4_HIP(ix, hipStreamSynchronize(st));
+  const uint64_t total = byte_end[(size_t)n_sl - 1];
   char* out = nullptr;
-  K4_HIP(ix, hipMalloc(&out, total + 16));
+  if (out_buf) {
+    K4_HIP(ix, out_buf->alloc(total + 16, st));
+    out = out_buf->as<char>();
+  } else
+    K4_HIP(ix, hipMalloc(&out, total + 16));
+  int rc = K4_OK;
   {  // lines per wave tile: as many as fit the wave's LDS buffer at 1.25 x the average line
     const uint64_t avg = total / m + 1;
     const int lpl = avg * 64 * 5 / 4 <= K4_SAM_WAVE_BUF ? 1 : avg * 32 * 5 / 4 <= K4_SAM_WAVE_BUF ? 2 : 4;
     const uint64_t per_block = 4 * (64 / lpl);
-    const dim3 grid((unsigned)std::min<uint64_t>((m + per_block - 1) / per_block, 1u << 16));
-    if (bam) {
-      if (lpl == 1) hipLaunchKernelGGL((k4k_sam_write<1, true>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
-      else if (lpl == 2) hipLaunchKernelGGL((k4k_sam_write<2, true>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
-      else hipLaunchKernelGGL((k4k_sam_write<4, true>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
-    } else {
-      if (lpl == 1) hipLaunchKernelGGL((k4k_sam_write<1, false>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
-      else if (lpl == 2) hipLaunchKernelGGL((k4k_sam_write<2, false>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
-      else hipLaunchKernelGGL((k4k_sam_write<4, false>), grid, dim3(256), 0, st, a, order, lo.as<uint64_t>(), m, out);
+    uint64_t b0 = 0;
+    for (int k = 0; k < n_sl && rc == K4_OK; k++) {
+      const uint64_t mk = line_end[(size_t)k] - b0;
+      if (mk) {
+        const dim3 grid((unsigned)std::min<uint64_t>((mk + per_block - 1) / per_block, 1u << 16));
+        const uint32_t* ord = order + b0;
+        const uint64_t* lok = lo.as<uint64_t>() + b0;
+        if (bam) {
+          if (lpl == 1) hipLaunchKernelGGL((k4k_sam_write<1, true>), grid, dim3(256), 0, st, a, ord, lok, mk, out);
+          else if (lpl == 2) hipLaunchKernelGGL((k4k_sam_write<2, true>), grid, dim3(256), 0, st, a, ord, lok, mk, out);
+          else hipLaunchKernelGGL((k4k_sam_write<4, true>), grid, dim3(256), 0, st, a, ord, lok, mk, out);
+        } else {
+          if (lpl == 1) hipLaunchKernelGGL((k4k_sam_write<1, false>), grid, dim3(256), 0, st, a, ord, lok, mk, out);
+          else if (lpl == 2) hipLaunchKernelGGL((k4k_sam_write<2, false>), grid, dim3(256), 0, st, a, ord, lok, mk, out);
+          else hipLaunchKernelGGL((k4k_sam_write<4, false>), grid, dim3(256), 0, st, a, ord, lok, mk, out);
+        }
+        rc = k4_check_hip(ix, hipGetLastError(), "SAM write");
+      }
+      b0 = line_end[(size_t)k];
+      if (slices && rc == K4_OK) {
+        hipEvent_t ev = nullptr;
+        rc = k4_check_hip(ix, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "event");
+        if (rc == K4_OK) {
+          slices->ev.push_back(ev);
+          slices->end.push_back(byte_end[(size_t)k]);
+          rc = k4_check_hip(ix, hipEventRecord(ev, st), "event");
+        }
+      }
     }
   }
-  int rc = k4_check_hip(ix, hipGetLastError(), "SAM write");
-  if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(st), "SAM write");
+  if (rc == K4_OK && !slices) rc = k4_check_hip(ix, hipStreamSynchronize(st), "SAM write");
   if (rc != K4_OK) {
-    hipFree(out);
+    (void)hipStreamSynchronize(st);
+    if (slices) slices->clear();
+    if (out_buf) out_buf->release(); else hipFree(out);
     return rc;
   }
   *d_sam = out;

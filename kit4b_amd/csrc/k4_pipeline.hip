@@ -22,24 +22,38 @@
 #include <thread>
 #include <vector>
 #include "k4_internal.h"
+#include "k4_pool.h"
+#include "k4_stages.h"
 
 namespace {
 
-struct Arena {  // grow-only device array; only the worker thread touches it while the pipeline runs
+struct Arena {  // grow-only device array from the device's block pool (k4_pool.h); only the worker thread touches it while the pipeline runs
+  K4PoolBuf b;
   uint8_t* p = nullptr;
   size_t cap = 0, used = 0;
+  hipStream_t st = nullptr;      // the stream whose kernels read and write the array (the compute stream)
+  hipStream_t writer = nullptr;  // a second stream that writes into it (the text arrays: the copy-in stream)
+  // Growing never blocks the host: the new block is taken behind its last user, the old contents are copied on `st` (behind what
+  // `writer` had queued into the old block), and the old block goes back to the pool behind that copy.
   int reserve(k4_index* ix, size_t need, size_t slack_div = 2) {
     if (need <= cap) return K4_OK;
-    size_t ncap = std::max(need + need / slack_div + 4096, cap * 2);
-    uint8_t* np = nullptr;
-    K4_HIP(ix, hipDeviceSynchronize());  // no copy or kernel may still use the old block
-    K4_HIP(ix, hipMalloc(&np, ncap + 64));
-    if (used) K4_HIP(ix, hipMemcpy(np, p, used, hipMemcpyDeviceToDevice));
-    if (p) hipFree(p);
-    p = np; cap = ncap;
+    const size_t ncap = std::max(need + need / slack_div + 4096, cap * 2);
+    K4PoolBuf nb;
+    K4_HIP(ix, nb.alloc(ncap + 64, st));
+    if (writer) K4_HIP(ix, hipStreamWaitEvent(writer, nb.ev, 0));  // (a fresh block's event was never recorded: no wait)
+    if (used) {
+      if (writer) {
+        K4_HIP(ix, hipEventRecord(b.ev, writer));  // the old block's own event: free to use while the block is held
+        K4_HIP(ix, hipStreamWaitEvent(st, b.ev, 0));
+      }
+      K4_HIP(ix, hipMemcpyAsync(nb.p, p, used, hipMemcpyDeviceToDevice, st));
+    }
+    std::swap(b.p, nb.p); std::swap(b.cap, nb.cap); std::swap(b.ev, nb.ev);
+    b.st = st; nb.st = st;  // nb now holds the old block: back to the pool behind the copy, at the end of this scope
+    p = (uint8_t*)b.p; cap = b.cap - 64;
     return K4_OK;
   }
-  void release() { if (p) hipFree(p); p = nullptr; cap = used = 0; }
+  void release() { b.release(); p = nullptr; cap = used = 0; }
 };
 
 struct PinBuf {
@@ -92,7 +106,10 @@ struct k4_pipeline {
   bool closing = false, worker_done = false;
   int err = K4_OK;
   // output
-  void* d_sam = nullptr;
+  void* d_sam = nullptr;        // the body, in sam_buf
+  K4PoolBuf sam_buf;
+  K4SamSlices slices;           // it is written slice by slice: the copy-out stream follows behind the slices' events
+  size_t slice_waited = 0;      // slices the copy-out stream already waits behind
   uint64_t sam_bytes = 0, sam_next = 0, sam_given = 0;
   std::vector<PinBuf> out_ring;
   std::deque<std::pair<int, uint64_t>> out_q;  // (ring index, bytes) of pieces on their way down, oldest first
@@ -112,20 +129,25 @@ int pin_alloc(k4_index* ix, PinBuf& b, size_t cap) {
 int parse_more(k4_pipeline* pl, int e) {
   k4_index* ix = pl->ix;
   End& E = pl->end[e];
-  // the compute stream may only read what the copy stream has delivered
-  if (E.up_ev) K4_HIP(ix, hipStreamWaitEvent(pl->s_comp, E.up_ev, 0));
+  // (the compute stream already waits behind the copy of everything below E.uploaded: worker_main)
   const uint64_t piece = 3ull << 30;
   while (E.parsed < E.uploaded) {
     const uint64_t len = std::min(piece, E.uploaded - E.parsed);
     const int final_chunk = E.final_seen && E.parsed + len == E.uploaded;
-    // room: a record takes at least ~ 2 lines; 1 per 24 bytes is generous for real reads, a shortfall only costs another round
-    const int64_t cap_rec = (int64_t)(len / 24 + 1024);
+    // room: a record takes at least ~ 2 lines; 1 per 24 bytes is generous for real reads -- until the first records show how long
+    // they are (then: twice as many as their mean length suggests); a shortfall only costs another round
+    int64_t cap_rec = (int64_t)(len / 24 + 1024);
+    if (E.n_rec > 4096 && E.parsed > 0) cap_rec = std::min<int64_t>(cap_rec, (int64_t)((long double)len * 2 * E.n_rec / E.parsed) + 1024);
+    // with the size of the whole input known, an array that has to grow grows once: to what the records seen so far project
+    const uint64_t expect = pl->prm.expect_text_bytes[e];
+    const long double scale = expect > E.parsed && E.parsed > 0 ? (long double)expect / E.parsed * 1.03L : 0.0L;
+    auto want = [&](size_t now, size_t have) { return std::max(now, scale > 0 ? (size_t)(have * scale) : (size_t)0); };
     int rc;
-    if ((rc = E.offs.reserve(ix, (size_t)(E.n_rec + cap_rec) * 8)) != K4_OK) return rc;
-    if ((rc = E.lens.reserve(ix, (size_t)(E.n_rec + cap_rec) * 4)) != K4_OK) return rc;
-    if ((rc = E.noff.reserve(ix, (size_t)(E.n_rec + cap_rec) * 8)) != K4_OK) return rc;
-    if ((rc = E.nlen.reserve(ix, (size_t)(E.n_rec + cap_rec) * 4)) != K4_OK) return rc;
-    if ((rc = pl->reads.reserve(ix, pl->reads.used + len + 64)) != K4_OK) return rc;
+    if ((rc = E.offs.reserve(ix, want((size_t)(E.n_rec + cap_rec) * 8, (size_t)E.n_rec * 8), 8)) != K4_OK) return rc;
+    if ((rc = E.lens.reserve(ix, want((size_t)(E.n_rec + cap_rec) * 4, (size_t)E.n_rec * 4), 8)) != K4_OK) return rc;
+    if ((rc = E.noff.reserve(ix, want((size_t)(E.n_rec + cap_rec) * 8, (size_t)E.n_rec * 8), 8)) != K4_OK) return rc;
+    if ((rc = E.nlen.reserve(ix, want((size_t)(E.n_rec + cap_rec) * 4, (size_t)E.n_rec * 4), 8)) != K4_OK) return rc;
+    if ((rc = pl->reads.reserve(ix, want(pl->reads.used + len + 64, pl->reads.used * (size_t)pl->n_ends), 8)) != K4_OK) return rc;
     k4_parse_info info;
     rc = k4_parse_fastx_dev(ix, E.text.p + E.parsed, len, E.parsed, final_chunk, E.fmt, cap_rec, pl->reads.p, pl->reads.used,
                             E.offs.p + 8 * E.n_rec, E.lens.p + 4 * E.n_rec, E.noff.p + 8 * E.n_rec, E.nlen.p + 4 * E.n_rec, &info,
@@ -150,12 +172,22 @@ int align_more(k4_pipeline* pl, bool flush) {
   const bool pe = pl->n_ends == 2;
   const int64_t avail = pe ? std::min(pl->end[0].n_rec, pl->end[1].n_rec) : pl->end[0].n_rec;
   const int64_t n = avail - pl->units_done;
-  if (n <= 0 || (!flush && n < (int64_t)pl->prm.min_batch_units)) return K4_OK;
+  // large batches while there is input to come (the align kernels want millions of reads per launch); with the size of the
+  // input known, the last eighth is aligned as it arrives, so that little is left to do behind the last upload
+  bool endgame = false;
+  if (pl->prm.expect_text_bytes[0]) endgame = pl->end[0].uploaded >= pl->prm.expect_text_bytes[0] - pl->prm.expect_text_bytes[0] / 8;
+  if (n <= 0 || (!flush && !endgame && n < (int64_t)pl->prm.min_batch_units)) return K4_OK;
   const int64_t r0 = pe ? 2 * pl->units_done : pl->units_done, nr = pe ? 2 * n : n;
   const int max_ml = std::max(pl->prm.kp.max_ml, 1);
   int rc;
-  if ((rc = pl->c_offs.reserve(ix, (size_t)(r0 + nr + 1) * 8)) != K4_OK) return rc;
-  if ((rc = pl->c_lens.reserve(ix, (size_t)(r0 + nr + 1) * 4)) != K4_OK) return rc;
+  // reads the whole input will hold, projected from the records of its first end so far (0: unknown) -- see parse_more
+  const End& E0 = pl->end[0];
+  const uint64_t expect0 = pl->prm.expect_text_bytes[0];
+  const int64_t all_reads = expect0 > E0.parsed && E0.parsed > 0 && E0.n_rec > 4096
+                                ? (int64_t)((long double)E0.n_rec * expect0 / E0.parsed * 1.03L) * (pe ? 2 : 1) : 0;
+  auto rows = [&](int64_t now) { return (size_t)std::max(now, all_reads); };
+  if ((rc = pl->c_offs.reserve(ix, rows(r0 + nr + 1) * 8, 8)) != K4_OK) return rc;
+  if ((rc = pl->c_lens.reserve(ix, rows(r0 + nr + 1) * 4, 8)) != K4_OK) return rc;
   uint64_t under = 0, over = 0;
   uint32_t max_len = 0;
   const int64_t d = pl->units_done;
@@ -167,7 +199,7 @@ int align_more(k4_pipeline* pl, bool flush) {
   pl->n_under += under; pl->n_over += over;
   pl->max_read_len = std::max(pl->max_read_len, max_len);
   if (pe) {
-    if ((rc = pl->pe.reserve(ix, (size_t)(r0 + nr) * sizeof(k4_pe_read))) != K4_OK) return rc;
+    if ((rc = pl->pe.reserve(ix, rows(r0 + nr) * sizeof(k4_pe_read), 8)) != K4_OK) return rc;
     pl->pe.used = (size_t)(r0 + nr) * sizeof(k4_pe_read);
     if (max_len > 0)
       rc = k4_kalign_pe_batch_dev(ix, &pl->prm.kp, &pl->prm.pe, n, (int32_t)max_len, pl->reads.p, pl->c_offs.p + 8 * r0, pl->c_lens.p + 4 * r0,
@@ -176,9 +208,9 @@ int align_more(k4_pipeline* pl, bool flush) {
       rc = k4_check_hip(ix, hipMemsetAsync(pl->pe.p + (size_t)r0 * sizeof(k4_pe_read), 0, (size_t)nr * sizeof(k4_pe_read), pl->s_comp), "memset");
   } else {
     const bool two = pl->prm.kp.micro_indel_len > 0 || pl->prm.kp.max_splice_junct_len > 0;
-    if ((rc = pl->rr.reserve(ix, (size_t)(r0 + nr) * sizeof(k4_read_result))) != K4_OK) return rc;
-    if ((rc = pl->hits.reserve(ix, (size_t)(r0 + nr) * max_ml * sizeof(k4_hit))) != K4_OK) return rc;
-    if (two && (rc = pl->seg2.reserve(ix, (size_t)(r0 + nr) * sizeof(k4_seg2))) != K4_OK) return rc;
+    if ((rc = pl->rr.reserve(ix, rows(r0 + nr) * sizeof(k4_read_result), 8)) != K4_OK) return rc;
+    if ((rc = pl->hits.reserve(ix, rows(r0 + nr) * max_ml * sizeof(k4_hit), 8)) != K4_OK) return rc;
+    if (two && (rc = pl->seg2.reserve(ix, rows(r0 + nr) * sizeof(k4_seg2), 8)) != K4_OK) return rc;
     pl->rr.used = (size_t)(r0 + nr) * sizeof(k4_read_result);
     pl->hits.used = (size_t)(r0 + nr) * max_ml * sizeof(k4_hit);
     if (two) pl->seg2.used = (size_t)(r0 + nr) * sizeof(k4_seg2);
@@ -197,61 +229,81 @@ int align_more(k4_pipeline* pl, bool flush) {
   return K4_OK;
 }
 
+// a chunk whose copy has been enqueued and that nobody has parsed yet
+struct Sent {
+  int end;
+  uint64_t upto;     // E.text.used behind this chunk
+  hipEvent_t ev;     // behind its copy on the copy-in stream
+  int final_chunk;
+};
+
 void worker_main(k4_pipeline* pl) {
   k4_index* ix = pl->ix;
   hipSetDevice(ix->device);
   int rc = K4_OK;
+  std::deque<Sent> sent;
+  std::vector<hipEvent_t> spare;  // events are reused: one per chunk in flight
   for (;;) {
-    Job j;
+    // 1. every chunk that is queued starts its way up at once: the copy-in stream never waits for the parsing and aligning below
+    std::deque<Job> take;
     {
       std::unique_lock<std::mutex> lk(pl->m);
-      pl->cv.wait(lk, [&] { return !pl->jobs.empty() || pl->closing; });
-      if (pl->jobs.empty()) break;
-      j = pl->jobs.front();
-      pl->jobs.pop_front();
+      pl->cv.wait(lk, [&] { return !pl->jobs.empty() || pl->closing || !sent.empty(); });
+      take.swap(pl->jobs);
+      if (take.empty() && sent.empty()) break;  // closing, nothing left
     }
-    if (rc != K4_OK) {  // drain: buffers must still be released
-      if (j.buf >= 0) { std::lock_guard<std::mutex> lk(pl->m); pl->end[j.end].ring[(size_t)j.buf].in_flight = false; pl->cv.notify_all(); }
+    for (const Job& j : take) {
+      End& E = pl->end[j.end];
+      if (rc == K4_OK && j.bytes) {
+        rc = E.text.reserve(ix, E.text.used + j.bytes + 64, 4);
+        if (rc == K4_OK) {
+          const void* src = j.buf >= 0 ? (const void*)E.ring[(size_t)j.buf].h : j.src;
+          rc = k4_check_hip(ix, hipMemcpyAsync(E.text.p + E.text.used, src, j.bytes, hipMemcpyHostToDevice, pl->s_in), "upload");
+        }
+        if (rc == K4_OK) {
+          E.text.used += j.bytes;
+          if (j.buf >= 0) rc = k4_check_hip(ix, hipEventRecord(E.ring[(size_t)j.buf].ev, pl->s_in), "event");
+        }
+      }
+      if (rc == K4_OK) {
+        hipEvent_t ev = nullptr;
+        if (!spare.empty()) { ev = spare.back(); spare.pop_back(); }
+        else rc = k4_check_hip(ix, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "event");
+        if (rc == K4_OK) rc = k4_check_hip(ix, hipEventRecord(ev, pl->s_in), "event");
+        if (rc == K4_OK) sent.push_back({j.end, E.text.used, ev, j.final_chunk});
+        else if (ev) spare.push_back(ev);
+      }
+      if (j.buf >= 0) {  // the ring buffer is free once its copy has completed: acquire() waits on the buffer's own event
+        std::lock_guard<std::mutex> lk(pl->m);
+        E.ring[(size_t)j.buf].in_flight = false;
+        pl->cv.notify_all();
+      }
+    }
+    if (rc != K4_OK) {  // drain
+      for (Sent& c : sent) spare.push_back(c.ev);
+      sent.clear();
       continue;
     }
-    End& E = pl->end[j.end];
-    // 1. this chunk starts its way up ...
-    if (j.bytes) {
-      rc = E.text.reserve(ix, E.text.used + j.bytes + 64, 4);
-      if (rc == K4_OK) {
-        const void* src = j.buf >= 0 ? (const void*)E.ring[(size_t)j.buf].h : j.src;
-        rc = k4_check_hip(ix, hipMemcpyAsync(E.text.p + E.text.used, src, j.bytes, hipMemcpyHostToDevice, pl->s_in), "upload");
-      }
-      if (rc == K4_OK) {
-        E.text.used += j.bytes;
-        if (j.buf >= 0) rc = k4_check_hip(ix, hipEventRecord(E.ring[(size_t)j.buf].ev, pl->s_in), "event");
-      }
+    // 2. the oldest chunk on its way becomes parseable (the compute stream waits for its copy): parse and align what it completes
+    if (!sent.empty()) {
+      const Sent c = sent.front();
+      sent.pop_front();
+      End& E = pl->end[c.end];
+      rc = k4_check_hip(ix, hipStreamWaitEvent(pl->s_comp, c.ev, 0), "event");
+      spare.push_back(c.ev);  // (the wait is enqueued: recording the event again later does not disturb it)
+      E.uploaded = c.upto;
+      if (c.final_chunk) E.final_seen = true;
+      if (rc == K4_OK) rc = parse_more(pl, c.end);
+      bool all_final = true;
+      for (int e = 0; e < pl->n_ends; e++) all_final &= pl->end[e].final_seen;
+      if (rc == K4_OK) rc = align_more(pl, all_final && sent.empty());
     }
-    // 2. ... while everything that had arrived before it is parsed and aligned (the copy stream runs on its own)
-    if (rc == K4_OK) rc = parse_more(pl, j.end);
-    if (rc == K4_OK) rc = align_more(pl, false);
-    // 3. the chunk just sent becomes parseable: everything up to here is behind up_ev
-    if (rc == K4_OK && j.bytes) {
-      if (!E.up_ev) rc = k4_check_hip(ix, hipEventCreateWithFlags(&E.up_ev, hipEventDisableTiming), "event");
-      if (rc == K4_OK) rc = k4_check_hip(ix, hipEventRecord(E.up_ev, pl->s_in), "event");
-      E.uploaded = E.text.used;
-    }
-    if (j.final_chunk) E.final_seen = true;  // (only now: the text parsed above was not the end of the input yet)
+  }
+  for (hipEvent_t ev : spare) hipEventDestroy(ev);
+  if (rc == K4_OK) {  // whatever is left (the caller closed the input without a final chunk on some end: wait_aligned reports it)
     bool all_final = true;
     for (int e = 0; e < pl->n_ends; e++) all_final &= pl->end[e].final_seen;
-    if (j.buf >= 0) {  // the ring buffer is free once its copy has completed: acquire() waits on the event
-      std::lock_guard<std::mutex> lk(pl->m);
-      E.ring[(size_t)j.buf].in_flight = false;
-      pl->cv.notify_all();
-    }
-    if (rc == K4_OK && all_final) {
-      bool empty;
-      { std::lock_guard<std::mutex> lk(pl->m); empty = pl->jobs.empty(); }
-      if (empty) {  // the last chunks: parse and align what is left
-        for (int e = 0; e < pl->n_ends && rc == K4_OK; e++) rc = parse_more(pl, e);
-        if (rc == K4_OK) rc = align_more(pl, true);
-      }
-    }
+    if (all_final) rc = align_more(pl, true);
   }
   if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(pl->s_comp), "pipeline");
   std::lock_guard<std::mutex> lk(pl->m);
@@ -283,13 +335,19 @@ extern "C" int k4_pipeline_open(k4_index* ix, const k4_pipeline_params* p, k4_pi
   pl->n_ends = p->paired ? 2 : 1;
   if (pl->prm.chunk_bytes == 0) pl->prm.chunk_bytes = 256ull << 20;
   pl->prm.chunk_bytes = std::min<uint64_t>(std::max<uint64_t>(pl->prm.chunk_bytes, 1ull << 20), 2ull << 30);
-  if (pl->prm.min_batch_units == 0) pl->prm.min_batch_units = 1u << 20;
+  if (pl->prm.min_batch_units == 0) pl->prm.min_batch_units = 1u << 22;  // (the align kernels want millions of reads per launch)
   if (pl->prm.n_buffers < 2) pl->prm.n_buffers = 3;
   int rc = K4_OK;
   auto ck = [&](hipError_t e, const char* what) { if (rc == K4_OK) rc = k4_check_hip(ix, e, what); };
   ck(hipStreamCreateWithFlags(&pl->s_in, hipStreamNonBlocking), "stream");
   ck(hipStreamCreateWithFlags(&pl->s_comp, hipStreamNonBlocking), "stream");
   ck(hipStreamCreateWithFlags(&pl->s_out, hipStreamNonBlocking), "stream");
+  for (int e = 0; e < 2; e++) {
+    End& E = pl->end[e];
+    for (Arena* a : {&E.text, &E.offs, &E.lens, &E.noff, &E.nlen}) a->st = pl->s_comp;
+    E.text.writer = pl->s_in;
+  }
+  for (Arena* a : {&pl->reads, &pl->c_offs, &pl->c_lens, &pl->rr, &pl->hits, &pl->seg2, &pl->pe}) a->st = pl->s_comp;
   for (int e = 0; e < pl->n_ends && rc == K4_OK; e++) {
     pl->end[e].ring.resize((size_t)pl->prm.n_buffers);
     if (p->expect_text_bytes[e]) rc = pl->end[e].text.reserve(ix, (size_t)p->expect_text_bytes[e] + 64, 64);
@@ -412,16 +470,33 @@ static int pipeline_format(k4_pipeline* pl, int bam, int sq_all, k4_sam_stats* s
   k4_pipeline_view v;
   int rc = k4_pipeline_wait_aligned(pl, &v);
   if (rc != K4_OK) return rc;
-  if (pl->d_sam) { hipFree(pl->d_sam); pl->d_sam = nullptr; }
+  if (pl->d_sam) {  // a second format call: the first body's way down may still be running
+    K4_HIP(pl->ix, hipStreamSynchronize(pl->s_out));
+    pl->sam_buf.st = pl->s_comp;
+    pl->sam_buf.release();
+    pl->d_sam = nullptr;
+  }
+  pl->slices.clear();
+  pl->slice_waited = 0;
   pl->sam_bytes = pl->sam_next = pl->sam_given = 0;
   if (stats) memset(stats, 0, sizeof(*stats));
-  if (v.n_units > 0 && v.max_read_len > 0)
-    rc = bam ? k4_format_bam_dev(pl->ix, pl->n_ends == 2 ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_seg2, v.d_reads, v.d_offs,
-                                 v.d_lens, &v.names, sq_all, &pl->d_sam, &pl->sam_bytes, stats, chrom_hit, pl->s_comp)
-             : k4_format_sam_ext_dev(pl->ix, pl->n_ends == 2 ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_seg2, v.d_reads, v.d_offs,
-                                     v.d_lens, &v.names, &pl->d_sam, &pl->sam_bytes, stats, chrom_hit, pl->s_comp);
+  if (v.n_units > 0 && v.max_read_len > 0)  // returns with the last slices still being written (k4_stages.h)
+    rc = k4i_format_records(pl->ix, bam, sq_all, pl->n_ends == 2 ? 1 : 0, v.n_units, v.d_rr, v.d_hits, v.max_ml, v.d_pe, v.d_seg2, v.d_reads,
+                            v.d_offs, v.d_lens, &v.names, &pl->d_sam, &pl->sam_bytes, stats, chrom_hit, pl->s_comp, &pl->slices, &pl->sam_buf);
   if (sam_bytes) *sam_bytes = pl->sam_bytes;
   return rc;
+}
+
+// the copy-out stream may read the body up to `upto`: it waits behind the slice that holds the last of those bytes
+static int wait_slices(k4_pipeline* pl, uint64_t upto) {
+  K4SamSlices& S = pl->slices;
+  size_t k = pl->slice_waited;
+  while (k < S.end.size() && (k == 0 ? 0 : S.end[k - 1]) < upto) k++;
+  if (k > pl->slice_waited) {
+    K4_HIP(pl->ix, hipStreamWaitEvent(pl->s_out, S.ev[k - 1], 0));  // (the slices are written in order on one stream)
+    pl->slice_waited = k;
+  }
+  return K4_OK;
 }
 
 // the next piece of the SAM body in a pinned buffer that stays valid until the following call; *bytes == 0 at the end.
@@ -446,6 +521,8 @@ extern "C" int k4_pipeline_next_sam(k4_pipeline* pl, const void** ptr, uint64_t*
     PinBuf& B = pl->out_ring[b];
     if (B.in_flight) continue;
     const uint64_t len = std::min<uint64_t>(B.cap, pl->sam_bytes - pl->sam_next);
+    int rcw = wait_slices(pl, pl->sam_next + len);
+    if (rcw != K4_OK) return rcw;
     K4_HIP(ix, hipMemcpyAsync(B.h, (const uint8_t*)pl->d_sam + pl->sam_next, len, hipMemcpyDeviceToHost, pl->s_out));
     K4_HIP(ix, hipEventRecord(B.ev, pl->s_out));
     B.in_flight = true;
@@ -469,7 +546,14 @@ extern "C" int k4_pipeline_read_sam(k4_pipeline* pl, void* dst, uint64_t cap, ui
   if (pl->sam_bytes == 0) return K4_OK;
   if (!dst || cap < pl->sam_bytes) return k4_fail(pl->ix, K4_ERR_PARAMS, "the SAM body takes %llu bytes", (unsigned long long)pl->sam_bytes);
   K4_HIP(pl->ix, hipSetDevice(pl->ix->device));
-  K4_HIP(pl->ix, hipMemcpyAsync(dst, pl->d_sam, pl->sam_bytes, hipMemcpyDeviceToHost, pl->s_out));
+  uint64_t pos = 0;
+  for (size_t k = 0; k < pl->slices.end.size(); k++) {  // slice k goes down while the slices behind it are still being written
+    const uint64_t end = pl->slices.end[k];
+    if (end == pos) continue;
+    K4_HIP(pl->ix, hipStreamWaitEvent(pl->s_out, pl->slices.ev[k], 0));
+    K4_HIP(pl->ix, hipMemcpyAsync((uint8_t*)dst + pos, (const uint8_t*)pl->d_sam + pos, end - pos, hipMemcpyDeviceToHost, pl->s_out));
+    pos = end;
+  }
   K4_HIP(pl->ix, hipStreamSynchronize(pl->s_out));
   return K4_OK;
 }
@@ -487,7 +571,9 @@ extern "C" void k4_pipeline_close(k4_pipeline* pl) {
   }
   for (PinBuf& b : pl->out_ring) { if (b.h) hipHostFree(b.h); if (b.ev) hipEventDestroy(b.ev); }
   for (Arena* a : {&pl->reads, &pl->c_offs, &pl->c_lens, &pl->rr, &pl->hits, &pl->seg2, &pl->pe}) a->release();
-  if (pl->d_sam) hipFree(pl->d_sam);
+  pl->slices.clear();
+  pl->sam_buf.st = pl->s_comp;  // (everything is idle: hipDeviceSynchronize above)
+  pl->sam_buf.release();
   for (hipStream_t s : {pl->s_in, pl->s_comp, pl->s_out}) if (s) hipStreamDestroy(s);
   delete pl;
 }
