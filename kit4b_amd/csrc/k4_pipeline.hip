@@ -575,5 +575,6 @@ extern "C" void k4_pipeline_close(k4_pipeline* pl) {
   pl->sam_buf.st = pl->s_comp;  // (everything is idle: hipDeviceSynchronize above)
   pl->sam_buf.release();
   for (hipStream_t s : {pl->s_in, pl->s_comp, pl->s_out}) if (s) hipStreamDestroy(s);
+  k4_pool_trim_to(32ull << 30);  // what a run of a few ten million reads needs stays cached for the next one; more goes back
   delete pl;
 }

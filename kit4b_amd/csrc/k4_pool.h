@@ -4,7 +4,8 @@
 // streams still have queued (the overlapped pipeline, k4_pipeline.hip: parse and align of chunk k would wait for the uploads
 // of chunks k+1.. to finish).  Blocks handed back here are kept per device and given out again; every block carries an event
 // recorded on the stream of its last user, and the stream of its next user waits for that event (no host-side wait).  Nothing is
-// freed before k4_pool_trim_current_device (k4_close, or an allocation that fails for want of memory).
+// freed before k4_pool_trim_current_device (k4_close, or an allocation that fails for want of memory) or k4_pool_trim_to (the
+// pipeline keeps at most 32 GB cached when it closes).
 #pragma once
 #include <stddef.h>
 #include <mutex>
@@ -29,6 +30,27 @@ inline void k4_pool_trim_current_device() {
   std::vector<K4PoolBlock> take;
   { std::lock_guard<std::mutex> lk(P.m); take.swap(P.free_); }
   for (K4PoolBlock& b : take) { (void)hipFree(b.p); (void)hipEventDestroy(b.ev); }
+}
+
+// keep at most `limit` bytes cached: the largest blocks go first (hipFree waits for the device: call it where that is harmless)
+inline void k4_pool_trim_to(size_t limit) {
+  K4Pool& P = k4_pool_of_current_device();
+  std::vector<K4PoolBlock> drop;
+  {
+    std::lock_guard<std::mutex> lk(P.m);
+    size_t held = 0;
+    for (const K4PoolBlock& b : P.free_) held += b.cap;
+    while (held > limit && !P.free_.empty()) {
+      size_t big = 0;
+      for (size_t k = 1; k < P.free_.size(); k++)
+        if (P.free_[k].cap > P.free_[big].cap) big = k;
+      held -= P.free_[big].cap;
+      drop.push_back(P.free_[big]);
+      P.free_[big] = P.free_.back();
+      P.free_.pop_back();
+    }
+  }
+  for (K4PoolBlock& b : drop) { (void)hipFree(b.p); (void)hipEventDestroy(b.ev); }
 }
 
 // capacity classes: eight per power of two, so that buffers sized by slightly different batches find each other
