@@ -117,11 +117,20 @@ __global__ void __launch_bounds__(256) k4k_snp_candidates(SnpArgs a, const uint6
   out[slot] = c;
 }
 
-// coverage per locus (TotBases) for the WIG: ref + nonref
+// coverage per locus (TotBases) for the WIG: ref + nonref.  First its maximum, then the array in the narrowest of 1 / 2 / 4 bytes
+// per locus that holds it (whole-genome coverage fits a byte: a quarter of the bytes to bring down and to walk through)
+__global__ void __launch_bounds__(256) k4k_snp_coverage_max(const uint32_t* __restrict__ ref, const uint32_t* __restrict__ non, uint32_t n,
+                                                            uint32_t* __restrict__ mx) {
+  uint32_t m = 0;
+  for (uint32_t l = blockIdx.x * 256u + threadIdx.x; l < n; l += gridDim.x * 256u) m = max(m, ref[l] + non[l]);
+  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_down(m, d, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(mx, m);
+}
+template <typename T>
 __global__ void __launch_bounds__(256) k4k_snp_coverage(const uint32_t* __restrict__ ref, const uint32_t* __restrict__ non, uint32_t n,
-                                                        uint32_t* __restrict__ cov) {
+                                                        T* __restrict__ cov) {
   const uint32_t l = blockIdx.x * 256u + threadIdx.x;
-  if (l < n) cov[l] = ref[l] + non[l];
+  if (l < n) cov[l] = (T)(ref[l] + non[l]);
 }
 
 // DiSNPs / TriSNPs (OutputSNPs :7767-8101 with IterateReadsOverlapping :10475-10546 and AdjAlignSNPBase :1581-1632): for two / three
@@ -229,41 +238,69 @@ static std::string hap_header(int n) {  // :8252-8330
 // device piles up the next chromosomes.  Returns the text of the chromosome's closed spans; `tail` = what closing the last open
 // span adds (the reference does that only for chromosomes with at least one candidate locus, :7582-7608 / :8135).
 struct WigOut { std::string body, tail; };
-static WigOut wig_chromosome(std::unique_ptr<uint32_t[]> cov, uint32_t clen, std::string name) {
+// The running mean cnts / len is kept as quotient and remainder (a span grows by one locus at a time), so the walk has no division:
+// 100 * (cnts / len) against 100 c, 75 c and 125 c is q against c, 4 q against 3 c and 5 c.
+template <typename T>
+static WigOut wig_walk(const T* cov, uint32_t clen, const std::string& name) {
   WigOut o;
   uint32_t loci = 0, len = 0, rptd_len = 0;
   bool started = false, rptd = false;  // m_WIGChromID != 0, m_WIGRptdChromID == this chromosome
-  uint64_t cnts = 0;
-  char line[160];
+  uint64_t cnts = 0, q = 0;            // q = cnts / len
+  int64_t r = 0;                       // cnts - q * len
+  // (a genome at low coverage makes a span of nearly every run of equal coverage -- hundreds of millions of lines: own digits, no printf)
+  const std::string head = "variableStep chrom=" + name + " span=";
+  char line[64];
+  auto put = [](char* p, uint32_t v) {
+    char t[10];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = t[--n];
+    return p;
+  };
   auto complete = [&](std::string& dst) {
     if (started && len > 0 && loci > 0 && cnts > 0) {
       if (!rptd || len != rptd_len) {
-        dst.append(line, (size_t)snprintf(line, sizeof(line), "variableStep chrom=%s span=%d\n", name.c_str(), (int)len));
+        dst += head;
+        char* p = put(line, len);
+        *p++ = '\n';
+        dst.append(line, (size_t)(p - line));
         rptd = true; rptd_len = len;
       }
-      dst.append(line, (size_t)snprintf(line, sizeof(line), "%d %d\n", (int)loci, (int)(uint32_t)((cnts + len - 1) / len)));
+      char* p = put(line, loci);
+      *p++ = ' ';
+      p = put(p, (uint32_t)(q + (r > 0 ? 1 : 0)));  // (cnts + len - 1) / len
+      *p++ = '\n';
+      dst.append(line, (size_t)(p - line));
     }
     loci = 0; len = 0; cnts = 0;
   };
   for (uint32_t l = 0; l < clen; l++) {
-    const uint32_t c = cov[l];
+    const uint64_t c = cov[l];
     if (!started || len >= 100000u || c == 0) {
       if (started) complete(o.body);
-      if (c > 0) { started = true; loci = l; len = 1; cnts = c; }
+      if (c > 0) { started = true; loci = l; len = 1; cnts = c; q = c; r = 0; }
       continue;
     }
-    if (len == 0 || cnts == 0) { loci = l; len = 1; cnts = c; continue; }
-    const uint32_t mean100 = 100u * (uint32_t)(cnts / (uint64_t)len);
-    if ((c <= 5 && (c * 100) != mean100) || (mean100 < (c * 75) || mean100 >= (c * 125))) {
+    if (len == 0 || cnts == 0) { loci = l; len = 1; cnts = c; q = c; r = 0; continue; }
+    if ((c <= 5 && c != q) || 4 * q < 3 * c || 4 * q >= 5 * c) {
       complete(o.body);
-      loci = l; len = 1; cnts = c;
+      loci = l; len = 1; cnts = c; q = c; r = 0;
       continue;
     }
     cnts += c;
-    len = l - loci + 1;
+    len = l - loci + 1;  // (= len + 1: the loci of a span follow each other)
+    r += (int64_t)c - (int64_t)q;
+    while (r >= (int64_t)len) { q++; r -= len; }
+    while (r < 0) { q--; r += len; }
   }
   complete(o.tail);
   return o;
+}
+// `width` bytes per locus (k4k_snp_coverage)
+static WigOut wig_chromosome(std::unique_ptr<uint8_t[]> cov, int width, uint32_t clen, std::string name) {
+  if (width == 1) return wig_walk<uint8_t>(cov.get(), clen, name);
+  if (width == 2) return wig_walk<uint16_t>((const uint16_t*)cov.get(), clen, name);
+  return wig_walk<uint32_t>((const uint32_t*)cov.get(), clen, name);
 }
 
 struct Buf {
@@ -367,7 +404,7 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
   if (wig) { *wig = nullptr; *wig_bytes = 0; }
   struct WigJob { std::future<WigOut> f; bool close_tail; };
   std::vector<WigJob> wig_jobs;  // one per chromosome with alignments, in chromosome order
-  Buf covb;
+  Buf covb, covmax;
   if (n_snps) *n_snps = 0;
   if (n_units < 0 || min_snp_reads < 1 || qvalue < 0.0 || snp_nonref_pcnt < 0.0) return k4_fail(ix, K4_ERR_PARAMS, "SNP parameters out of range");
   if (n_units > 0 && ((pe && !d_pe) || (!pe && (!d_rr || !d_hits || max_ml < 1)) || !d_reads || !d_offs || !d_lens))
@@ -423,15 +460,24 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
     K4_HIP(ix, hipStreamSynchronize(st));
     if (t3[2] == 0) continue;  // no alignment on this chromosome
     size_t wig_slot = 0;
-    if (wig) {  // coverage down to the host, its walk on a thread of its own (at most four chromosomes in flight: 4 bytes per locus each)
-      if (!covb.p) K4_HIP(ix, covb.alloc(S * 4));
-      hipLaunchKernelGGL(k4k_snp_coverage, dim3((a.clen + 255) / 256), dim3(256), 0, st, a.cnt, a.cnt + K4_SNP_STRIDE(a), a.clen, covb.as<uint32_t>());
-      std::unique_ptr<uint32_t[]> cov(new uint32_t[(size_t)a.clen + 1]);
-      K4_HIP(ix, hipMemcpyAsync(cov.get(), covb.p, (size_t)a.clen * 4, hipMemcpyDeviceToHost, st));
+    if (wig) {  // coverage down to the host, its walk on a thread of its own (at most twelve chromosomes in flight)
+      if (!covb.p) { K4_HIP(ix, covb.alloc(S * 4)); K4_HIP(ix, covmax.alloc(4)); }
+      K4_HIP(ix, hipMemsetAsync(covmax.p, 0, 4, st));
+      hipLaunchKernelGGL(k4k_snp_coverage_max, dim3(1024), dim3(256), 0, st, a.cnt, a.cnt + K4_SNP_STRIDE(a), a.clen, covmax.as<uint32_t>());
+      uint32_t mx = 0;
+      K4_HIP(ix, hipMemcpyAsync(&mx, covmax.p, 4, hipMemcpyDeviceToHost, st));
       K4_HIP(ix, hipStreamSynchronize(st));
-      if (wig_jobs.size() >= 4) wig_jobs[wig_jobs.size() - 4].f.wait();
+      const int width = mx < 256 ? 1 : mx < 65536 ? 2 : 4;
+      const dim3 cg((a.clen + 255) / 256);
+      if (width == 1) hipLaunchKernelGGL(k4k_snp_coverage<uint8_t>, cg, dim3(256), 0, st, a.cnt, a.cnt + K4_SNP_STRIDE(a), a.clen, covb.as<uint8_t>());
+      else if (width == 2) hipLaunchKernelGGL(k4k_snp_coverage<uint16_t>, cg, dim3(256), 0, st, a.cnt, a.cnt + K4_SNP_STRIDE(a), a.clen, covb.as<uint16_t>());
+      else hipLaunchKernelGGL(k4k_snp_coverage<uint32_t>, cg, dim3(256), 0, st, a.cnt, a.cnt + K4_SNP_STRIDE(a), a.clen, covb.as<uint32_t>());
+      std::unique_ptr<uint8_t[]> cov(new uint8_t[((size_t)a.clen + 1) * (size_t)width]);
+      K4_HIP(ix, hipMemcpyAsync(cov.get(), covb.p, (size_t)a.clen * (size_t)width, hipMemcpyDeviceToHost, st));
+      K4_HIP(ix, hipStreamSynchronize(st));
+      if (wig_jobs.size() >= 12) wig_jobs[wig_jobs.size() - 12].f.wait();
       wig_slot = wig_jobs.size();
-      wig_jobs.push_back({std::async(std::launch::async, wig_chromosome, std::move(cov), a.clen, std::string(e.name)), false});
+      wig_jobs.push_back({std::async(std::launch::async, wig_chromosome, std::move(cov), width, a.clen, std::string(e.name)), false});
     }
     // prefix sums over [0, clen]: element l = sum of the loci below l (the arrays are zero behind clen)
     K4_HIP(ix, rocprim::exclusive_scan(tmp.p, tb, a.cnt, pref.as<uint64_t>(), (uint64_t)0, (size_t)a.clen + 1, rocprim::plus<uint64_t>(), st));
@@ -556,18 +602,31 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
       text.append(line, (size_t)n);
     }
   }
-  if (wig) {
-    std::string w = "track type=wiggle_0 name=\"Coverage\" description=\"Alignment Segment Coverage\" useScore=1\n";  // :8235
+  if (wig) {  // header + the chromosomes' texts, copied side by side into the one block the caller gets (gigabytes at low coverage)
+    const std::string hdr = "track type=wiggle_0 name=\"Coverage\" description=\"Alignment Segment Coverage\" useScore=1\n";  // :8235
+    std::vector<WigOut> parts;
+    parts.reserve(wig_jobs.size());
+    std::vector<size_t> at;
+    size_t total = hdr.size();
     for (WigJob& j : wig_jobs) {
-      WigOut o = j.f.get();
-      w += o.body;
-      if (j.close_tail) w += o.tail;
+      parts.push_back(j.f.get());
+      if (!j.close_tail) parts.back().tail.clear();
+      at.push_back(total);
+      total += parts.back().body.size() + parts.back().tail.size();
     }
-    char* wo = (char*)malloc(w.size() + 1);
+    char* wo = (char*)malloc(total + 1);
     if (!wo) return k4_fail(ix, K4_ERR_MEM, "out of memory");
-    memcpy(wo, w.c_str(), w.size() + 1);
+    memcpy(wo, hdr.data(), hdr.size());
+    std::vector<std::future<void>> cp;
+    for (size_t k = 0; k < parts.size(); k++)
+      cp.push_back(std::async(std::launch::async, [&, k] {
+        memcpy(wo + at[k], parts[k].body.data(), parts[k].body.size());
+        memcpy(wo + at[k] + parts[k].body.size(), parts[k].tail.data(), parts[k].tail.size());
+      }));
+    for (std::future<void>& f : cp) f.get();
+    wo[total] = 0;
     *wig = wo;
-    *wig_bytes = w.size();
+    *wig_bytes = total;
   }
   char* out = (char*)malloc(text.size() + 1);
   if (!out) return k4_fail(ix, K4_ERR_MEM, "out of memory");

@@ -691,9 +691,28 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
                                                                                 {stem + ".trisnp.csv", sf.trisnp, sf.trisnp_bytes},
                                                                                 {o.snp_file, sf.snp, sf.snp_bytes}};
       std::string failed;
-      for (const auto& f : files) {
+      for (const auto& f : files) {  // (the coverage WIG of a genome at low coverage runs to gigabytes: pwrite()s side by side)
         FILE* fp = fopen(f.name.c_str(), "wb");
-        bool ok = fp && fwrite(f.p, 1, f.n, fp) == f.n;
+        bool ok = fp != nullptr;
+        if (ok && f.n >= (64u << 20)) {
+          const int fd = fileno(fp);
+          const int nt = std::max(o.io_threads, 1);
+          std::atomic<bool> good(true);
+          std::vector<std::thread> th;
+          for (int t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+              const uint64_t a = f.n * (uint64_t)t / nt, b = f.n * (uint64_t)(t + 1) / nt;
+              uint64_t done = a;
+              while (done < b) {
+                const ssize_t g = pwrite(fd, f.p + done, b - done, (off_t)done);
+                if (g <= 0) { good = false; return; }
+                done += (uint64_t)g;
+              }
+            });
+          for (std::thread& x : th) x.join();
+          ok = good;
+        } else if (ok)
+          ok = fwrite(f.p, 1, f.n, fp) == f.n;
         if (fp && fclose(fp) != 0) ok = false;
         if (!ok && failed.empty()) failed = f.name;
       }

@@ -58,7 +58,10 @@ print("reads written (%.1f GB) in %.1fs" % (os.path.getsize(fq) / 1e9, time.time
 res = {"workload": "C2: %d x 100 bp FASTQ reads (%.1f GB) vs 3 Gbp .sfx (%.1f GB), files in tmpfs, kalign -s2" % (n_reads, os.path.getsize(fq) / 1e9, os.path.getsize(sfx) / 1e9)}
 exe = os.path.join(ROOT, "kit4b_amd", "k4align")
 sams = {}
+only = os.environ.get("K4_E2E_TAGS", "").split(",") if os.environ.get("K4_E2E_TAGS") else None  # a subset of the runs below
 for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r01", ["-Z"]), ("bam_z6_t16", ["-t", "16"]), ("bam_z1_t16", ["-t", "16", "-z", "1"]), ("snp_p5", ["-p", "5"])):
+    if only and tag not in only:
+        continue
     sam = os.path.join(tmp, tag + (".bam" if tag.startswith("bam") else ".sam"))
     t0 = time.time()
     p = subprocess.run([exe, "-I", sfx, "-i", fq, "-o", sam, "-s2"] + extra, capture_output=True, text=True)
@@ -74,7 +77,9 @@ for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r0
     if tag.startswith("snp"):
         snp_line = [l for l in p.stderr.splitlines() if "putative SNPs" in l]
         res[tag]["snp_report"] = snp_line[-1] if snp_line else None
-        for f in (sam, sam + ".snp"):
+        side = [sam + ext for ext in (".covsegs.wig", ".disnp.csv", ".trisnp.csv")]
+        res[tag]["side_files_GB"] = {os.path.basename(f): os.path.getsize(f) / 1e9 for f in side if os.path.exists(f)}
+        for f in [sam, sam + ".snp"] + side:
             if os.path.exists(f):
                 os.remove(f)
     elif tag.startswith("bam"):
