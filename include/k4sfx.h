@@ -366,6 +366,14 @@ int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, const void* d_r
                           const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
                           const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
                           uint8_t* chrom_hit, void* stream);
+/* k4_format_sam_all_dev <- kalign -M1 (eFMsamAll; WriteBAMReadHits KAligner.cpp:5846-5866, the unaligned branch of ReportBAMread
+ * :6253-6276): the same body followed by one record per loaded read that was not accepted, grouped by NAR code in ascending order
+ * (SortHitMatch sorts on NAR first; within a code the reference's order is undefined, here load order):
+ * QNAME FLAG(4; PE: 1|2|64/128|4 and the mate's 8 or 32) * 0 128 <len>M * 0 0 SEQ(as read) * <empty field> YU:Z:<two-letter NAR> */
+int k4_format_sam_all_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                          const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
+                          const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
+                          uint8_t* chrom_hit, void* stream);
 /* k4_format_bam_dev <- the same alignments as uncompressed BAM records in coordinate order (CSAMfile::AddAlignment's BAM branch,
  * SAMfile.cpp:2379-2640: block_size, refID, pos, bin<<16|MAPQ<<8|l_read_name, FLAG<<16|n_cigar_op, l_seq, next_refID,
  * next_pos, tlen, read_name, cigar, 4-bit seq -- reverse complemented for a Crick alignment --, qual 0xff).  refID is the
@@ -460,6 +468,8 @@ int k4_pipeline_wait_aligned(k4_pipeline* pl, k4_pipeline_view* view); /* after 
 int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit /* host, n_entries + 1, or NULL */, uint64_t* sam_bytes);
 /* ... as BAM records (k4_format_bam_dev); the pieces come down through k4_pipeline_next_sam / k4_pipeline_read_sam all the same */
 int k4_pipeline_format_bam(k4_pipeline* pl, int32_t sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* bam_bytes);
+/* ... as SAM text with every loaded read (k4_format_sam_all_dev, kalign -M1) */
+int k4_pipeline_format_all(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* sam_bytes);
 int k4_pipeline_next_sam(k4_pipeline* pl, const void** ptr, uint64_t* bytes); /* valid until the next call; 0 bytes: done */
 int k4_pipeline_read_sam(k4_pipeline* pl, void* dst, uint64_t cap, uint64_t* bytes); /* the whole body into caller memory */
 void k4_pipeline_close(k4_pipeline* pl);

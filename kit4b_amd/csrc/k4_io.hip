@@ -463,6 +463,7 @@ struct K4SamArgs {
   const uint8_t* cname_len;
   uint32_t n_entries;
   const int32_t* refid;         // BAM: chromosome id - 1 -> index in the header's reference dictionary
+  int all_reads;                // `-M1` (eFMsamAll): the reads that were not accepted are reported too, as unaligned records
 };
 #define K4_SAM_NAME_STRIDE 96
 
@@ -472,11 +473,26 @@ K4_DEV int k4d_sam_nar(const K4SamArgs& a, int64_t i) { return a.pe ? a.pr[i].na
 K4_DEV int64_t k4d_sam_read(const K4SamArgs& a, int64_t v) { return a.pe ? v : v / a.max_ml; }
 K4_DEV k4_hit k4d_sam_hit(const K4SamArgs& a, int64_t v) { return a.pe ? a.pr[v].hit : a.hits[v]; }
 K4_DEV bool k4d_sam_reported(const K4SamArgs& a, int64_t v) {
-  if (a.pe) return a.pr[v].nar == K4_NAR_ACCEPTED;
+  if (a.pe) return a.pr[v].nar == K4_NAR_ACCEPTED || (a.all_reads && a.lens[v] != 0);
   const int64_t i = v / a.max_ml;
   const k4_read_result r = a.rr[i];
-  return r.nar == K4_NAR_ACCEPTED && (int)(v - i * a.max_ml) < max(r.num_hits, 1);
+  if (r.nar != K4_NAR_ACCEPTED) return a.all_reads && v == i * a.max_ml && a.lens[i] != 0;  // one record, if the read was loaded
+  return (int)(v - i * a.max_ml) < max(r.num_hits, 1);
 }
+// a line of a read that was not accepted (only with all_reads)
+K4_DEV bool k4d_sam_unaligned(const K4SamArgs& a, int64_t v) { return a.all_reads && k4d_sam_nar(a, k4d_sam_read(a, v)) != K4_NAR_ACCEPTED; }
+// the unaligned record of `-M1` (ReportBAMread's last branch, KAligner.cpp:6253-6276, as CSAMfile::AddAlignment prints it):
+//   QNAME FLAG * 0 128 <len>M * 0 0 SEQ * <empty> YU:Z:<NAR code>     FLAG: 4, PE: 1 | 2 | 64 / 128 | 4 and the mate's 8 or 32
+K4_DEV uint32_t k4d_sam_unaligned_flag(const K4SamArgs& a, int64_t i) {
+  if (!a.pe) return 0x4u;
+  const k4_pe_read me = a.pr[i], mt = a.pr[i ^ 1];
+  uint32_t f = 0x1u | 0x2u | ((i & 1) ? 0x80u : 0x40u) | 0x4u;
+  if (me.pe_aligned && mt.pe_aligned && mt.nar == K4_NAR_ACCEPTED) f |= mt.hit.strand != '+' ? 0x20u : 0u;
+  else f |= 0x8u;
+  return f;
+}
+#define K4_SAM_UNALIGNED_TAIL 12  // "\t*\t\tYU:Z:xx\n"
+__device__ const char k4_nar_codes[] = "NAAAENNLMHMLETOJOMDPDSFCPRUIOIUPISITNPLC";  // m_NARdesc, KAligner.cpp:48-67
 
 struct K4SamFields {
   uint32_t flag, pos, mapq, pnext;
@@ -566,6 +582,7 @@ __global__ void __launch_bounds__(256) k4k_sam_key_minor(K4SamArgs a, const uint
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
   const int64_t v = idx[j];
+  if (k4d_sam_unaligned(a, v)) { key[j] = 0; return; }  // (SortHitMatch leaves them in no defined order within a NAR: load order here)
   const k4_hit h = k4d_sam_hit(a, v);
   // AdjHitLen(Seg[0]), Strand, then the READ's LowMMCnt (both segments' mismatches for a two-segment hit)
   const int64_t i = k4d_sam_read(a, v);
@@ -575,6 +592,11 @@ __global__ void __launch_bounds__(256) k4k_sam_key_minor(K4SamArgs a, const uint
 __global__ void __launch_bounds__(256) k4k_sam_key_major(K4SamArgs a, const uint32_t* __restrict__ idx, uint64_t m, uint64_t* __restrict__ key) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
+  if (k4d_sam_unaligned(a, idx[j])) {  // behind every accepted alignment, by NAR (SortHitMatch: NAR first; accepted is the lowest in use)
+    const int nar = k4d_sam_nar(a, k4d_sam_read(a, idx[j]));
+    key[j] = (uint64_t)(a.n_entries + 1u + (uint32_t)(nar & 31)) << 32;
+    return;
+  }
   const k4_hit h = k4d_sam_hit(a, idx[j]);
   key[j] = ((uint64_t)h.chrom_id << 32) | k4d_adj_start(h);
 }
@@ -604,6 +626,13 @@ __global__ void __launch_bounds__(256) k4k_sam_stats(K4SamArgs a, unsigned long 
 }
 
 K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t v) {
+  if (k4d_sam_unaligned(a, v)) {
+    const int64_t i = k4d_sam_read(a, v);
+    const int w = a.pe ? (int)(i & 1) : 0;
+    const int64_t rec = a.pe ? (i >> 1) : i;
+    return a.name_len[w][rec] + 1 + k4d_udigits(k4d_sam_unaligned_flag(a, i)) + 1 + 2 /* "*\t" */ + 2 /* "0\t" */ + 4 /* "128\t" */ +
+           k4d_udigits(a.lens[i]) + 2 /* "M\t" */ + 2 /* "*\t" */ + 2 + 2 /* "0\t0\t" */ + a.lens[i] + K4_SAM_UNALIGNED_TAIL;
+  }
   const k4_hit h = k4d_sam_hit(a, v);
   const K4SamFields f = k4d_sam_fields(a, v, h);
   const int64_t i = k4d_sam_read(a, v);
@@ -718,8 +747,28 @@ K4_DEV uint32_t k4d_read4(const uint32_t* __restrict__ s32, uint32_t sh, uint32_
 K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int64_t i, char* line, uint32_t line_len, int sub,
                              int lpl) {
   const uint32_t len = a.lens[i];
-  char* seq = line + line_len - 3 - len;
-  if (sub == 0) {
+  const bool unal = k4d_sam_unaligned(a, v);
+  char* seq = line + line_len - (unal ? K4_SAM_UNALIGNED_TAIL : 3) - len;
+  if (sub == 0 && unal) {
+    const int w = a.pe ? (int)(i & 1) : 0;
+    const int64_t rec = a.pe ? (i >> 1) : i;
+    char* p = line;
+    const uint8_t* nm = a.text[w] + a.name_off[w][rec];
+    const uint32_t nl_ = a.name_len[w][rec];
+    for (uint32_t q = 0; q < nl_; q++) p[q] = (char)nm[q];
+    p += nl_;
+    *p++ = '\t'; p += k4d_put_uint(p, k4d_sam_unaligned_flag(a, i));
+    const char mid[] = "\t*\t0\t128\t";
+    for (int q = 0; q < 9; q++) *p++ = mid[q];
+    p += k4d_put_uint(p, len);
+    const char mid2[] = "M\t*\t0\t0\t";
+    for (int q = 0; q < 8; q++) *p++ = mid2[q];
+    const int nar = k4d_sam_nar(a, i);
+    const int code = nar >= 0 && nar < 20 ? nar : 0;
+    char* t = seq + len;
+    t[0] = '\t'; t[1] = '*'; t[2] = '\t'; t[3] = '\t'; t[4] = 'Y'; t[5] = 'U'; t[6] = ':'; t[7] = 'Z'; t[8] = ':';
+    t[9] = k4_nar_codes[2 * code]; t[10] = k4_nar_codes[2 * code + 1]; t[11] = '\n';
+  } else if (sub == 0) {
     const K4SamFields f = k4d_sam_fields(a, v, h);
     const int w = a.pe ? (int)(i & 1) : 0;
     const int64_t rec = a.pe ? (i >> 1) : i;
@@ -751,7 +800,7 @@ K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int
   const uint32_t span = len + sh;
   const uint32_t q0 = (uint32_t)((uint64_t)len * sub / lpl), q1 = (uint32_t)((uint64_t)len * (sub + 1) / lpl);
   const uint64_t fwd = 0x4E4E4E4E54474341ull, rev = 0x4E4E4E4E41434754ull;  // "ACGTNNNN" / "TGCANNNN" by symbol (:6279)
-  if (h.strand == '+') {
+  if (unal || h.strand == '+') {
     for (uint32_t q = q0; q < q1; q += 4) {
       const uint32_t d = k4d_read4(s32, sh, span, q);
 #pragma unroll
@@ -880,6 +929,14 @@ extern "C" int k4_format_sam_ext_dev(k4_index* ix, int pe, int64_t n_units, cons
   return k4i_format_records(ix, 0, 0, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_sam, sam_bytes, stats,
                             chrom_hit, stream, nullptr, nullptr);
 }
+// `-M1` (eFMsamAll): the SAM body with the reads that were not accepted reported too, as unaligned records behind the alignments
+extern "C" int k4_format_sam_all_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                                     const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
+                                     const void* d_lens, const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes,
+                                     k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
+  return k4i_format_records(ix, 2, 0, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_sam, sam_bytes, stats,
+                            chrom_hit, stream, nullptr, nullptr);
+}
 extern "C" int k4_format_bam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                                  const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
                                  const void* d_lens, const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes,
@@ -893,6 +950,8 @@ int k4i_format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_unit
                        k4_sam_stats* stats, uint8_t* chrom_hit, void* stream, K4SamSlices* slices, K4PoolBuf* out_buf) {
   if (!ix || !names || !d_sam || !sam_bytes) return K4_ERR_PARAMS;
   if (slices) slices->clear();
+  const bool all_reads = bam == 2;  // SAM text with the reads that were not accepted behind the alignments (`-M1`)
+  if (all_reads) bam = 0;
   *d_sam = nullptr;
   *sam_bytes = 0;
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -933,6 +992,7 @@ int k4i_format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_unit
     a.name_len[w] = (const uint32_t*)names->d_name_len[w];
   }
   a.cnames = cn.as<char>(); a.cname_len = cl.as<uint8_t>(); a.n_entries = ne;
+  a.all_reads = all_reads ? 1 : 0;
 
   Buf stb, chb, cnt, idx0, idx1, k32a, k32b, k64a, k64b, tmp, ll, lo;
   K4_HIP(ix, stb.alloc(22 * 8));
@@ -998,7 +1058,7 @@ int k4i_format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_unit
     rocprim::double_buffer<uint64_t> kb2(k64a.as<uint64_t>(), k64b.as<uint64_t>());
     size_t tb2 = 0;
     unsigned top = 33;  // key = chrom << 32 | start: only the bits chromosome ids can reach are sorted on
-    while (top < 64 && (a.n_entries >> (top - 32)) != 0) top++;
+    while (top < 64 && ((a.n_entries + (all_reads ? 33u : 0u)) >> (top - 32)) != 0) top++;
     K4_HIP(ix, rocprim::radix_sort_pairs(nullptr, tb2, kb2, vb, (size_t)m, 0u, top, st));
     Buf t3;
     K4_HIP(ix, t3.alloc(tb2));

@@ -462,6 +462,10 @@ extern "C" int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t*
 }
 // the same alignments as BAM records (uncompressed, coordinate order): the caller deflates them into BGZF blocks as the pieces
 // come down (k4_pipeline_next_sam) and writes header and index
+// `-M1`: SAM text with the reads that were not accepted behind the alignments (k4_format_sam_all_dev)
+extern "C" int k4_pipeline_format_all(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* sam_bytes) {
+  return pipeline_format(pl, 2, 0, stats, chrom_hit, sam_bytes);
+}
 extern "C" int k4_pipeline_format_bam(k4_pipeline* pl, int32_t sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* bam_bytes) {
   return pipeline_format(pl, 1, sq_all, stats, chrom_hit, bam_bytes);
 }

@@ -51,6 +51,7 @@ struct Opts {
   int rank = 0, n_ranks = 1;        // this process's place in a -G run
   struct MultiShared* shared = nullptr;
   int print_slices = 0;             // -W <n>: print the byte offsets -G would cut the reads files at for n ranks, and stop (no GPU needed)
+  int fmode = 0;                    // -M <0|1>: 0 SAM / BAM with the accepted alignments, 1 SAM with every loaded read (KAlignerCL.cpp:217)
   bool legacy = false;              // -Z: the serial whole-input path of round 1 (one batch, no overlap), kept for comparison
   int chunk_mb = 256;               // -B <MB>: size of one pinned upload buffer of the pipeline
   int io_threads = 8;               // -t <n>: concurrent pread / pwrite calls per buffer; BAM: deflate threads
@@ -379,7 +380,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam|out.bam [-z bgzf level=6] [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
 }  // namespace
@@ -722,6 +723,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
                           (unsigned long long)sf.n_snps, o.snp_file.c_str(), secs(ts, now()));
     }
     if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= 10000 ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
+    else if (o.fmode == 1) CK(k4_pipeline_format_all(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     else CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     s_align = secs(tg, now());
     n_under = v.n_under; n_over = v.n_over; n_units = (uint64_t)v.n_units;
@@ -1024,6 +1026,7 @@ int main(int argc, char** argv) {
       case 'b': o.batch_mb = atof(val().c_str()); break;
       case 'B': o.chunk_mb = std::max(1, atoi(val().c_str())); break;
       case 't': o.io_threads = std::max(1, atoi(val().c_str())); break;
+      case 'M': o.fmode = atoi(val().c_str()); break;
       case 'Z': o.legacy = true; break;
       case 'z': o.bam_level = std::min(9, std::max(0, atoi(val().c_str()))); break;
       case 'W': o.print_slices = atoi(val().c_str()); break;
@@ -1071,6 +1074,18 @@ int main(int argc, char** argv) {
   if (pe && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDel '-a' / splice junction '-A' processing not supported in paired end processing\n"); return 1; }
   if (o.ml_mode == 5 && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDels / splice junctions not supported when reporting multiloci alignments '-r5'\n"); return 1; }
   if (o.min_chimeric && (o.best || o.ml_mode == 3 || o.ml_mode == 4)) { fprintf(stderr, "k4align: chimeric read processing cannot be combined with -N / -r3 / -r4\n"); return 1; }
+  // output format (KAlignerCL.cpp:217,514-519): -M0 the accepted alignments, -M1 every loaded read; -M2 (BED) and -M3 (packed base
+  // alleles) are not built
+  if (o.fmode < 0 || o.fmode > 3) { fprintf(stderr, "k4align: output format mode '-M%d' specified outside of range 0..3\n", o.fmode); return 1; }
+  if (o.fmode >= 2) { fprintf(stderr, "k4align: output format -M%d (BED / packed base alleles) is not built\n", o.fmode); return 3; }
+  if (o.fmode == 1) {
+    const bool bam = o.out.size() >= 4 && strcasecmp(o.out.c_str() + o.out.size() - 4, ".bam") == 0;
+    if (bam || o.batch_mb > 0 || o.n_shards > 1 || !o.gpus.empty() || o.legacy || o.ml_mode == 5) {
+      fprintf(stderr, "k4align: -M1 writes SAM text from the pipelined single-GPU mode (not BAM, -b, -S i/N, -G, -Z, -r5)\n");
+      return 3;
+    }
+    if (o.min_snp_reads > 0 || !o.snp_file.empty()) { fprintf(stderr, "k4align: SNP calling is not available in '-M1' output mode\n"); return 1; }  // KAlignerCL.cpp:935
+  }
   // SNP calling (KAlignerCL.cpp:877-945): -S alone means -p20; -p alone writes <out>.snp; -P defaults to 0.05
   if (!o.snp_file.empty() && o.min_snp_reads == 0) o.min_snp_reads = 20;
   if (o.min_snp_reads != 0 && (o.min_snp_reads < 1 || o.min_snp_reads > 100)) { fprintf(stderr, "k4align: minimum read coverage at any loci '-p%d' must be in range 1..100\n", o.min_snp_reads); return 1; }

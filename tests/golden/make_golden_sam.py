@@ -71,6 +71,11 @@ PE_CASES = {
 }
 
 
+# `-M1` (eFMsamAll): the same runs with every loaded read in the SAM -- the reads that were not accepted follow the alignments as
+# unaligned records with a YU:Z:<NAR> tag.  The reads are those of the base case (no second copy); kept in sam_all_cases.json
+ALL_READS_CASES = {"se_s2_M1": "se_s2", "se_c50_M1": "se_c50", "pe_u1_M1": "pe_u1", "pe_c60_u3_wide_M1": "pe_c60_u3_wide"}
+
+
 def foreign_flanks(reads, frac, seed):
     """a share of the reads gets 5..35 % of random sequence at its 5' and / or 3' end (chimeric reads)"""
     import numpy as np
@@ -171,6 +176,29 @@ def main():
                     g.write(f.read())
             meta[name] = dict(args=args, nar=hist)
             print(name, hist)
+        if not ONLY or any(c in ONLY for c in ALL_READS_CASES):
+            base_meta = meta if not ONLY else json.load(open(os.path.join(HERE, "sam_cases.json")))
+            all_meta = {}
+            for name, base in ALL_READS_CASES.items():
+                b = base_meta[base]
+                sfx = os.path.join(HERE, "g1.sfx")
+                if b.get("index"):
+                    sfx = os.path.join(tmp, b["index"] + ".sfx")
+                    if not os.path.exists(sfx):
+                        with lzma.open(os.path.join(HERE, b["index"] + ".sfx.xz"), "rb") as f, open(sfx, "wb") as g:
+                            g.write(f.read())
+                files = []
+                for flag, suffix in (("-i", "_1"), ("-u", "_2")) if base.startswith("pe") else (("-i", ""),):
+                    fa = os.path.join(tmp, "%s%s.all.fa" % (base, suffix))
+                    with lzma.open(os.path.join(HERE, "sam_%s%s.fa.xz" % (base, suffix)), "rb") as f, open(fa, "wb") as g:
+                        g.write(f.read())
+                    files += [flag, fa]
+                hist = run(tmp, name, b["args"] + ["-M1"], files, sfx=sfx)
+                all_meta[name] = dict(args=b["args"] + ["-M1"], nar=hist, reads_of=base, **({"index": b["index"]} if b.get("index") else {}))
+                print(name, hist)
+            json.dump(all_meta, open(os.path.join(HERE, "sam_all_cases.json"), "w"), indent=1, sort_keys=True)
+    if ONLY and not any(c in ONLY for c in list(CASES) + list(CLUSTER_CASES) + list(EXT_CASES) + list(PE_CASES)):
+        return  # only -M1 cases were asked for: sam_cases.json stays as it is
     json.dump(meta, open(os.path.join(HERE, "sam_cases.json"), "w"), indent=1, sort_keys=True)
 
 

@@ -72,12 +72,27 @@ def cigar_mapq(h, seg2, read_len):
     return ops, min(254, max(1, int(mq * (aligned / read_len))))
 
 
-def sam_records(names, reads, results, chrom_names, paired=False):
+NAR_CODES = ["NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"]  # m_NARdesc, KAligner.cpp:48-67
+
+
+def sam_records(names, reads, results, chrom_names, paired=False, all_reads=False):
     """results: per read dict(nar, hit(chrom_id, match_loci, match_len, strand, reserved=ext), pe_aligned[, seg2]); for paired
-    input reads are interleaved PE1, PE2.  Returns the SAM lines kit4b would write for the accepted reads (unsorted)."""
+    input reads are interleaved PE1, PE2.  Returns the SAM lines kit4b would write for the accepted reads (unsorted); all_reads:
+    kalign -M1, the other reads too, as unaligned records (ReportBAMread's last branch, KAligner.cpp:6253-6276)."""
     out = []
     for i, (nm, rd, r) in enumerate(zip(names, reads, results)):
         if r["nar"] != 1:
+            if all_reads:
+                flag = 0x4
+                if paired:
+                    mate = results[i ^ 1]
+                    flag |= 0x1 | 0x2 | (0x40 if i % 2 == 0 else 0x80)
+                    if r["pe_aligned"] and mate["pe_aligned"] and mate["nar"] == 1:
+                        flag |= 0x20 if mate["hit"]["strand"] == ord("-") else 0
+                    else:
+                        flag |= 0x8
+                seq = "".join("ACGTN"[b] if b <= 3 else "N" for b in rd)
+                out.append("\t".join([nm, str(flag), "*", "0", "128", "%dM" % len(rd), "*", "0", "0", seq, "*", "", "YU:Z:" + NAR_CODES[int(r["nar"])]]))
             continue
         h = r["hit"]
         minus = h["strand"] == ord("-")

@@ -546,3 +546,64 @@ def test_k4align_bam_and_snp_outputs_of_a_run_without_alignments(golden_dir, tmp
     assert recs == [] and len(refs) == 5 and text.startswith("@HD")
     assert len(samutil.read_bai(out + ".bai")) == 5
     assert open(out + ".snp").read().count("\n") == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["se_s2_M1", "se_c50_M1", "pe_u1_M1", "pe_c60_u3_wide_M1"])
+def test_k4align_all_reads_mode_writes_the_reference_sam(golden_dir, tmp_path, case):
+    """`-M1` (eFMsamAll): the alignments, then every other loaded read as an unaligned record with its NAR in a YU:Z tag, NAR codes
+    ascending (WriteBAMReadHits / ReportBAMread, KAligner.cpp:5846-5866, 6253-6276) -- against what `ngskit4b kalign -M1` wrote.
+    Within one NAR code the reference's order is not defined (SortHitMatch returns 0): compared as sets there."""
+    import json
+    import lzma
+    import subprocess
+
+    import samutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(golden_dir, "sam_all_cases.json")))[case]
+    base = meta["reads_of"]
+
+    def unxz(name):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        return dst
+
+    files = ["-i", unxz("sam_%s_1.fa.xz" % base), "-u", unxz("sam_%s_2.fa.xz" % base)] if base.startswith("pe_") else ["-i", unxz("sam_%s.fa.xz" % base)]
+    sfx = unxz("g3.sfx.xz") if meta.get("index") == "g3" else os.path.join(golden_dir, "g1.sfx")
+    out = str(tmp_path / "o.sam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", sfx, "-o", out] + meta["args"] + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    got = [l for l in open(out).read().split("\n") if l and not l.startswith("@")]
+    _, want = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    n_acc = meta["nar"]["AA"]
+    assert len(got) == len(want) and got[:n_acc] == want[:n_acc]  # the alignments: line for line
+    code = lambda l: samutil.NAR_CODES.index(l.rsplit("YU:Z:", 1)[1])  # noqa: E731
+    assert [code(l) for l in got[n_acc:]] == [code(l) for l in want[n_acc:]]  # the same NAR groups in the same order
+    assert sorted(got[n_acc:]) == sorted(want[n_acc:])
+    assert any(l.endswith("\t*\t\tYU:Z:NL") for l in got)
+    for name, n in meta["nar"].items():
+        assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+
+
+@pytest.mark.gpu
+def test_all_reads_mode_option_rules(golden_dir, tmp_path):
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa = tmp_path / "r.fa"
+    fa.write_text(">r1\n" + "ACGT" * 25 + "\n")
+    base = [os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-i", str(fa)]
+    p = subprocess.run(base + ["-o", str(tmp_path / "o.sam"), "-M7"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "range 0..3" in p.stderr
+    p = subprocess.run(base + ["-o", str(tmp_path / "o.sam"), "-M2"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3 and "not built" in p.stderr
+    for extra in (["-o", str(tmp_path / "o.bam"), "-M1"], ["-o", str(tmp_path / "o.sam"), "-M1", "-r5"], ["-o", str(tmp_path / "o.sam"), "-M1", "-b", "1"]):
+        p = subprocess.run(base + extra, capture_output=True, text=True, timeout=60)
+        assert p.returncode == 3, (extra, p.stderr)
+    p = subprocess.run(base + ["-o", str(tmp_path / "o.sam"), "-M1", "-p5"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "SNP" in p.stderr
+    p = subprocess.run(base + ["-o", str(tmp_path / "o.sam"), "-M1"], capture_output=True, text=True, timeout=120)  # one read, no locus
+    assert p.returncode == 0, p.stderr
+    body = [l for l in open(str(tmp_path / "o.sam")).read().split("\n") if l and not l.startswith("@")]
+    assert body == ["r1\t4\t*\t0\t128\t100M\t*\t0\t0\t" + "ACGT" * 25 + "\t*\t\tYU:Z:NL"]

@@ -186,3 +186,48 @@ def test_reference_dies_on_wide_rescue_window(golden_dir, tmp_path):
                         str(tmp_path / "log2.txt"), "-s2", "-U1", "-d200", "-D600", "-i", files[0], "-u", files[1]],
                        capture_output=True, timeout=300)
     assert r.returncode == 0
+
+
+ALL_CASES = json.load(open(os.path.join(GOLDEN, "sam_all_cases.json")))
+
+
+@pytest.mark.parametrize("case", sorted(ALL_CASES))
+def test_all_reads_mode_matches_reference_sam(oracle, golden_dir, g3_path, case):
+    """kalign -M1 (eFMsamAll): the alignments of the base case, then one unaligned record per read that was not accepted --
+    FLAG 4 (+ the pair bits), RNAME *, POS 0, MAPQ 128, CIGAR <len>M, the read as loaded, an empty field and YU:Z:<NAR> -- grouped
+    by NAR in ascending order behind the alignments (WriteBAMReadHits / ReportBAMread, KAligner.cpp:5846-5866, 6253-6276)"""
+    meta = ALL_CASES[case]
+    base = meta["reads_of"]
+    args = [a for a in meta["args"] if a != "-M1"]
+    kw, pe = kalign_args(args)
+    if base.startswith("pe_"):
+        n1, r1 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_1.fa.xz" % base))
+        n2, r2 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_2.fa.xz" % base))
+        h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+        oracle.set_max_iter(h, 5000)
+        out = oracle_kalign_pe(oracle, h, r1, r2, threads=4, **pe, **kw)
+        check_hist(out["nar"], meta["nar"])
+        names = [x for p in zip(n1, n2) for x in p]
+        reads = [x for p in zip(r1, r2) for x in p]
+        res = [dict(nar=int(o["nar"]), hit=o["hit"], pe_aligned=int(o["pe_aligned"])) for o in out]
+        got = samutil.sam_records(names, reads, res, CHROMS, paired=True, all_reads=True)
+    else:
+        names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % base))
+        h = oracle.open(g3_path if meta.get("index") == "g3" else os.path.join(golden_dir, "g1.sfx"))
+        oracle.set_max_iter(h, 5000)
+        if ext_case(args):
+            r = oracle_se_ext(oracle, h, reads, kw, pe)
+            res = [dict(nar=int(o["nar"]), hit=hh[0], pe_aligned=0, seg2=s2) for o, hh, s2 in zip(r["out"], r["hits"], r["seg2"])]
+        else:
+            r = oracle.kalign_batch(h, reads, **kw)
+            res = [dict(nar=int(o["nar"]), hit=hh[0], pe_aligned=0) for o, hh in zip(r["out"], r["hits"])]
+        check_hist(r["out"]["nar"], meta["nar"])
+        got = samutil.sam_records(names, reads, res, ["chr1", "chr2", "chr3"] if meta.get("index") == "g3" else CHROMS, all_reads=True)
+    _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    assert len(recs) == len(reads) and sorted(got) == sorted(recs)
+    # order in the file: the alignments first (the base case's body, line for line), then the NAR codes ascending
+    _, base_recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % base))
+    assert recs[:len(base_recs)] == base_recs
+    codes = [samutil.NAR_CODES.index(l.rsplit("YU:Z:", 1)[1]) for l in recs[len(base_recs):]]
+    assert codes == sorted(codes) and len(set(codes)) >= 3
+    oracle.close(h)
