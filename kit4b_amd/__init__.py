@@ -639,7 +639,7 @@ class SfxIndex:
                 cnt[key] = c.value
         return (d_rr.cpu().numpy().view(RESULT_DTYPE), d_hits.cpu().numpy().view(HIT_DTYPE).reshape(n, max_ml), cnt)
 
-    def pipeline_sam(self, texts, kp, pe=None, min_len=50, max_len=500, chunk_bytes=0, ring=False, out=None):
+    def pipeline_sam(self, texts, kp, pe=None, min_len=50, max_len=500, chunk_bytes=0, ring=False, out=None, min_batch_units=0, all_reads=False, expect=True):
         """host text (bytes-like / pinned tensors: one for SE, two for PE) -> SAM body through the overlapped pipeline.
         ring=True feeds through acquire / submit (what k4align's reader threads do), else submit_host.  Returns (body or
         number of bytes written into `out`, stats dict, view)."""
@@ -650,6 +650,7 @@ class SfxIndex:
         if pe is not None:
             prm.pe = pe
         prm.min_len, prm.max_len, prm.chunk_bytes = min_len, max_len, chunk_bytes
+        prm.min_batch_units = min_batch_units  # 0: the default (4 M); small values make several alignment batches of a small input
         bufs = []
         for e, t in enumerate(texts):
             if hasattr(t, "data_ptr"):
@@ -657,7 +658,7 @@ class SfxIndex:
             else:
                 a = np.frombuffer(bytes(t), dtype=np.uint8)
                 bufs.append((a.ctypes.data, len(a), a))
-            prm.expect_text_bytes[e] = bufs[-1][1]
+            prm.expect_text_bytes[e] = bufs[-1][1] if expect else 0  # (unknown sizes: the arrays grow by doubling)
         pl = C.c_void_p()
         self._ck(L.k4_pipeline_open(self.h, C.byref(prm), C.byref(pl)))
         try:
@@ -681,7 +682,7 @@ class SfxIndex:
             view = PipelineView()
             self._ck(L.k4_pipeline_wait_aligned(pl, C.byref(view)))
             stats, nbytes = SamStats(), C.c_uint64()
-            self._ck(L.k4_pipeline_format(pl, C.byref(stats), None, C.byref(nbytes)))
+            self._ck((L.k4_pipeline_format_all if all_reads else L.k4_pipeline_format)(pl, C.byref(stats), None, C.byref(nbytes)))
             st = {"nar": list(stats.nar), "plus": stats.plus, "minus": stats.minus, "n_lines": stats.n_lines,
                   "n_units": view.n_units, "n_under": view.n_under, "n_over": view.n_over, "sam_bytes": nbytes.value}
             if out is not None:

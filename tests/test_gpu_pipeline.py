@@ -90,6 +90,44 @@ def test_pipeline_pe_equals_single_batch(ix, k4):
         assert got == want and st["nar"] == wst["nar"] and st["n_units"] == 12000
 
 
+@pytest.mark.parametrize("expect", [True, False])
+def test_pipeline_many_alignment_batches_and_growing_arrays(ix, k4, expect):
+    """small chunks and a small batch threshold: dozens of uploads in flight behind their events, an alignment batch every few
+    chunks, the per-read arrays growing (projected from the input size when it is known, by doubling when not) -- same body"""
+    names, chroms = synth.golden_genome()
+    reads = synth.make_reads(chroms, 60000, 100, seed=911, n_prob=0.03, edge_frac=0.05, random_frac=0.03)[0]
+    text = fastx(reads, True)
+    kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+    want, wst, _ = single_batch_sam(ix, k4, [text], kp, None)
+    for ring in (False, True):
+        got, st, _ = ix.pipeline_sam([text], kp, chunk_bytes=1 << 20, ring=ring, min_batch_units=3000, expect=expect)
+        assert got == want and st["nar"] == wst["nar"] and st["n_units"] == 60000
+    pe1, pe2, _ = synth.make_pe_reads(chroms, 15000, 125, seed=912, n_prob=0.02, random_mate_frac=0.03)
+    t1, t2 = fastx(pe1, True, "a"), fastx(pe2, True, "b")
+    kpp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 10, 1, 0, 0)
+    pe = k4.PeParams(1, 200, 600, 0)
+    want, wst, _ = single_batch_sam(ix, k4, [t1, t2], kpp, pe)
+    got, st, _ = ix.pipeline_sam([t1, t2], kpp, pe=pe, chunk_bytes=1 << 20, ring=True, min_batch_units=1500, expect=expect)
+    assert got == want and st["nar"] == wst["nar"]
+
+
+def test_pipeline_all_reads_body(ix, k4):
+    """k4_pipeline_format_all (-M1): the usual body, then one YU:Z record per loaded read that was not accepted, NAR codes ascending"""
+    names, chroms = synth.golden_genome()
+    reads = synth.make_reads(chroms, 20000, 100, seed=913, n_prob=0.04, edge_frac=0.05, random_frac=0.05)[0] + synth.make_reads(chroms, 30, 30, seed=914)[0]
+    text = fastx(reads, False)
+    kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+    body, st, _ = ix.pipeline_sam([text], kp, chunk_bytes=1 << 20)
+    full, st2, _ = ix.pipeline_sam([text], kp, chunk_bytes=1 << 20, all_reads=True, min_batch_units=4000)
+    assert full.startswith(body) and st2["nar"] == st["nar"]
+    rest = full[len(body):].decode().split("\n")[:-1]
+    assert len(rest) == sum(st["nar"]) - st["nar"][1] and st2["n_lines"] == st["n_lines"] + len(rest)  # (the 30 short reads were never loaded)
+    codes = [l.rsplit("YU:Z:", 1)[1] for l in rest]
+    order = ["EN", "NL", "MH", "ML"]
+    assert [order.index(c) for c in codes] == sorted(order.index(c) for c in codes) and len(set(codes)) >= 3
+    assert all(l.split("\t")[1:9] == ["4", "*", "0", "128", "100M", "*", "0", "0"] for l in rest)
+
+
 def test_pipeline_degenerate_inputs(ix, k4):
     kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
     got, st, _ = ix.pipeline_sam([b""], kp)

@@ -59,7 +59,7 @@ res = {"workload": "C2: %d x 100 bp FASTQ reads (%.1f GB) vs 3 Gbp .sfx (%.1f GB
 exe = os.path.join(ROOT, "kit4b_amd", "k4align")
 sams = {}
 only = os.environ.get("K4_E2E_TAGS", "").split(",") if os.environ.get("K4_E2E_TAGS") else None  # a subset of the runs below
-for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("serial_r01", ["-Z"]), ("bam_z6_t16", ["-t", "16"]), ("bam_z1_t16", ["-t", "16", "-z", "1"]), ("snp_p5", ["-p", "5"])):
+for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("pipelined_t16", ["-t", "16"]), ("serial_r01", ["-Z"]), ("bam_z6_t16", ["-t", "16"]), ("bam_z1_t16", ["-t", "16", "-z", "1"]), ("snp_p5", ["-p", "5"])):
     if only and tag not in only:
         continue
     sam = os.path.join(tmp, tag + (".bam" if tag.startswith("bam") else ".sam"))
