@@ -318,7 +318,7 @@ int k4_kalign_pe_batch_dev(k4_index* ix, const k4_kalign_params* p, const k4_pe_
  *                         number of lines) or FASTQ ('@', four lines per record) text resident in HBM -> etSeqBase reads
  *                         (a/c/g/t/u either case -> 0..3, '-' -> 6, other letters -> 4, anything else sloughed:
  *                         CFasta::ReadSequence / Ascii2Sense, Fasta.cpp:1172,1657), offsets, lengths, and the span of
- *                         each descriptor's first token (<= 127 bytes).  A chunk that is not the last one may end inside a
+ *                         each descriptor up to its first white space (<= 79 bytes; FASTA: behind leading blanks).  A chunk that is not the last one may end inside a
  *                         record: info->consumed tells how many bytes were used; resubmit the rest in front of the next
  *                         chunk.  The bases go to d_reads[reads_base ...) (room for text_bytes + 16 bytes), offs are
  *                         relative to d_reads; name offsets are text_base + offset in this chunk; the per-record arrays

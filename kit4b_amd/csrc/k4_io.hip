@@ -64,10 +64,15 @@ __global__ void __launch_bounds__(256) k4k_fastx_records(K4FastxArgs a) {
   const uint64_t hl = a.fastq ? (uint64_t)4 * r : a.hdr[r];
   uint32_t s0 = k4d_line_start(a.nl, hl), e0 = a.nl[hl];
   bool bad = a.text[s0] != (a.fastq ? '@' : '>');
-  uint32_t p = s0 + 1;
+  // the read's name: the descriptor up to its first white space, at most 79 characters (cMaxDescrIDLen - 1, KAligner.cpp:12268-12275);
+  // a FASTA descriptor starts behind any blanks and tabs that follow the '>' (CFasta, Fasta.cpp:1069-1071; not so in FASTQ)
+  uint32_t p0 = s0 + 1;
+  if (!a.fastq)
+    while (p0 < e0 && (a.text[p0] == ' ' || a.text[p0] == '\t')) p0++;
+  uint32_t p = p0;
   while (p < e0 && !k4d_is_space(a.text[p])) p++;
-  a.name_off[r] = a.text_base + s0 + 1;
-  a.name_len[r] = min(p - (s0 + 1), 127u);
+  a.name_off[r] = a.text_base + p0;
+  a.name_len[r] = min(p - p0, 79u);
   const uint32_t s1 = e0 + 1;
   uint32_t e1;
   if (a.fastq) e1 = a.nl[hl + 1];

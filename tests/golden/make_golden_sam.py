@@ -76,6 +76,23 @@ PE_CASES = {
 ALL_READS_CASES = {"se_s2_M1": "se_s2", "se_c50_M1": "se_c50", "pe_u1_M1": "pe_u1", "pe_c60_u3_wide_M1": "pe_c60_u3_wide"}
 
 
+# read names (QNAME): the descriptor up to its first white space, at most 79 characters; FASTA descriptors start behind the blanks and
+# tabs that follow '>' (FASTQ ones do not).  names.fa / names.fq (the first reads of se_s2) -> names_fa.sam / names_fq.sam, run with -M1
+NAMES = ["A" * 100, "short/1 extra words", "tab\tafter", " leading_space", "\t \ttabs_and_blanks x", "x" * 79, "y" * 80, "z" * 78 + " q",
+         "with|pipe:colon;semi", "UPPER_lower-123.4", "B" * 130 + " tail"]
+
+
+def names_case(tmp):
+    seqs = [l.strip() for l in lzma.open(os.path.join(HERE, "sam_se_s2.fa.xz"), "rt") if not l.startswith(">")]
+    with open(os.path.join(HERE, "names.fa"), "w") as f, open(os.path.join(HERE, "names.fq"), "w") as q:
+        for k, nm in enumerate(NAMES):
+            f.write(">%s\n%s\n" % (nm, seqs[k]))
+            q.write("@%s\n%s\n+\n%s\n" % (nm, seqs[k], "I" * len(seqs[k])))
+    for ext in ("fa", "fq"):
+        subprocess.run([NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", os.path.join(HERE, "names_%s.sam" % ext), "-T", "1", "-F",
+                        os.path.join(tmp, "names.log"), "-s2", "-M1", "-i", os.path.join(HERE, "names." + ext)], check=True, capture_output=True)
+
+
 def foreign_flanks(reads, frac, seed):
     """a share of the reads gets 5..35 % of random sequence at its 5' and / or 3' end (chimeric reads)"""
     import numpy as np
@@ -176,6 +193,8 @@ def main():
                     g.write(f.read())
             meta[name] = dict(args=args, nar=hist)
             print(name, hist)
+        if not ONLY or "names" in ONLY:
+            names_case(tmp)
         if not ONLY or any(c in ONLY for c in ALL_READS_CASES):
             base_meta = meta if not ONLY else json.load(open(os.path.join(HERE, "sam_cases.json")))
             all_meta = {}

@@ -3,6 +3,7 @@ CKAligner::LoadRawReads (KAligner.cpp:11648-12421) and ReportBAMread / AddAlignm
 SAMfile.cpp:2194-2377) do.  The end-to-end check against the reference's own SAM files is
 test_gpu_parity.py::test_k4align_writes_the_reference_sam (k4align runs this pipeline)."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -15,7 +16,8 @@ CODE = {ord(c): v for c, v in zip("aAcCgGtTuU", [0, 0, 1, 1, 2, 2, 3, 3, 3, 3])}
 
 
 def host_parse(text):
-    """records as LoadRawReads sees them: (first token of the descriptor cut at 127 bytes, etSeqBase codes)"""
+    """records as LoadRawReads sees them: (the descriptor up to its first white space cut at 79 bytes -- behind leading blanks and
+    tabs in FASTA only --, etSeqBase codes); KAligner.cpp:12268-12275, Fasta.cpp:1069-1071"""
     lines = text.split(b"\n")
     if lines and lines[-1] == b"":
         lines.pop()
@@ -26,15 +28,14 @@ def host_parse(text):
     i = 0
     if fastq:
         while i + 3 < len(lines) or (i + 3 == len(lines) - 0 and False):
-            name = lines[i][1:].split()[0][:127] if lines[i][1:].split() else b""
+            name = re.split(rb"\s", lines[i][1:], maxsplit=1)[0][:79]
             recs.append((name, enc(lines[i + 1])))
             i += 4
         return recs
     cur = None
     for ln in lines:
         if ln[:1] == b">":
-            tok = ln[1:].split()
-            cur = (tok[0][:127] if tok else b"", [])
+            cur = (re.split(rb"\s", ln[1:].lstrip(b" \t"), maxsplit=1)[0][:79], [])
             recs.append(cur)
         elif cur is not None:
             cur[1].extend(enc(ln))
@@ -607,3 +608,22 @@ def test_all_reads_mode_option_rules(golden_dir, tmp_path):
     assert p.returncode == 0, p.stderr
     body = [l for l in open(str(tmp_path / "o.sam")).read().split("\n") if l and not l.startswith("@")]
     assert body == ["r1\t4\t*\t0\t128\t100M\t*\t0\t0\t" + "ACGT" * 25 + "\t*\t\tYU:Z:NL"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", ["fa", "fq"])
+def test_read_names_as_the_reference_takes_them(golden_dir, tmp_path, ext):
+    """QNAME = the descriptor up to its first white space, cut at 79 characters (KAligner.cpp:12268-12275); a FASTA descriptor starts
+    behind the blanks and tabs after '>' (CFasta, Fasta.cpp:1069-1071), a FASTQ one does not (a name that starts with a blank is empty)
+    -- against `ngskit4b kalign -M1` on the same files (tests/golden/names.*, make_golden_sam.py)"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "o.sam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-s2", "-M1", "-i",
+                        os.path.join(golden_dir, "names." + ext)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    body = lambda path: sorted(l for l in open(path).read().split("\n") if l and not l.startswith("@"))  # noqa: E731
+    got, want = body(out), body(os.path.join(golden_dir, "names_%s.sam" % ext))
+    assert got == want and len(got) == 11
+    assert max(len(l.split("\t")[0]) for l in got) == 79 and (min(len(l.split("\t")[0]) for l in got) == 0) == (ext == "fq")
