@@ -39,7 +39,7 @@ namespace {
 struct Opts {
   std::vector<std::string> in1, in2;  // -i / -u may repeat: the files are read one after the other (KAlignerCL.cpp: up to cRRMaxInFiles)
   std::string sfx, out;
-  int max_subs = 5, min_edit = 1, pmode = 0, max_ns = 1, pe_mode = 0, pair_min = 100, pair_max = 1000, pair_strand = 0;
+  int max_subs = 5, min_edit = 1, pmode = 0, max_ns = 1, pe_mode = 0, pair_min = 100, pair_max = -1 /* not given */, pair_strand = 0;
   int min_len = 50, max_len = 500;  // cDfltMinAcceptReadLen / cDfltMaxAcceptReadLen, KAligner.h:112-113
   int ml_mode = 0, max_multi = 0;   // -r / -R (etMLMode, KAligner.h:250-258)
   bool clamp = false, best = false; // -X / -N (KAlignerCL.cpp:278-280)
@@ -1099,8 +1099,21 @@ int main(int argc, char** argv) {
   }
   if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830
   if (o.min_flank_exacts > 7) o.min_flank_exacts = 7;
-  if (pe && o.pe_mode == 0) o.pe_mode = 1;  // kalign: -u without -U defaults to orphan recovery
+  // kalign's argument rules for the alignment proper (KAlignerCL.cpp:546-553,645-657,789-821)
+  if (o.min_edit < 1 || o.min_edit > 2) { fprintf(stderr, "k4align: Minimum edit distance '-e%d' specified outside of range 1..2\n", o.min_edit); return 1; }
+  if (o.max_subs < 0 || o.max_subs > 15) { fprintf(stderr, "k4align: Max allowed substitutions per 100bp read length '-s%d' specified outside of range 0..15\n", o.max_subs); return 1; }
+  if (o.max_ns < 0 || o.max_ns > 5) { fprintf(stderr, "k4align: Allowed number of indeterminate bases in reads '-n%d' specified outside of range 0..5\n", o.max_ns); return 1; }
+  if (pe && o.pe_mode == 0) {  // "-u" without "-U": unique alignments only
+    o.pe_mode = 2;
+    fprintf(stderr, "k4align: PE2 file(s) with '-u<files>' specified, defaulting PE processing mode to unique alignments only '-U2'\n");
+  }
   if (!pe) o.pe_mode = 0;
+  if (pe) {
+    if (o.pe_mode < 1 || o.pe_mode > 4) { fprintf(stderr, "k4align: PE processing mode '-U%d' specified outside of range 0..4\n", o.pe_mode); return 1; }
+    if (o.pair_min < 25 || o.pair_min > 100000) { fprintf(stderr, "k4align: paired end apparent min length '-d%d' must be in range 25..100000\n", o.pair_min); return 1; }
+    if (o.pair_max < 0) o.pair_max = std::max(1000, o.pair_min);  // max(cDfltPairMaxLen, PairMinLen)
+    if (o.pair_max < std::max(1, o.pair_min) || o.pair_max > 100000) { fprintf(stderr, "k4align: paired end apparent max length '-D%d' must be in range %d..100000\n", o.pair_max, std::max(1, o.pair_min)); return 1; }
+  } else if (o.pair_max < 0) o.pair_max = 1000;
 
   if (!o.gpus.empty()) return run_multi_gpu(o, pe, max_ml);
   return run_rank(o, pe, max_ml);

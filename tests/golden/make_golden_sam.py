@@ -93,6 +93,11 @@ def names_case(tmp):
                         os.path.join(tmp, "names.log"), "-s2", "-M1", "-i", os.path.join(HERE, "names." + ext)], check=True, capture_output=True)
 
 
+# runs that reuse another case's reads with other arguments (sam_extra_cases.json): -u without -U (kalign then takes -U2, insert
+# sizes 100..1000)
+EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"])}
+
+
 def foreign_flanks(reads, frac, seed):
     """a share of the reads gets 5..35 % of random sequence at its 5' and / or 3' end (chimeric reads)"""
     import numpy as np
@@ -195,6 +200,19 @@ def main():
             print(name, hist)
         if not ONLY or "names" in ONLY:
             names_case(tmp)
+        if not ONLY or any(c in ONLY for c in EXTRA_CASES):
+            extra_meta = {}
+            for name, (base, args) in EXTRA_CASES.items():
+                files = []
+                for flag, suffix in (("-i", "_1"), ("-u", "_2")) if base.startswith("pe") else (("-i", ""),):
+                    fa = os.path.join(tmp, "%s%s.extra.fa" % (base, suffix))
+                    with lzma.open(os.path.join(HERE, "sam_%s%s.fa.xz" % (base, suffix)), "rb") as f, open(fa, "wb") as g:
+                        g.write(f.read())
+                    files += [flag, fa]
+                hist = run(tmp, name, args, files)
+                extra_meta[name] = dict(args=args, nar=hist, reads_of=base)
+                print(name, hist)
+            json.dump(extra_meta, open(os.path.join(HERE, "sam_extra_cases.json"), "w"), indent=1, sort_keys=True)
         if not ONLY or any(c in ONLY for c in ALL_READS_CASES):
             base_meta = meta if not ONLY else json.load(open(os.path.join(HERE, "sam_cases.json")))
             all_meta = {}
@@ -217,7 +235,7 @@ def main():
                 print(name, hist)
             json.dump(all_meta, open(os.path.join(HERE, "sam_all_cases.json"), "w"), indent=1, sort_keys=True)
     if ONLY and not any(c in ONLY for c in list(CASES) + list(CLUSTER_CASES) + list(EXT_CASES) + list(PE_CASES)):
-        return  # only -M1 cases were asked for: sam_cases.json stays as it is
+        return  # only cases that reuse reads were asked for: sam_cases.json stays as it is
     json.dump(meta, open(os.path.join(HERE, "sam_cases.json"), "w"), indent=1, sort_keys=True)
 
 

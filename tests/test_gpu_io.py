@@ -627,3 +627,34 @@ def test_read_names_as_the_reference_takes_them(golden_dir, tmp_path, ext):
     got, want = body(out), body(os.path.join(golden_dir, "names_%s.sam" % ext))
     assert got == want and len(got) == 11
     assert max(len(l.split("\t")[0]) for l in got) == 79 and (min(len(l.split("\t")[0]) for l in got) == 0) == (ext == "fq")
+
+
+@pytest.mark.gpu
+def test_k4align_argument_defaults_and_ranges(golden_dir, tmp_path):
+    """kalign's own defaults: `-u` without `-U` means -U2 with inserts of 100..1000 (KAlignerCL.cpp:546-553,645-657; golden written by
+    `ngskit4b kalign -s2 -i .. -u ..`), -D defaults to max(1000, -d); the range checks of -e / -s / -n / -d / -D / -U (:789-821)"""
+    import json
+    import lzma
+    import subprocess
+
+    import samutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(golden_dir, "sam_extra_cases.json")))["pe_defaults"]
+    f1, f2 = str(tmp_path / "r1.fa"), str(tmp_path / "r2.fa")
+    for dst, k in ((f1, "1"), (f2, "2")):
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, "sam_%s_%s.fa.xz" % (meta["reads_of"], k))).read())
+    base = [os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", str(tmp_path / "o.sam"), "-i", f1, "-u", f2]
+    p = subprocess.run(base + meta["args"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "defaulting PE processing mode to unique alignments only '-U2'" in p.stderr, p.stderr
+    got = [l for l in open(str(tmp_path / "o.sam")).read().splitlines() if not l.startswith("@")]
+    _, want = samutil.read_sam_xz(os.path.join(golden_dir, "sam_pe_defaults.sam.xz"))
+    assert sorted(got) == sorted(want)
+    for name, n in meta["nar"].items():
+        assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+    for extra, word in ((["-e3"], "-e3"), (["-s16"], "-s16"), (["-n6"], "-n6"), (["-U5"], "-U5"), (["-U1", "-d10"], "-d10"), (["-U1", "-d300", "-D200"], "-D200"),
+                        (["-U1", "-D100001"], "-D100001")):
+        p = subprocess.run(base + extra, capture_output=True, text=True, timeout=60)
+        assert p.returncode == 1 and word in p.stderr, (extra, p.stderr)
+    p = subprocess.run(base + ["-s2", "-U1", "-d1500"], capture_output=True, text=True, timeout=120)  # -D then defaults to 1500: accepted
+    assert p.returncode == 0, p.stderr
