@@ -51,6 +51,7 @@ struct Opts {
   int rank = 0, n_ranks = 1;        // this process's place in a -G run
   struct MultiShared* shared = nullptr;
   int print_slices = 0;             // -W <n>: print the byte offsets -G would cut the reads files at for n ranks, and stop (no GPU needed)
+  int align_strand = 0;             // -Q <0|1|2>: align to either strand, the sense or the antisense strand only (KAlignerCL.cpp:241,491)
   int fmode = 0;                    // -M <0|1>: 0 SAM / BAM with the accepted alignments, 1 SAM with every loaded read (KAlignerCL.cpp:217)
   bool legacy = false;              // -Z: the serial whole-input path of round 1 (one batch, no overlap), kept for comparison
   int chunk_mb = 256;               // -B <MB>: size of one pinned upload buffer of the pipeline
@@ -380,7 +381,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam|out.bam [-z bgzf level=6] [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
 }  // namespace
@@ -456,7 +457,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     fprintf(stderr, "k4align: -a / -A drop junctions no second read of the RUN supports; they cannot be combined with -b or -S\n");
     return 1;
   }
-  k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, K4_STRAND_BOTH, max_ml,
+  k4_kalign_params kp = {o.max_subs, o.min_edit, o.max_ns, o.pmode, o.align_strand /* K4_STRAND_*: the same codes as eALStrand */, max_ml,
                          o.ml_mode == 5 ? (o.best ? 4 : o.clamp ? 3 : 2) : o.ml_mode == 2 ? 2 : o.ml_mode != 0 ? 1 : 0,
                          mcl, slides, o.min_chimeric, o.micro_indel, o.splice_junct};
   const bool two_seg = o.micro_indel > 0 || o.splice_junct > 0;
@@ -1027,6 +1028,7 @@ int main(int argc, char** argv) {
       case 'B': o.chunk_mb = std::max(1, atoi(val().c_str())); break;
       case 't': o.io_threads = std::max(1, atoi(val().c_str())); break;
       case 'M': o.fmode = atoi(val().c_str()); break;
+      case 'Q': o.align_strand = atoi(val().c_str()); break;
       case 'Z': o.legacy = true; break;
       case 'z': o.bam_level = std::min(9, std::max(0, atoi(val().c_str()))); break;
       case 'W': o.print_slices = atoi(val().c_str()); break;
@@ -1099,6 +1101,7 @@ int main(int argc, char** argv) {
   }
   if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830
   if (o.min_flank_exacts > 7) o.min_flank_exacts = 7;
+  if (o.align_strand < 0 || o.align_strand > 2) { fprintf(stderr, "k4align: Aligned to strand '-Q%d' specified outside of range 0..2\n", o.align_strand); return 1; }
   // kalign's argument rules for the alignment proper (KAlignerCL.cpp:546-553,645-657,789-821)
   if (o.min_edit < 1 || o.min_edit > 2) { fprintf(stderr, "k4align: Minimum edit distance '-e%d' specified outside of range 1..2\n", o.min_edit); return 1; }
   if (o.max_subs < 0 || o.max_subs > 15) { fprintf(stderr, "k4align: Max allowed substitutions per 100bp read length '-s%d' specified outside of range 0..15\n", o.max_subs); return 1; }

@@ -95,7 +95,10 @@ def names_case(tmp):
 
 # runs that reuse another case's reads with other arguments (sam_extra_cases.json): -u without -U (kalign then takes -U2, insert
 # sizes 100..1000)
-EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"])}
+EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"]),
+               # -Q: alignments to one strand only (Align2Strand of AlignReads; the PE flow's single-end pass included)
+               "se_Q1": ("se_s2", ["-s2", "-Q1"]), "se_Q2": ("se_s2", ["-s2", "-Q2"]),
+               "pe_u1_Q1": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-Q1"]), "pe_u3_Q2": ("pe_u1", ["-s2", "-U3", "-d200", "-D600", "-Q2"])}
 
 
 def foreign_flanks(reads, frac, seed):

@@ -658,3 +658,34 @@ def test_k4align_argument_defaults_and_ranges(golden_dir, tmp_path):
         assert p.returncode == 1 and word in p.stderr, (extra, p.stderr)
     p = subprocess.run(base + ["-s2", "-U1", "-d1500"], capture_output=True, text=True, timeout=120)  # -D then defaults to 1500: accepted
     assert p.returncode == 0, p.stderr
+    p = subprocess.run(base + ["-s2", "-Q3"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "-Q3" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["se_Q1", "se_Q2", "pe_u1_Q1", "pe_u3_Q2"])
+def test_k4align_one_strand_only(golden_dir, tmp_path, case):
+    """-Q1 / -Q2: alignments to the sense / antisense strand only (Align2Strand of AlignReads, the paired-end flow's single-end pass
+    included) -- against what `ngskit4b kalign -Q` wrote for the same reads"""
+    import json
+    import lzma
+    import subprocess
+
+    import samutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(golden_dir, "sam_extra_cases.json")))[case]
+    base = meta["reads_of"]
+    files = []
+    for flag, suffix in (("-i", "_1"), ("-u", "_2")) if base.startswith("pe_") else (("-i", ""),):
+        dst = str(tmp_path / ("r%s.fa" % suffix))
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, "sam_%s%s.fa.xz" % (base, suffix))).read())
+        files += [flag, dst]
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", str(tmp_path / "o.sam")] + meta["args"] + files,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    got = [l for l in open(str(tmp_path / "o.sam")).read().splitlines() if not l.startswith("@")]
+    _, want = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    assert sorted(got) == sorted(want) and len(want) == meta["nar"]["AA"]
+    for name, n in meta["nar"].items():
+        assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)

@@ -36,6 +36,7 @@ def kalign_args(args):
         elif a.startswith("-a"): kw["micro_indel_len"] = int(a[2:])
         elif a.startswith("-A"): kw["max_splice_junct_len"] = int(a[2:])
         elif a.startswith("-x"): pe["min_flank_exacts"] = int(a[2:])
+        elif a.startswith("-Q"): kw["strand"] = int(a[2:])             # 0 either, 1 Watson, 2 Crick
     # `-A` without `-c` / `-x` forces the flank autotrim to -s exact bases (KAlignerCL.cpp:829-830)
     if kw.get("max_splice_junct_len") and not kw.get("min_chimeric_len") and not pe.get("min_flank_exacts"):
         pe["min_flank_exacts"] = kw["max_subs"]
@@ -230,4 +231,41 @@ def test_all_reads_mode_matches_reference_sam(oracle, golden_dir, g3_path, case)
     assert recs[:len(base_recs)] == base_recs
     codes = [samutil.NAR_CODES.index(l.rsplit("YU:Z:", 1)[1]) for l in recs[len(base_recs):]]
     assert codes == sorted(codes) and len(set(codes)) >= 3
+    oracle.close(h)
+
+
+EXTRA_CASES = json.load(open(os.path.join(GOLDEN, "sam_extra_cases.json")))
+
+
+@pytest.mark.parametrize("case", sorted(EXTRA_CASES))
+def test_runs_with_other_arguments_match_reference_sam(oracle, golden_dir, case):
+    """the reads of another case under other arguments: kalign's defaults for the pairing options (`-u` alone: -U2, 100..1000) and
+    alignments to one strand only (-Q1 / -Q2, single-end and through the paired-end flow)"""
+    meta = EXTRA_CASES[case]
+    base = meta["reads_of"]
+    kw, pe = kalign_args(meta["args"])
+    h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
+    oracle.set_max_iter(h, 5000)
+    _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    if base.startswith("pe_"):
+        if pe["pe_mode"] == 0:
+            pe["pe_mode"] = 2  # KAlignerCL.cpp:546-553
+        n1, r1 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_1.fa.xz" % base))
+        n2, r2 = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s_2.fa.xz" % base))
+        out = oracle_kalign_pe(oracle, h, r1, r2, threads=4, **pe, **kw)
+        check_hist(out["nar"], meta["nar"])
+        names = [x for p in zip(n1, n2) for x in p]
+        reads = [x for p in zip(r1, r2) for x in p]
+        res = [dict(nar=int(o["nar"]), hit=o["hit"], pe_aligned=int(o["pe_aligned"])) for o in out]
+        got = samutil.sam_records(names, reads, res, CHROMS, paired=True)
+    else:
+        names, reads = samutil.read_fasta_xz(os.path.join(golden_dir, "sam_%s.fa.xz" % base))
+        r = oracle.kalign_batch(h, reads, **kw)
+        check_hist(r["out"]["nar"], meta["nar"])
+        got = samutil.sam_records(names, reads, [dict(nar=int(o["nar"]), hit=hh[0], pe_aligned=0) for o, hh in zip(r["out"], r["hits"])], CHROMS)
+    assert sorted(got) == sorted(recs) and len(recs) == meta["nar"]["AA"] > 20
+    if "-Q1" in meta["args"] and not base.startswith("pe_"):
+        assert all(int(l.split("\t")[1]) & 16 == 0 for l in recs)
+    if "-Q2" in meta["args"] and not base.startswith("pe_"):
+        assert all(int(l.split("\t")[1]) & 16 for l in recs)
     oracle.close(h)
