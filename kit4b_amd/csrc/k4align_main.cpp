@@ -51,6 +51,7 @@ struct Opts {
   int rank = 0, n_ranks = 1;        // this process's place in a -G run
   struct MultiShared* shared = nullptr;
   int print_slices = 0;             // -W <n>: print the byte offsets -G would cut the reads files at for n ranks, and stop (no GPU needed)
+  int rpt_sq_thres = 10000;         // -4 <n>: with more reference sequences than this only those with alignments are declared in the header (KAlignerCL.cpp:289,868-870)
   int trim5 = 0, trim3 = 0;         // -y / -Y <n>: bases taken off the 5' / 3' end of every read when loading (KAlignerCL.cpp:763-774)
   int align_strand = 0;             // -Q <0|1|2>: align to either strand, the sense or the antisense strand only (KAlignerCL.cpp:241,491)
   int fmode = 0;                    // -M <0|1>: 0 SAM / BAM with the accepted alignments, 1 SAM with every loaded read (KAlignerCL.cpp:217)
@@ -382,7 +383,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam|out.bam [-z bgzf level=6] [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-y trim5] [-Y trim3] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-4 all @SQ up to n=10000] [-y trim5] [-Y trim3] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
 }  // namespace
@@ -725,7 +726,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       if (chatty) fprintf(stderr, "k4align: SNP processing completed with %llu putative SNPs discovered, written to %s in %.2fs\n",
                           (unsigned long long)sf.n_snps, o.snp_file.c_str(), secs(ts, now()));
     }
-    if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= 10000 ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
+    if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= (uint32_t)o.rpt_sq_thres ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
     else if (o.fmode == 1) CK(k4_pipeline_format_all(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     else CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     s_align = secs(tg, now());
@@ -792,7 +793,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     // ---- BAM (+ .bai): dictionary and BGZF blocks here (include/k4_bam.hpp), the records as packed on the device ------------
     std::string hdr = "@HD\tVN:1.4\tSO:coordinate\n";
     std::vector<k4bam::RefSeq> refs;
-    const bool all_sq = info.n_entries <= 10000;  // m_MaxRptSAMSeqsThres, KAligner.cpp:5785-5821
+    const bool all_sq = info.n_entries <= (uint32_t)o.rpt_sq_thres;  // m_MaxRptSAMSeqsThres, KAligner.cpp:5785-5821
     for (uint32_t c = 1; c <= info.n_entries; c++) {
       k4_entry e;
       k4_get_entry(ix, c, &e);
@@ -829,7 +830,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   fprintf(fp, "@HD\tVN:1.4\tSO:coordinate\n");
   // m_MaxRptSAMSeqsThres, KAligner.cpp:5785-5821: with more sequences only those that were hit are declared -- a shard (-S, -G)
   // declares all of them and leaves that rule to the merge, which sees every shard's records
-  const bool all_chroms = info.n_entries <= 10000 || o.n_shards > 1 || multi;
+  const bool all_chroms = info.n_entries <= (uint32_t)o.rpt_sq_thres || o.n_shards > 1 || multi;
   std::map<std::string, long> order;
   for (uint32_t c = 1; c <= info.n_entries; c++) {
     k4_entry e;
@@ -974,7 +975,7 @@ static int run_multi_gpu(Opts& o, bool pe, int max_ml) {
   }
   auto t1 = std::chrono::steady_clock::now();
   unsigned long long n = 0;
-  const int rc = k4merge::merge_sam(shards, final_out, 10000, &n, "k4align");
+  const int rc = k4merge::merge_sam(shards, final_out, o.rpt_sq_thres, &n, "k4align");
   for (const std::string& q : shards) remove(q.c_str());
   if (rc) return rc;
   fprintf(stderr, "k4align: %llu alignments from %d GPUs written to %s; ranks %.2fs, merge %.2fs\n", n, N, final_out.c_str(),
@@ -1031,6 +1032,7 @@ int main(int argc, char** argv) {
       case 't': o.io_threads = std::max(1, atoi(val().c_str())); break;
       case 'M': o.fmode = atoi(val().c_str()); break;
       case 'Q': o.align_strand = atoi(val().c_str()); break;
+      case '4': o.rpt_sq_thres = std::max(1, atoi(val().c_str())); break;
       case 'y': o.trim5 = atoi(val().c_str()); break;
       case 'Y': o.trim3 = atoi(val().c_str()); break;
       case 'Z': o.legacy = true; break;

@@ -100,7 +100,9 @@ EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"]),
                "se_Q1": ("se_s2", ["-s2", "-Q1"]), "se_Q2": ("se_s2", ["-s2", "-Q2"]),
                "pe_u1_Q1": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-Q1"]), "pe_u3_Q2": ("pe_u1", ["-s2", "-U3", "-d200", "-D600", "-Q2"]),
                # -y / -Y: bases taken off the 5' / 3' end of every read when loading (the SAM shows the trimmed read)
-               "se_y7_Y12": ("se_s2", ["-s2", "-y7", "-Y12"]), "pe_u1_y5_Y20": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-y5", "-Y20", "-l120"])}
+               "se_y7_Y12": ("se_s2", ["-s2", "-y7", "-Y12"]),
+               # -4: with more reference sequences than this only those with alignments are declared in the SAM header
+               "se_s2_sq2": ("se_s2", ["-s2", "-4", "2"]), "pe_u1_y5_Y20": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-y5", "-Y20", "-l120"])}
 
 
 def foreign_flanks(reads, frac, seed):
