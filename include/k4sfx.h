@@ -451,7 +451,8 @@ typedef struct {
   k4_pe_params pe;
   int32_t min_len, max_len;     /* the length filter of LoadRawReads (k4_prepare_reads_dev) */
   uint32_t n_buffers;           /* pinned buffers per end (0: 3) */
-  uint32_t min_batch_units;     /* reads / pairs that must have arrived before an alignment batch is launched (0: 2^20) */
+  uint32_t min_batch_units;     /* reads / pairs that must have arrived before an alignment batch is launched (0: 2^22; not
+                                 * over the last eighth of an input whose size is known: little is left behind the last upload) */
   uint64_t chunk_bytes;         /* size of one pinned buffer = one upload (0: 256 MiB) */
   uint64_t expect_text_bytes[2];/* text per end, if known (file sizes): the HBM arena is sized once */
 } k4_pipeline_params;
