@@ -241,6 +241,7 @@ class Writer {
 
   void add_to_index(const Rec& r) {
     if (!index_ok_) return;
+    if (r.ref < 0) n_no_coor_++;  // (-M1: the reads that were not accepted follow the alignments)
     if (r.ref < 0 || (size_t)r.ref >= idx_.size() || r.pos < 0) return;
     RefIndex& x = idx_[(size_t)r.ref];
     const uint64_t vb = voffset(r.ubeg), ve = voffset(r.uend);
@@ -278,7 +279,7 @@ class Writer {
       put32(o, (uint32_t)x.linear.size());
       for (uint64_t v : x.linear) put64(o, v);
     }
-    put64(o, 0);  // n_no_coor: unaligned reads are not reported in this mode
+    put64(o, n_no_coor_);  // records without coordinates (only with -M1)
     const std::string ip = path_ + ".bai";
     FILE* f = fopen(ip.c_str(), "wb");
     if (!f) return fail("cannot create " + ip);
@@ -296,7 +297,7 @@ class Writer {
   std::vector<RefIndex> idx_;
   std::vector<uint8_t> pend_;                 // uncompressed bytes not yet in a block
   std::vector<uint64_t> block_uoff_, block_coff_;
-  uint64_t uwritten_ = 0, coff_ = 0, consumed_ = 0, header_bytes_ = 0, rec_ubeg_ = 0, n_rec_ = 0;  // consumed_: record-stream bytes seen
+  uint64_t uwritten_ = 0, coff_ = 0, consumed_ = 0, header_bytes_ = 0, rec_ubeg_ = 0, n_rec_ = 0, n_no_coor_ = 0;  // consumed_: record-stream bytes seen
   std::vector<uint8_t> carry_, body_;
   uint32_t need_ = 0;
   std::vector<Rec> recs_;

@@ -379,6 +379,11 @@ int k4_format_sam_all_dev(k4_index* ix, int pe, int64_t n_units, const void* d_r
                           const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
                           const k4_sam_names* names, void** d_sam, uint64_t* sam_bytes, k4_sam_stats* stats,
                           uint8_t* chrom_hit, void* stream);
+/* ... as BAM records: refID, pos and the mate fields -1, bin 0, MAPQ 128, one CIGAR operation <len>M, aux YU:Z:<NAR> */
+int k4_format_bam_all_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                          const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
+                          const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes, k4_sam_stats* stats,
+                          uint8_t* chrom_hit, void* stream);
 /* k4_format_bam_dev <- the same alignments as uncompressed BAM records in coordinate order (CSAMfile::AddAlignment's BAM branch,
  * SAMfile.cpp:2379-2640: block_size, refID, pos, bin<<16|MAPQ<<8|l_read_name, FLAG<<16|n_cigar_op, l_seq, next_refID,
  * next_pos, tlen, read_name, cigar, 4-bit seq -- reverse complemented for a Crick alignment --, qual 0xff).  refID is the
@@ -477,6 +482,7 @@ int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit 
 int k4_pipeline_format_bam(k4_pipeline* pl, int32_t sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* bam_bytes);
 /* ... as SAM text with every loaded read (k4_format_sam_all_dev, kalign -M1) */
 int k4_pipeline_format_all(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* sam_bytes);
+int k4_pipeline_format_bam_all(k4_pipeline* pl, int32_t sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* bam_bytes);
 int k4_pipeline_next_sam(k4_pipeline* pl, const void** ptr, uint64_t* bytes); /* valid until the next call; 0 bytes: done */
 int k4_pipeline_read_sam(k4_pipeline* pl, void* dst, uint64_t cap, uint64_t* bytes); /* the whole body into caller memory */
 void k4_pipeline_close(k4_pipeline* pl);

@@ -664,6 +664,7 @@ K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t v) {
 }
 // the same alignment as a BAM record (CSAMfile::AddAlignment's BAM branch, SAMfile.cpp:2379-2640, over ReportBAMread's fields):
 // block_size | refID pos bin_mq_nl flag_nc l_seq next_refID next_pos tlen | read_name\0 | cigar | seq (4-bit) | qual (0xff: none)
+#define K4_BAM_UNALIGNED_AUX 6  // 'Y' 'U' 'Z' + the two-letter NAR code + NUL
 K4_DEV uint32_t k4d_bam_n_ops(const K4SamArgs& a, int64_t v, const k4_hit& h) {
   const uint32_t tl = K4_HIT_TRIM_LEFT(h), tr = K4_HIT_TRIM_RIGHT(h);
   const bool two = !a.pe && a.seg2 && k4d_two_segs(h);
@@ -675,6 +676,7 @@ K4_DEV uint32_t k4d_bam_rec_len(const K4SamArgs& a, int64_t v) {
   const int w = a.pe ? (int)(i & 1) : 0;
   const int64_t rec = a.pe ? (i >> 1) : i;
   const uint32_t len = a.lens[i];
+  if (k4d_sam_unaligned(a, v)) return 4u + 32u + a.name_len[w][rec] + 1u + 4u + (len + 1) / 2 + len + K4_BAM_UNALIGNED_AUX;
   return 4u + 32u + a.name_len[w][rec] + 1u + 4u * k4d_bam_n_ops(a, v, h) + (len + 1) / 2 + len;
 }
 template <bool BAM>
@@ -697,9 +699,33 @@ K4_DEV void k4d_put_le32(char* p, uint32_t v) { p[0] = (char)v; p[1] = (char)(v 
 K4_DEV void k4d_bam_put_rec(const K4SamArgs& a, int64_t v, const k4_hit& h, int64_t i, char* line, uint32_t line_len, int sub, int lpl) {
   const uint32_t len = a.lens[i];
   const uint32_t nseq = (len + 1) / 2;
-  char* seq = line + line_len - len - nseq;
-  char* qual = line + line_len - len;
-  if (sub == 0) {
+  const bool unal = k4d_sam_unaligned(a, v);
+  const uint32_t aux = unal ? K4_BAM_UNALIGNED_AUX : 0u;
+  char* seq = line + line_len - aux - len - nseq;
+  char* qual = line + line_len - aux - len;
+  if (sub == 0 && unal) {  // ReportBAMread's unaligned branch (KAligner.cpp:6253-6276): refID / pos / mate -1, bin 0, MAPQ 128, <len>M, YU:Z:<NAR>
+    const int w = a.pe ? (int)(i & 1) : 0;
+    const int64_t rec = a.pe ? (i >> 1) : i;
+    const uint32_t nl_ = a.name_len[w][rec];
+    k4d_put_le32(line, line_len - 4);
+    k4d_put_le32(line + 4, 0xFFFFFFFFu);
+    k4d_put_le32(line + 8, 0xFFFFFFFFu);
+    k4d_put_le32(line + 12, (128u << 8) | (nl_ + 1));
+    k4d_put_le32(line + 16, (k4d_sam_unaligned_flag(a, i) << 16) | 1u);
+    k4d_put_le32(line + 20, len);
+    k4d_put_le32(line + 24, 0xFFFFFFFFu);
+    k4d_put_le32(line + 28, 0xFFFFFFFFu);
+    k4d_put_le32(line + 32, 0u);
+    char* p = line + 36;
+    const uint8_t* nm = a.text[w] + a.name_off[w][rec];
+    for (uint32_t q = 0; q < nl_; q++) p[q] = (char)nm[q];
+    p[nl_] = 0;
+    k4d_put_le32(p + nl_ + 1, len << 4);
+    const int nar = k4d_sam_nar(a, i);
+    const int code = nar >= 0 && nar < 20 ? nar : 0;
+    char* t = line + line_len - K4_BAM_UNALIGNED_AUX;
+    t[0] = 'Y'; t[1] = 'U'; t[2] = 'Z'; t[3] = k4_nar_codes[2 * code]; t[4] = k4_nar_codes[2 * code + 1]; t[5] = 0;
+  } else if (sub == 0) {
     const K4SamFields f = k4d_sam_fields(a, v, h);
     const int w = a.pe ? (int)(i & 1) : 0;
     const int64_t rec = a.pe ? (i >> 1) : i;
@@ -733,7 +759,7 @@ K4_DEV void k4d_bam_put_rec(const K4SamArgs& a, int64_t v, const k4_hit& h, int6
   const uint64_t fwd = 0x0F0F0F0F08040201ull, rev = 0x0F0F0F0F01020408ull;  // by symbol: A C G T N.. / their complements
   for (uint32_t b = b0; b < b1; b++) {
     uint32_t hi, lo = 0;
-    if (h.strand == '+') {
+    if (unal || h.strand == '+') {
       hi = (uint32_t)(fwd >> (8 * (s[2 * b] & 7))) & 0xF;
       if (2 * b + 1 < len) lo = (uint32_t)(fwd >> (8 * (s[2 * b + 1] & 7))) & 0xF;
     } else {
@@ -954,6 +980,14 @@ extern "C" int k4_format_sam_all_dev(k4_index* ix, int pe, int64_t n_units, cons
   return k4i_format_records(ix, 2, 0, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_sam, sam_bytes, stats,
                             chrom_hit, stream, nullptr, nullptr);
 }
+// ... and the same as BAM records (refID / pos / mate -1, bin 0, MAPQ 128, <len>M, aux YU:Z:<NAR>)
+extern "C" int k4_format_bam_all_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
+                                     const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
+                                     const void* d_lens, const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes,
+                                     k4_sam_stats* stats, uint8_t* chrom_hit, void* stream) {
+  return k4i_format_records(ix, 3, sq_all, pe, n_units, d_rr, d_hits, max_ml, d_pe, d_seg2, d_reads, d_offs, d_lens, names, d_bam, bam_bytes, stats,
+                            chrom_hit, stream, nullptr, nullptr);
+}
 extern "C" int k4_format_bam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
                                  const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs,
                                  const void* d_lens, const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes,
@@ -967,8 +1001,8 @@ int k4i_format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_unit
                        k4_sam_stats* stats, uint8_t* chrom_hit, void* stream, K4SamSlices* slices, K4PoolBuf* out_buf) {
   if (!ix || !names || !d_sam || !sam_bytes) return K4_ERR_PARAMS;
   if (slices) slices->clear();
-  const bool all_reads = bam == 2;  // SAM text with the reads that were not accepted behind the alignments (`-M1`)
-  if (all_reads) bam = 0;
+  const bool all_reads = bam >= 2;  // 2: SAM text, 3: BAM records with the reads that were not accepted behind the alignments (`-M1`)
+  if (all_reads) bam -= 2;
   *d_sam = nullptr;
   *sam_bytes = 0;
   if (stats) memset(stats, 0, sizeof(*stats));

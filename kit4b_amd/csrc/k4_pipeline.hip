@@ -474,6 +474,9 @@ extern "C" int k4_pipeline_format(k4_pipeline* pl, k4_sam_stats* stats, uint8_t*
 extern "C" int k4_pipeline_format_all(k4_pipeline* pl, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* sam_bytes) {
   return pipeline_format(pl, 2, 0, stats, chrom_hit, sam_bytes);
 }
+extern "C" int k4_pipeline_format_bam_all(k4_pipeline* pl, int32_t sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* bam_bytes) {
+  return pipeline_format(pl, 3, sq_all, stats, chrom_hit, bam_bytes);
+}
 extern "C" int k4_pipeline_format_bam(k4_pipeline* pl, int32_t sq_all, k4_sam_stats* stats, uint8_t* chrom_hit, uint64_t* bam_bytes) {
   return pipeline_format(pl, 1, sq_all, stats, chrom_hit, bam_bytes);
 }

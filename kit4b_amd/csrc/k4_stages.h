@@ -18,7 +18,7 @@ struct K4SamSlices {
   }
 };
 
-// k4_format_sam_ext_dev (bam 0) / k4_format_bam_dev (bam 1) / k4_format_sam_all_dev (bam 2) (include/k4sfx.h) with two additions: `slices` != nullptr -- the call returns with the
+// k4_format_sam_ext_dev (bam 0) / k4_format_bam_dev (bam 1) / k4_format_sam_all_dev (bam 2) / k4_format_bam_all_dev (bam 3) (include/k4sfx.h) with two additions: `slices` != nullptr -- the call returns with the
 // writing kernels still running (wait for the events, or synchronise the stream); `out_buf` != nullptr -- the body is placed in
 // a block of the device's pool held by *out_buf (and *d_sam points into it) instead of a hipMalloc'd block of the caller's.
 int k4i_format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,

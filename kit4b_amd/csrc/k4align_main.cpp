@@ -726,7 +726,8 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       if (chatty) fprintf(stderr, "k4align: SNP processing completed with %llu putative SNPs discovered, written to %s in %.2fs\n",
                           (unsigned long long)sf.n_snps, o.snp_file.c_str(), secs(ts, now()));
     }
-    if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= (uint32_t)o.rpt_sq_thres ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
+    if (bam_out && o.fmode == 1) CK(k4_pipeline_format_bam_all(pl, info.n_entries <= (uint32_t)o.rpt_sq_thres ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
+    else if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= (uint32_t)o.rpt_sq_thres ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
     else if (o.fmode == 1) CK(k4_pipeline_format_all(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     else CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     s_align = secs(tg, now());
@@ -1087,9 +1088,8 @@ int main(int argc, char** argv) {
   if (o.fmode < 0 || o.fmode > 3) { fprintf(stderr, "k4align: output format mode '-M%d' specified outside of range 0..3\n", o.fmode); return 1; }
   if (o.fmode >= 2) { fprintf(stderr, "k4align: output format -M%d (BED / packed base alleles) is not built\n", o.fmode); return 3; }
   if (o.fmode == 1) {
-    const bool bam = o.out.size() >= 4 && strcasecmp(o.out.c_str() + o.out.size() - 4, ".bam") == 0;
-    if (bam || o.batch_mb > 0 || o.n_shards > 1 || !o.gpus.empty() || o.legacy || o.ml_mode == 5) {
-      fprintf(stderr, "k4align: -M1 writes SAM text from the pipelined single-GPU mode (not BAM, -b, -S i/N, -G, -Z, -r5)\n");
+    if (o.batch_mb > 0 || o.n_shards > 1 || !o.gpus.empty() || o.legacy || o.ml_mode == 5) {
+      fprintf(stderr, "k4align: -M1 is written by the pipelined single-GPU mode (not with -b, -S i/N, -G, -Z, -r5)\n");
       return 3;
     }
     if (o.min_snp_reads > 0 || !o.snp_file.empty()) { fprintf(stderr, "k4align: SNP calling is not available in '-M1' output mode\n"); return 1; }  // KAlignerCL.cpp:935

@@ -20,6 +20,7 @@ import samutil  # noqa: E402
 
 NGS = os.path.join(ROOT, "oracle", "_ref", "ngskit4b")
 CASES = ["se_s2", "pe_u1", "se_all_120"]
+ALL_READS_CASES = ["se_s2_M1", "pe_u1_M1"]  # -M1 (sam_all_cases.json): the unaligned records follow the alignments
 
 
 def main():
@@ -54,6 +55,25 @@ def main():
             _, sam_recs = samutil.read_sam_xz(os.path.join(HERE, "sam_%s.sam.xz" % case))
             as_sam = [samutil.bam_record_as_sam_fields(r, refs) for r in recs]
             assert sorted(as_sam) == sorted(samutil.sam_line_fields(x) for x in sam_recs), case
+            shutil.copy(bam, os.path.join(HERE, "bam_%s.bam" % case))
+            shutil.copy(bam + ".bai", os.path.join(HERE, "bam_%s.bam.bai" % case))
+            print(case, len(recs), "records,", os.path.getsize(bam), "bytes")
+        all_meta = json.load(open(os.path.join(HERE, "sam_all_cases.json")))
+        for case in ALL_READS_CASES:
+            m = all_meta[case]
+            base = m["reads_of"]
+            files = []
+            for flag, suffix in (("-i", "_1"), ("-u", "_2")) if base.startswith("pe_") else (("-i", ""),):
+                fa = os.path.join(tmp, "%s%s.all.fa" % (base, suffix))
+                with lzma.open(os.path.join(HERE, "sam_%s%s.fa.xz" % (base, suffix))) as f, open(fa, "wb") as g:
+                    g.write(f.read())
+                files += [flag, fa]
+            bam = os.path.join(tmp, case + ".bam")
+            subprocess.run([NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", bam, "-T", "4", "-F", os.path.join(tmp, case + ".log")] + m["args"] + files,
+                           check=True, capture_output=True)
+            hdr, refs, recs = samutil.read_bam(bam)
+            _, sam_recs = samutil.read_sam_xz(os.path.join(HERE, "sam_%s.sam.xz" % case))
+            assert len(recs) == len(sam_recs) and sum(1 for r in recs if r["ref"] < 0) == len(recs) - m["nar"]["AA"], case
             shutil.copy(bam, os.path.join(HERE, "bam_%s.bam" % case))
             shutil.copy(bam + ".bai", os.path.join(HERE, "bam_%s.bam.bai" % case))
             print(case, len(recs), "records,", os.path.getsize(bam), "bytes")

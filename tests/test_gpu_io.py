@@ -599,7 +599,7 @@ def test_all_reads_mode_option_rules(golden_dir, tmp_path):
     assert p.returncode == 1 and "range 0..3" in p.stderr
     p = subprocess.run(base + ["-o", str(tmp_path / "o.sam"), "-M2"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 3 and "not built" in p.stderr
-    for extra in (["-o", str(tmp_path / "o.bam"), "-M1"], ["-o", str(tmp_path / "o.sam"), "-M1", "-r5"], ["-o", str(tmp_path / "o.sam"), "-M1", "-b", "1"]):
+    for extra in (["-o", str(tmp_path / "o.sam"), "-M1", "-r5"], ["-o", str(tmp_path / "o.sam"), "-M1", "-b", "1"]):
         p = subprocess.run(base + extra, capture_output=True, text=True, timeout=60)
         assert p.returncode == 3, (extra, p.stderr)
     p = subprocess.run(base + ["-o", str(tmp_path / "o.sam"), "-M1", "-p5"], capture_output=True, text=True, timeout=60)
@@ -692,3 +692,42 @@ def test_k4align_one_strand_only_and_end_trims(golden_dir, tmp_path, case):
     hdr = [l for l in open(str(tmp_path / "o.sam")).read().splitlines() if l.startswith("@") and not l.startswith("@PG")]
     want_hdr, _ = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
     assert hdr == [l for l in want_hdr if not l.startswith("@PG")]  # (-4: only the sequences with alignments once there are more than the threshold)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["se_s2_M1", "pe_u1_M1"])
+def test_k4align_all_reads_mode_as_bam(golden_dir, tmp_path, case):
+    """`-M1 -o x.bam`: the unaligned records as the reference packs them (refID / pos / mate -1, bin 0, MAPQ 128, one operation
+    <len>M, the read as loaded, aux YU:Z:<NAR>) behind the alignments, NAR codes ascending -- decoded against `ngskit4b kalign -M1
+    -o x.bam` (tests/golden/bam_<case>.bam); the index counts them as records without coordinates"""
+    import json
+    import lzma
+    import subprocess
+
+    import samutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(golden_dir, "sam_all_cases.json")))[case]
+    base = meta["reads_of"]
+    files = []
+    for flag, suffix in (("-i", "_1"), ("-u", "_2")) if base.startswith("pe_") else (("-i", ""),):
+        dst = str(tmp_path / ("r%s.fa" % suffix))
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, "sam_%s%s.fa.xz" % (base, suffix))).read())
+        files += [flag, dst]
+    out = str(tmp_path / "o.bam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-t", "3"] + meta["args"] + files,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    text, refs, recs = samutil.read_bam(out)
+    wtext, wrefs, wrecs = samutil.read_bam(os.path.join(golden_dir, "bam_%s.bam" % case))
+    assert refs == wrefs and len(recs) == len(wrecs)
+    n_acc = meta["nar"]["AA"]
+    key = lambda r: (r["ref"], r["pos"], r["name"], r["flag"])  # noqa: E731
+    assert sorted(recs[:n_acc], key=key) == sorted(wrecs[:n_acc], key=key)
+    assert [r["aux"] for r in recs[n_acc:]] == [r["aux"] for r in wrecs[n_acc:]]  # the NAR groups, in the reference's order
+    assert sorted(recs[n_acc:], key=key) == sorted(wrecs[n_acc:], key=key)
+    u = recs[n_acc]
+    assert (u["ref"], u["pos"], u["bin"], u["mapq"], u["next_ref"], u["next_pos"], u["tlen"]) == (-1, -1, 0, 128, -1, -1, 0)
+    assert u["cigar"] == [(u["l_seq"], "M")] and u["aux"][:3] == b"YUZ" and u["aux"][-1:] == b"\0"
+    raw = open(out + ".bai", "rb").read()
+    assert int.from_bytes(raw[-8:], "little") == len(recs) - n_acc  # n_no_coor
