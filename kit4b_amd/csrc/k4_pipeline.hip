@@ -243,7 +243,7 @@ void worker_main(k4_pipeline* pl) {
   hipSetDevice(ix->device);
   int rc = K4_OK;
   std::deque<Sent> sent;
-  std::vector<hipEvent_t> spare;  // events are reused: one per chunk in flight
+  std::vector<hipEvent_t> spare;  // one event per chunk, destroyed when the compute stream has drained (never re-recorded while a wait on it may be queued)
   for (;;) {
     // 1. every chunk that is queued starts its way up at once: the copy-in stream never waits for the parsing and aligning below
     std::deque<Job> take;
@@ -268,8 +268,7 @@ void worker_main(k4_pipeline* pl) {
       }
       if (rc == K4_OK) {
         hipEvent_t ev = nullptr;
-        if (!spare.empty()) { ev = spare.back(); spare.pop_back(); }
-        else rc = k4_check_hip(ix, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "event");
+        rc = k4_check_hip(ix, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "event");
         if (rc == K4_OK) rc = k4_check_hip(ix, hipEventRecord(ev, pl->s_in), "event");
         if (rc == K4_OK) sent.push_back({j.end, E.text.used, ev, j.final_chunk});
         else if (ev) spare.push_back(ev);
@@ -291,7 +290,7 @@ void worker_main(k4_pipeline* pl) {
       sent.pop_front();
       End& E = pl->end[c.end];
       rc = k4_check_hip(ix, hipStreamWaitEvent(pl->s_comp, c.ev, 0), "event");
-      spare.push_back(c.ev);  // (the wait is enqueued: recording the event again later does not disturb it)
+      spare.push_back(c.ev);
       E.uploaded = c.upto;
       if (c.final_chunk) E.final_seen = true;
       if (rc == K4_OK) rc = parse_more(pl, c.end);
@@ -300,13 +299,14 @@ void worker_main(k4_pipeline* pl) {
       if (rc == K4_OK) rc = align_more(pl, all_final && sent.empty());
     }
   }
-  for (hipEvent_t ev : spare) hipEventDestroy(ev);
   if (rc == K4_OK) {  // whatever is left (the caller closed the input without a final chunk on some end: wait_aligned reports it)
     bool all_final = true;
     for (int e = 0; e < pl->n_ends; e++) all_final &= pl->end[e].final_seen;
     if (all_final) rc = align_more(pl, true);
   }
   if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(pl->s_comp), "pipeline");
+  else (void)hipStreamSynchronize(pl->s_comp);
+  for (hipEvent_t ev : spare) hipEventDestroy(ev);
   std::lock_guard<std::mutex> lk(pl->m);
   pl->err = rc;
   pl->worker_done = true;
