@@ -493,7 +493,7 @@ int k4_alloc_device(k4_index* ix, uint64_t bytes, void** d_ptr);
 int k4_copy_to_device(k4_index* ix, void* d_dst, const void* src, uint64_t bytes);
 int k4_copy_to_host(k4_index* ix, void* dst, const void* d_src, uint64_t bytes);
 
-/* kernel timing for roofline measurement: when enabled, every batch brackets the dominant kernel (k4k_align_fast) with
+/* kernel timing for roofline measurement: when enabled, every batch brackets the dominant kernel (k4k_align_step, one launch per AlignReads phase) with
  * HIP events on the stream it is launched on; k4_get_kernel_times synchronises, returns the summed duration and the
  * number of launches since the last call, and resets. */
 int k4_enable_kernel_timing(k4_index* ix, int on);

@@ -357,7 +357,7 @@ class SfxIndex:
         self._ck(lib().k4_enable_kernel_timing(self.h, 1 if on else 0))
 
     def kernel_times(self):
-        """(summed k4k_align_fast milliseconds, launches) since the last call; synchronises."""
+        """(summed k4k_align_step milliseconds, launches) since the last call; synchronises."""
         ms, n = C.c_double(0), C.c_int32(0)
         self._ck(lib().k4_get_kernel_times(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
