@@ -356,9 +356,11 @@ int k4_prepare_reads_dev(k4_index* ix, int pe, int64_t n_units, int32_t min_len,
                          const void* d_lens1, const void* d_offs2, const void* d_lens2, uint64_t reads2_base,
                          void* d_offs_out, void* d_lens_out, uint64_t* n_under, uint64_t* n_over, uint32_t* max_read_len,
                          void* stream);
-/* ... with kalign's end trims (`-y` / `-Y`: KAligner.cpp:12254-12260, the length tests over the trimmed lengths :12040-12090) */
+/* ... with kalign's end trims (`-y` / `-Y`: KAligner.cpp:12254-12260, the length tests over the trimmed lengths :12040-12090) and
+ * its sampling (`-#<n>`, :11983-11989: of the file's reads / pairs every n-th is loaded, the first included; first_unit = index in
+ * the file of this call's first unit; 0 / 1: all) */
 int k4_prepare_reads_trim_dev(k4_index* ix, int pe, int64_t n_units, int32_t min_len, int32_t max_len, int32_t trim5, int32_t trim3,
-                              const void* d_offs1, const void* d_lens1, const void* d_offs2, const void* d_lens2, uint64_t reads2_base,
+                              int32_t sample_nth, int64_t first_unit, const void* d_offs1, const void* d_lens1, const void* d_offs2, const void* d_lens2, uint64_t reads2_base,
                               void* d_offs_out, void* d_lens_out, uint64_t* n_under, uint64_t* n_over, uint32_t* max_read_len,
                               void* stream);
 int k4_format_sam_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_hits, int32_t max_ml,
@@ -472,6 +474,7 @@ typedef struct {                /* where the aligned batch lives in HBM (for the
 } k4_pipeline_view;
 int k4_pipeline_open(k4_index* ix, const k4_pipeline_params* p, k4_pipeline** out);
 int k4_pipeline_set_trims(k4_pipeline* pl, int32_t trim5, int32_t trim3); /* kalign -y / -Y; before the first chunk is submitted */
+int k4_pipeline_set_sampling(k4_pipeline* pl, int32_t sample_nth);          /* kalign -#<n> (one input file per end); likewise */
 int k4_pipeline_acquire(k4_pipeline* pl, int end, void** buf, uint64_t* cap); /* blocks while every buffer is on its way up */
 int k4_pipeline_submit(k4_pipeline* pl, int end, uint64_t bytes, int final_chunk);
 /* text in the caller's own memory (pinned for the full PCIe rate); it must stay valid until k4_pipeline_wait_aligned returns */

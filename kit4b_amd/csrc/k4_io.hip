@@ -386,7 +386,8 @@ __global__ void __launch_bounds__(256) k4k_prepare_reads(int pe, int64_t n, uint
                                                          const uint64_t* __restrict__ o1, const uint32_t* __restrict__ l1,
                                                          const uint64_t* __restrict__ o2, const uint32_t* __restrict__ l2,
                                                          uint64_t base2, uint64_t* __restrict__ oo, uint32_t* __restrict__ lo,
-                                                         unsigned long long* __restrict__ tot, uint32_t trim5, uint32_t trim3) {
+                                                         unsigned long long* __restrict__ tot, uint32_t trim5, uint32_t trim3, uint32_t sample_nth,
+                                                         int64_t first_unit) {
   // grid-stride, tallies kept per thread and folded once per wave at the end: a same-address atomic per wave of a
   // one-thread-per-read launch (312 k of them for 20 M reads) costs more than the whole copy
   uint32_t n_u = 0, n_o = 0, mx = 0;
@@ -397,9 +398,11 @@ __global__ void __launch_bounds__(256) k4k_prepare_reads(int pe, int64_t n, uint
     const uint32_t trims = trim5 + trim3;
     const uint32_t ra = l1[i], rb = pe ? l2[i] : ra;
     const uint32_t a = ra > trims ? ra - trims : 0, b = rb > trims ? rb - trims : 0;
-    const bool under = a < min_len || (a <= max_len && b < min_len);
-    const bool over = !under && (a > max_len || b > max_len);
-    const bool keep = !under && !over;
+    // `-#<n>`: every n-th read (pair) of the file is loaded, the first one included; the others are never looked at (:11983-11989)
+    const bool sampled = sample_nth <= 1 || (uint64_t)(first_unit + i) % sample_nth == 0;
+    const bool under = sampled && (a < min_len || (a <= max_len && b < min_len));
+    const bool over = sampled && !under && (a > max_len || b > max_len);
+    const bool keep = sampled && !under && !over;
     if (pe) {
       oo[2 * i] = o1[i] + trim5; lo[2 * i] = keep ? a : 0;
       oo[2 * i + 1] = o2[i] + base2 + trim5; lo[2 * i + 1] = keep ? b : 0;
@@ -426,15 +429,16 @@ extern "C" int k4_prepare_reads_dev(k4_index* ix, int pe, int64_t n, int32_t min
                                     const void* d_lens1, const void* d_offs2, const void* d_lens2, uint64_t reads2_base,
                                     void* d_offs_out, void* d_lens_out, uint64_t* n_under, uint64_t* n_over,
                                     uint32_t* max_read_len, void* stream) {
-  return k4_prepare_reads_trim_dev(ix, pe, n, min_len, max_len, 0, 0, d_offs1, d_lens1, d_offs2, d_lens2, reads2_base, d_offs_out, d_lens_out, n_under,
-                                   n_over, max_read_len, stream);
+  return k4_prepare_reads_trim_dev(ix, pe, n, min_len, max_len, 0, 0, 1, 0, d_offs1, d_lens1, d_offs2, d_lens2, reads2_base, d_offs_out, d_lens_out,
+                                   n_under, n_over, max_read_len, stream);
 }
-// ... with kalign's end trims (`-y` / `-Y`, 0..50 bases off the 5' / 3' end of every read before the length filter)
+// ... with kalign's end trims (`-y` / `-Y`, 0..50 bases off the 5' / 3' end of every read before the length filter) and its
+// sampling (`-#<n>`: of the file's reads / pairs, counted from first_unit for the first of this call, every n-th is loaded)
 extern "C" int k4_prepare_reads_trim_dev(k4_index* ix, int pe, int64_t n, int32_t min_len, int32_t max_len, int32_t trim5, int32_t trim3,
-                                         const void* d_offs1, const void* d_lens1, const void* d_offs2, const void* d_lens2,
+                                         int32_t sample_nth, int64_t first_unit, const void* d_offs1, const void* d_lens1, const void* d_offs2, const void* d_lens2,
                                          uint64_t reads2_base, void* d_offs_out, void* d_lens_out, uint64_t* n_under, uint64_t* n_over,
                                          uint32_t* max_read_len, void* stream) {
-  if (!ix || n < 0 || trim5 < 0 || trim3 < 0) return K4_ERR_PARAMS;
+  if (!ix || n < 0 || trim5 < 0 || trim3 < 0 || sample_nth < 0 || first_unit < 0) return K4_ERR_PARAMS;
   if (n_under) *n_under = 0;
   if (n_over) *n_over = 0;
   if (max_read_len) *max_read_len = 0;
@@ -449,7 +453,7 @@ extern "C" int k4_prepare_reads_trim_dev(k4_index* ix, int pe, int64_t n, int32_
   hipLaunchKernelGGL(k4k_prepare_reads, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, st, pe ? 1 : 0, n,
                      (uint32_t)std::max(min_len, 0), (uint32_t)std::max(max_len, 0), (const uint64_t*)d_offs1, (const uint32_t*)d_lens1,
                      (const uint64_t*)d_offs2, (const uint32_t*)d_lens2, reads2_base, (uint64_t*)d_offs_out, (uint32_t*)d_lens_out,
-                     tot.as<unsigned long long>(), (uint32_t)trim5, (uint32_t)trim3);
+                     tot.as<unsigned long long>(), (uint32_t)trim5, (uint32_t)trim3, (uint32_t)sample_nth, first_unit);
   unsigned long long t[3];
   K4_HIP(ix, hipMemcpyAsync(t, tot.p, 24, hipMemcpyDeviceToHost, st));
   K4_HIP(ix, hipStreamSynchronize(st));

@@ -99,6 +99,7 @@ struct k4_pipeline {
   uint64_t n_under = 0, n_over = 0;
   int n_ends = 1;
   int32_t trim5 = 0, trim3 = 0;  // kalign -y / -Y (k4_pipeline_set_trims)
+  int32_t sample_nth = 1;        // kalign -#<n> (k4_pipeline_set_sampling)
   // worker
   std::thread worker;
   std::mutex m;
@@ -192,7 +193,7 @@ int align_more(k4_pipeline* pl, bool flush) {
   uint64_t under = 0, over = 0;
   uint32_t max_len = 0;
   const int64_t d = pl->units_done;
-  rc = k4_prepare_reads_trim_dev(ix, pe ? 1 : 0, n, pl->prm.min_len, pl->prm.max_len, pl->trim5, pl->trim3, pl->end[0].offs.p + 8 * d, pl->end[0].lens.p + 4 * d,
+  rc = k4_prepare_reads_trim_dev(ix, pe ? 1 : 0, n, pl->prm.min_len, pl->prm.max_len, pl->trim5, pl->trim3, pl->sample_nth, d, pl->end[0].offs.p + 8 * d, pl->end[0].lens.p + 4 * d,
                             pe ? pl->end[1].offs.p + 8 * d : nullptr, pe ? pl->end[1].lens.p + 4 * d : nullptr, 0,
                             pl->c_offs.p + 8 * r0, pl->c_lens.p + 4 * r0, &under, &over, &max_len, pl->s_comp);
   if (rc != K4_OK) return rc;
@@ -363,6 +364,13 @@ extern "C" int k4_pipeline_set_trims(k4_pipeline* pl, int32_t trim5, int32_t tri
   if (!pl || trim5 < 0 || trim3 < 0 || trim5 > 50 || trim3 > 50) return K4_ERR_PARAMS;
   std::lock_guard<std::mutex> lk(pl->m);
   pl->trim5 = trim5; pl->trim3 = trim3;  // (read by the worker when it prepares a batch: set them before the first submit)
+  return K4_OK;
+}
+
+extern "C" int k4_pipeline_set_sampling(k4_pipeline* pl, int32_t sample_nth) {
+  if (!pl || sample_nth < 1 || sample_nth > 10000) return K4_ERR_PARAMS;
+  std::lock_guard<std::mutex> lk(pl->m);
+  pl->sample_nth = sample_nth;
   return K4_OK;
 }
 

@@ -52,6 +52,7 @@ struct Opts {
   struct MultiShared* shared = nullptr;
   int print_slices = 0;             // -W <n>: print the byte offsets -G would cut the reads files at for n ranks, and stop (no GPU needed)
   int rpt_sq_thres = 10000;         // -4 <n>: with more reference sequences than this only those with alignments are declared in the header (KAlignerCL.cpp:289,868-870)
+  int sample_nth = 1;               // -# <n>: every n-th read / pair of the input is processed (KAlignerCL.cpp:244,484-489)
   int trim5 = 0, trim3 = 0;         // -y / -Y <n>: bases taken off the 5' / 3' end of every read when loading (KAlignerCL.cpp:763-774)
   int align_strand = 0;             // -Q <0|1|2>: align to either strand, the sense or the antisense strand only (KAlignerCL.cpp:241,491)
   int fmode = 0;                    // -M <0|1>: 0 SAM / BAM with the accepted alignments, 1 SAM with every loaded read (KAlignerCL.cpp:217)
@@ -383,7 +384,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam|out.bam [-z bgzf level=6] [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-4 all @SQ up to n=10000] [-y trim5] [-Y trim3] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-# every nth read] [-4 all @SQ up to n=10000] [-y trim5] [-Y trim3] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
 }  // namespace
@@ -558,7 +559,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     void *d_offs = nullptr, *d_lens = nullptr;
     CK(k4_alloc_device(ix, (uint64_t)(n_reads + 1) * 8, &d_offs));
     CK(k4_alloc_device(ix, (uint64_t)(n_reads + 1) * 4, &d_lens));
-    CK(k4_prepare_reads_trim_dev(ix, pe ? 1 : 0, n, o.min_len, o.max_len, o.trim5, o.trim3, p1.d_offs, p1.d_lens, p2.d_offs, p2.d_lens, 0, d_offs, d_lens,
+    CK(k4_prepare_reads_trim_dev(ix, pe ? 1 : 0, n, o.min_len, o.max_len, o.trim5, o.trim3, 1, 0, p1.d_offs, p1.d_lens, p2.d_offs, p2.d_lens, 0, d_offs, d_lens,
                             &under, &over, &max_len, nullptr));
     auto tb = now();
     // ---- align (ProcCoredApprox / ProcessPairedEnds) ---------------------------------------------------------------
@@ -643,6 +644,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     }
     CK(k4_pipeline_open(ix, &pp2, &pl));
     CK(k4_pipeline_set_trims(pl, o.trim5, o.trim3));
+    CK(k4_pipeline_set_sampling(pl, o.sample_nth));
     auto tr = now();
     int rc_end[2] = {K4_OK, K4_OK};
     double rd[2] = {0, 0};
@@ -1034,6 +1036,7 @@ int main(int argc, char** argv) {
       case 'M': o.fmode = atoi(val().c_str()); break;
       case 'Q': o.align_strand = atoi(val().c_str()); break;
       case '4': o.rpt_sq_thres = std::max(1, atoi(val().c_str())); break;
+      case '#': o.sample_nth = std::min(10000, std::max(1, atoi(val().c_str()))); break;
       case 'y': o.trim5 = atoi(val().c_str()); break;
       case 'Y': o.trim3 = atoi(val().c_str()); break;
       case 'Z': o.legacy = true; break;
@@ -1107,6 +1110,10 @@ int main(int argc, char** argv) {
   }
   if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830
   if (o.min_flank_exacts > 7) o.min_flank_exacts = 7;
+  if (o.sample_nth > 1 && (o.in1.size() > 1 || o.batch_mb > 0 || o.n_shards > 1 || !o.gpus.empty() || o.legacy)) {
+    fprintf(stderr, "k4align: -#%d samples the reads of ONE input file per end in the pipelined single-GPU mode (not with several -i files, -b, -S i/N, -G, -Z)\n", o.sample_nth);
+    return 3;
+  }
   if (o.trim5 < 0 || o.trim5 > 50) { fprintf(stderr, "k4align: Trim 5' raw reads '-y%d' specified outside of range 0..50\n", o.trim5); return 1; }
   if (o.trim3 < 0 || o.trim3 > 50) { fprintf(stderr, "k4align: Trim 3' raw reads '-Y%d' specified outside of range 0..50\n", o.trim3); return 1; }
   if (o.align_strand < 0 || o.align_strand > 2) { fprintf(stderr, "k4align: Aligned to strand '-Q%d' specified outside of range 0..2\n", o.align_strand); return 1; }

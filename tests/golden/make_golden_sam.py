@@ -102,7 +102,9 @@ EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"]),
                # -y / -Y: bases taken off the 5' / 3' end of every read when loading (the SAM shows the trimmed read)
                "se_y7_Y12": ("se_s2", ["-s2", "-y7", "-Y12"]),
                # -4: with more reference sequences than this only those with alignments are declared in the SAM header
-               "se_s2_sq2": ("se_s2", ["-s2", "-4", "2"]), "pe_u1_y5_Y20": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-y5", "-Y20", "-l120"])}
+               "se_s2_sq2": ("se_s2", ["-s2", "-4", "2"]),
+               # -#: every n-th read / pair of the file is loaded (the first included)
+               "se_s2_nth3": ("se_s2", ["-s2", "-#3"]), "pe_u1_nth4": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-#4"]), "pe_u1_y5_Y20": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-y5", "-Y20", "-l120"])}
 
 
 def foreign_flanks(reads, frac, seed):
