@@ -386,6 +386,13 @@ int k4_format_bam_all_dev(k4_index* ix, int pe, int64_t n_units, const void* d_r
                           const void* d_pe, const void* d_seg2, const void* d_reads, const void* d_offs, const void* d_lens,
                           const k4_sam_names* names, int32_t sq_all, void** d_bam, uint64_t* bam_bytes, k4_sam_stats* stats,
                           uint8_t* chrom_hit, void* stream);
+/* k4_unaligned_fasta_dev <- kalign -j / -J (CKAligner::ReportNoneAligned / ReportMultiAlign, KAligner.cpp:3833-4020): the loaded reads
+ * whose NAR is EN or NL (which 0) / ML (which 1) as FASTA, `>lcl|na|<ReadID> <name> <ReadID>|1|<len>` (`lcl|ml` for which 1; ReadID
+ * 1.. over the loaded reads in load order) and the read as loaded at 70 bases per line, grouped by NAR.  *text: malloc'd host text
+ * (k4_free_host). */
+int k4_unaligned_fasta_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_pe, const void* d_reads,
+                           const void* d_offs, const void* d_lens, const k4_sam_names* names, int32_t which, char** text,
+                           uint64_t* text_bytes, uint64_t* n_listed, void* stream);
 /* k4_format_bam_dev <- the same alignments as uncompressed BAM records in coordinate order (CSAMfile::AddAlignment's BAM branch,
  * SAMfile.cpp:2379-2640: block_size, refID, pos, bin<<16|MAPQ<<8|l_read_name, FLAG<<16|n_cigar_op, l_seq, next_refID,
  * next_pos, tlen, read_name, cigar, 4-bit seq -- reverse complemented for a Crick alignment --, qual 0xff).  refID is the

@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
-    "k4_get_kernel_times", "k4_snp_csv_dev", "k4_snp_vcf_dev", "k4_snp_files_dev", "k4_snp_run_dev", "k4_free_host", "k4_format_bam_dev", "k4_format_sam_all_dev", "k4_pipeline_format_bam", "k4_pipeline_format_all", "k4_pipeline_format_bam_all", "k4_format_bam_all_dev", "k4_pipeline_set_trims", "k4_pipeline_set_sampling", "k4_prepare_reads_trim_dev", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
+    "k4_get_kernel_times", "k4_snp_csv_dev", "k4_snp_vcf_dev", "k4_snp_files_dev", "k4_snp_run_dev", "k4_free_host", "k4_format_bam_dev", "k4_format_sam_all_dev", "k4_pipeline_format_bam", "k4_pipeline_format_all", "k4_pipeline_format_bam_all", "k4_format_bam_all_dev", "k4_pipeline_set_trims", "k4_pipeline_set_sampling", "k4_unaligned_fasta_dev", "k4_prepare_reads_trim_dev", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
     "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
     "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",

@@ -950,6 +950,148 @@ __global__ void k4k_select_hits(int64_t n, int32_t max_ml, k4_read_result* __res
   }
 }
 
+// ---- kalign -j / -J: the reads that found no alignment, or too many, as FASTA ---------------------------------------------------
+// CKAligner::ReportNoneAligned / ReportMultiAlign (KAligner.cpp:3833-4020): for every loaded read whose NAR is EN or NL (-j) / ML (-J),
+//   >lcl|na|<ReadID> <name> <ReadID>|1|<length>      (-J: lcl|ml)         ReadID: 1.. over the loaded reads in load order
+// and the read as loaded, 70 bases to the line; the reads in the order of the sorted index: by NAR, within one NAR undefined (here:
+// load order).  These are a few per cent of the reads: one thread per read, no tiling.
+namespace {
+struct NarIs {
+  K4SamArgs a;
+  int nar;
+  __device__ bool operator()(uint32_t i) const { return a.lens[i] != 0 && k4d_sam_nar(a, i) == nar; }
+};
+struct IsLoaded {
+  const uint32_t* lens;
+  __device__ uint32_t operator()(uint32_t i) const { return lens[i] != 0 ? 1u : 0u; }
+};
+K4_DEV uint32_t k4d_fasta_rec_len(const K4SamArgs& a, int64_t i, uint32_t id) {
+  const int w = a.pe ? (int)(i & 1) : 0;
+  const int64_t rec = a.pe ? (i >> 1) : i;
+  const uint32_t len = a.lens[i];
+  return 8u + k4d_udigits(id) + 1u + a.name_len[w][rec] + 1u + k4d_udigits(id) + 3u + k4d_udigits(len) + 1u + len + (len + 69u) / 70u;
+}
+__global__ void __launch_bounds__(256) k4k_fasta_lens(K4SamArgs a, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ ids, uint64_t m,
+                                                      uint32_t* __restrict__ ll) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < m) ll[j] = k4d_fasta_rec_len(a, idx[j], ids[idx[j]] + 1);
+}
+__global__ void __launch_bounds__(256) k4k_fasta_write(K4SamArgs a, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ ids, uint64_t m,
+                                                       const uint64_t* __restrict__ lo, int multi, char* __restrict__ out) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const int64_t i = idx[j];
+  const uint32_t id = ids[i] + 1, len = a.lens[i];
+  const int w = a.pe ? (int)(i & 1) : 0;
+  const int64_t rec = a.pe ? (i >> 1) : i;
+  char* p = out + lo[j];
+  const char* head = multi ? ">lcl|ml|" : ">lcl|na|";
+  for (int q = 0; q < 8; q++) *p++ = head[q];
+  p += k4d_put_uint(p, id);
+  *p++ = ' ';
+  const uint8_t* nm = a.text[w] + a.name_off[w][rec];
+  const uint32_t nl_ = a.name_len[w][rec];
+  for (uint32_t q = 0; q < nl_; q++) *p++ = (char)nm[q];
+  *p++ = ' ';
+  p += k4d_put_uint(p, id);
+  *p++ = '|'; *p++ = '1'; *p++ = '|';
+  p += k4d_put_uint(p, len);
+  *p++ = '\n';
+  const uint8_t* s = a.reads + a.offs[i];
+  for (uint32_t q = 0; q < len; q++) {
+    *p++ = "ACGTNU-?"[s[q] & 7u];  // CSeqTrans::MapSeq2Ascii's defaults (N, undefined, InDel; SeqTrans.cpp:157-181)
+    if (q % 70 == 69 || q + 1 == len) *p++ = '\n';
+  }
+}
+}  // namespace
+
+// which: 0 = the reads without an alignment (NAR EN, then NL), 1 = the multi-aligned reads (NAR ML).  *text: malloc'd host text
+// (k4_free_host); *n_listed: records in it.
+extern "C" int k4_unaligned_fasta_dev(k4_index* ix, int pe, int64_t n_units, const void* d_rr, const void* d_pe, const void* d_reads,
+                                      const void* d_offs, const void* d_lens, const k4_sam_names* names, int32_t which, char** text,
+                                      uint64_t* text_bytes, uint64_t* n_listed, void* stream) {
+  if (!ix || !names || !text || !text_bytes || which < 0 || which > 1) return K4_ERR_PARAMS;
+  *text = nullptr;
+  *text_bytes = 0;
+  if (n_listed) *n_listed = 0;
+  if (n_units < 0) return k4_fail(ix, K4_ERR_PARAMS, "negative count");
+  const int64_t n_reads = pe ? 2 * n_units : n_units;
+  if (n_reads >= 0xFFFFFF00ll) return k4_fail(ix, K4_ERR_PARAMS, "at most 2^32-256 reads per call");
+  auto empty = [&]() { *text = (char*)calloc(1, 1); return *text ? K4_OK : k4_fail(ix, K4_ERR_MEM, "out of memory"); };
+  if (n_reads == 0) return empty();
+  if ((pe && !d_pe) || (!pe && !d_rr) || !d_reads || !d_offs || !d_lens || !names->d_text[0] || !names->d_name_off[0] || !names->d_name_len[0] ||
+      (pe && (!names->d_text[1] || !names->d_name_off[1] || !names->d_name_len[1])))
+    return k4_fail(ix, K4_ERR_PARAMS, "null buffer");
+  K4_HIP(ix, hipSetDevice(ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  PoolStream pool_scope(st);
+  K4SamArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pe = pe ? 1 : 0; a.n_reads = n_reads; a.rr = (const k4_read_result*)d_rr; a.pr = (const k4_pe_read*)d_pe; a.max_ml = 1;
+  a.reads = (const uint8_t*)d_reads; a.offs = (const uint64_t*)d_offs; a.lens = (const uint32_t*)d_lens;
+  for (int w = 0; w < 2; w++) {
+    a.text[w] = (const uint8_t*)names->d_text[w]; a.name_off[w] = (const uint64_t*)names->d_name_off[w];
+    a.name_len[w] = (const uint32_t*)names->d_name_len[w];
+  }
+  Buf ids, idx, cnt, tmp, ll, lo, outb;
+  K4_HIP(ix, ids.alloc((size_t)(n_reads + 1) * 4));
+  K4_HIP(ix, idx.alloc((size_t)n_reads * 4));
+  K4_HIP(ix, cnt.alloc(8));
+  {  // ReadID - 1: the loaded reads before this one
+    rocprim::counting_iterator<uint32_t> all(0);
+    auto loaded = rocprim::make_transform_iterator(all, IsLoaded{a.lens});
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, loaded, ids.as<uint32_t>(), 0u, (size_t)n_reads, rocprim::plus<uint32_t>(), st));
+    K4_HIP(ix, tmp.alloc(tb));
+    K4_HIP(ix, rocprim::exclusive_scan(tmp.p, tb, loaded, ids.as<uint32_t>(), 0u, (size_t)n_reads, rocprim::plus<uint32_t>(), st));
+  }
+  uint64_t m = 0;
+  const int nars[2][2] = {{K4_NAR_NS, K4_NAR_NOHIT}, {K4_NAR_MULTIALIGN, -1}};
+  for (int g = 0; g < 2; g++) {  // one group of the sorted index after the other
+    if (nars[which][g] < 0) continue;
+    rocprim::counting_iterator<uint32_t> all(0);
+    NarIs pred{a, nars[which][g]};
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::select(nullptr, tb, all, idx.as<uint32_t>() + m, cnt.as<uint64_t>(), (size_t)n_reads, pred, st));
+    Buf t2;
+    K4_HIP(ix, t2.alloc(tb));
+    K4_HIP(ix, rocprim::select(t2.p, tb, all, idx.as<uint32_t>() + m, cnt.as<uint64_t>(), (size_t)n_reads, pred, st));
+    uint64_t got = 0;
+    K4_HIP(ix, hipMemcpyAsync(&got, cnt.p, 8, hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+    m += got;
+  }
+  if (n_listed) *n_listed = m;
+  if (m == 0) return empty();
+  K4_HIP(ix, ll.alloc((m + 1) * 4));
+  K4_HIP(ix, lo.alloc((m + 1) * 8));
+  K4_HIP(ix, hipMemsetAsync(ll.as<uint32_t>() + m, 0, 4, st));
+  const unsigned mb = (unsigned)((m + 255) / 256);
+  hipLaunchKernelGGL(k4k_fasta_lens, dim3(mb), dim3(256), 0, st, a, idx.as<uint32_t>(), ids.as<uint32_t>(), m, ll.as<uint32_t>());
+  {
+    size_t tb = 0;
+    K4_HIP(ix, rocprim::exclusive_scan(nullptr, tb, ll.as<uint32_t>(), lo.as<uint64_t>(), (uint64_t)0, (size_t)(m + 1), rocprim::plus<uint64_t>(), st));
+    Buf t3;
+    K4_HIP(ix, t3.alloc(tb));
+    K4_HIP(ix, rocprim::exclusive_scan(t3.p, tb, ll.as<uint32_t>(), lo.as<uint64_t>(), (uint64_t)0, (size_t)(m + 1), rocprim::plus<uint64_t>(), st));
+  }
+  uint64_t total = 0;
+  K4_HIP(ix, hipMemcpyAsync(&total, lo.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost, st));
+  K4_HIP(ix, hipStreamSynchronize(st));
+  K4_HIP(ix, outb.alloc(total + 16));
+  hipLaunchKernelGGL(k4k_fasta_write, dim3(mb), dim3(256), 0, st, a, idx.as<uint32_t>(), ids.as<uint32_t>(), m, lo.as<uint64_t>(), (int)which, outb.as<char>());
+  char* h = (char*)malloc(total + 1);
+  if (!h) return k4_fail(ix, K4_ERR_MEM, "out of memory");
+  int rc = k4_check_hip(ix, hipMemcpyAsync(h, outb.p, total, hipMemcpyDeviceToHost, st), "copy");
+  if (rc == K4_OK) rc = k4_check_hip(ix, hipStreamSynchronize(st), "FASTA of the unaligned reads");
+  if (rc != K4_OK) { free(h); return rc; }
+  h[total] = 0;
+  *text = h;
+  *text_bytes = total;
+  return K4_OK;
+}
+
+
 extern "C" int k4_select_hits_dev(k4_index* ix, int64_t n_reads, int32_t max_ml, void* d_rr, void* d_hits, const void* d_choice,
                                   void* stream) {
   if (!ix || n_reads < 0 || max_ml < 1 || (n_reads && (!d_rr || !d_hits || !d_choice))) return K4_ERR_PARAMS;

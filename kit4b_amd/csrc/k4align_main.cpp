@@ -52,6 +52,7 @@ struct Opts {
   struct MultiShared* shared = nullptr;
   int print_slices = 0;             // -W <n>: print the byte offsets -G would cut the reads files at for n ranks, and stop (no GPU needed)
   int rpt_sq_thres = 10000;         // -4 <n>: with more reference sequences than this only those with alignments are declared in the header (KAlignerCL.cpp:289,868-870)
+  std::string none_file, multi_file; // -j / -J <file>: the reads without an alignment / the multi-aligned reads as FASTA (KAlignerCL.cpp:254-255)
   int sample_nth = 1;               // -# <n>: every n-th read / pair of the input is processed (KAlignerCL.cpp:244,484-489)
   int trim5 = 0, trim3 = 0;         // -y / -Y <n>: bases taken off the 5' / 3' end of every read when loading (KAlignerCL.cpp:763-774)
   int align_strand = 0;             // -Q <0|1|2>: align to either strand, the sense or the antisense strand only (KAlignerCL.cpp:241,491)
@@ -384,7 +385,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam|out.bam [-z bgzf level=6] [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-# every nth read] [-4 all @SQ up to n=10000] [-y trim5] [-Y trim3] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-j unaligned.fa] [-J multialigned.fa] [-# every nth read] [-4 all @SQ up to n=10000] [-y trim5] [-Y trim3] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
 }  // namespace
@@ -680,6 +681,19 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     s_parse = secs(tr, now()) - s_read;  // what the device side added behind the reading
     auto tg = now();
     CK(global_stages(v.n_units, v.max_read_len, v.d_rr, v.d_hits, v.d_seg2, v.d_pe, v.d_reads, v.d_offs, v.d_lens));
+    for (int which = 0; which < 2; which++) {  // ReportNoneAligned / ReportMultiAlign (KAligner.cpp:709-733): before the alignments are reported
+      const std::string& fn = which ? o.multi_file : o.none_file;
+      if (fn.empty()) continue;
+      char* txt = nullptr;
+      uint64_t nb = 0, nl = 0;
+      CK(k4_unaligned_fasta_dev(ix, pe ? 1 : 0, v.n_units, v.d_rr, v.d_pe, v.d_reads, v.d_offs, v.d_lens, &v.names, which, &txt, &nb, &nl, nullptr));
+      FILE* fp = fopen(fn.c_str(), "wb");
+      bool ok = fp && fwrite(txt, 1, nb, fp) == nb;
+      if (fp && fclose(fp) != 0) ok = false;
+      k4_free_host(txt);
+      if (!ok) { fprintf(stderr, "k4align: unable to write %s\n", fn.c_str()); return 5; }
+      if (chatty) fprintf(stderr, "k4align: %llu %s reads written to %s\n", (unsigned long long)nl, which ? "multi-aligned" : "unalignable", fn.c_str());
+    }
     if (o.min_snp_reads > 0) {  // ProcessSNPs (KAligner.cpp:768-790 calls it behind the alignment report): the SNP file and its side files
       auto ts = now();
       // a file name ending in .vcf: VCF instead of the CSV (KAligner.cpp:186-187)
@@ -1036,6 +1050,8 @@ int main(int argc, char** argv) {
       case 'M': o.fmode = atoi(val().c_str()); break;
       case 'Q': o.align_strand = atoi(val().c_str()); break;
       case '4': o.rpt_sq_thres = std::max(1, atoi(val().c_str())); break;
+      case 'j': o.none_file = val(); break;
+      case 'J': o.multi_file = val(); break;
       case '#': o.sample_nth = std::min(10000, std::max(1, atoi(val().c_str()))); break;
       case 'y': o.trim5 = atoi(val().c_str()); break;
       case 'Y': o.trim3 = atoi(val().c_str()); break;
@@ -1110,6 +1126,10 @@ int main(int argc, char** argv) {
   }
   if (o.splice_junct > 0 && o.min_chimeric == 0 && o.min_flank_exacts == 0) o.min_flank_exacts = o.max_subs;  // "force flank trim", :829-830
   if (o.min_flank_exacts > 7) o.min_flank_exacts = 7;
+  if ((!o.none_file.empty() || !o.multi_file.empty()) && (o.batch_mb > 0 || o.n_shards > 1 || !o.gpus.empty() || o.legacy)) {
+    fprintf(stderr, "k4align: -j / -J are written by the pipelined single-GPU mode (not with -b, -S i/N, -G, -Z)\n");
+    return 3;
+  }
   if (o.sample_nth > 1 && (o.in1.size() > 1 || o.batch_mb > 0 || o.n_shards > 1 || !o.gpus.empty() || o.legacy)) {
     fprintf(stderr, "k4align: -#%d samples the reads of ONE input file per end in the pipelined single-GPU mode (not with several -i files, -b, -S i/N, -G, -Z)\n", o.sample_nth);
     return 3;

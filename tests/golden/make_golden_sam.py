@@ -82,6 +82,25 @@ NAMES = ["A" * 100, "short/1 extra words", "tab\tafter", " leading_space", "\t \
          "with|pipe:colon;semi", "UPPER_lower-123.4", "B" * 130 + " tail"]
 
 
+def unaligned_fasta_cases(tmp):
+    """-j / -J: the reads without an alignment / the multi-aligned reads as FASTA (ReportNoneAligned / ReportMultiAlign): se_s2's and
+    pe_u1's reads (the SAM of these runs is the base case's) -> unal_<case>_none.fa.xz, unal_<case>_multi.fa.xz"""
+    for base, args in (("se_s2", ["-s2"]), ("pe_u1", ["-s2", "-U1", "-d200", "-D600"])):
+        files = []
+        for flag, suffix in (("-i", "_1"), ("-u", "_2")) if base.startswith("pe") else (("-i", ""),):
+            fa = os.path.join(tmp, "%s%s.unal.fa" % (base, suffix))
+            with lzma.open(os.path.join(HERE, "sam_%s%s.fa.xz" % (base, suffix)), "rb") as f, open(fa, "wb") as g:
+                g.write(f.read())
+            files += [flag, fa]
+        none, multi = os.path.join(tmp, base + ".none.fa"), os.path.join(tmp, base + ".multi.fa")
+        subprocess.run([NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", os.path.join(tmp, base + ".unal.sam"), "-T", "4", "-F",
+                        os.path.join(tmp, base + ".unal.log"), "-j", none, "-J", multi] + args + files, check=True, capture_output=True, timeout=600)
+        for src, tag in ((none, "none"), (multi, "multi")):
+            with open(src, "rb") as f, lzma.open(os.path.join(HERE, "unal_%s_%s.fa.xz" % (base, tag)), "wb", preset=9) as g:
+                g.write(f.read())
+        print("unaligned fasta", base, open(none).read().count(">"), open(multi).read().count(">"))
+
+
 def names_case(tmp):
     seqs = [l.strip() for l in lzma.open(os.path.join(HERE, "sam_se_s2.fa.xz"), "rt") if not l.startswith(">")]
     with open(os.path.join(HERE, "names.fa"), "w") as f, open(os.path.join(HERE, "names.fq"), "w") as q:
@@ -209,6 +228,8 @@ def main():
             print(name, hist)
         if not ONLY or "names" in ONLY:
             names_case(tmp)
+        if not ONLY or "unaligned_fasta" in ONLY:
+            unaligned_fasta_cases(tmp)
         if not ONLY or any(c in ONLY for c in EXTRA_CASES):
             extra_meta = {}
             for name, (base, args) in EXTRA_CASES.items():

@@ -731,3 +731,47 @@ def test_k4align_all_reads_mode_as_bam(golden_dir, tmp_path, case):
     assert u["cigar"] == [(u["l_seq"], "M")] and u["aux"][:3] == b"YUZ" and u["aux"][-1:] == b"\0"
     raw = open(out + ".bai", "rb").read()
     assert int.from_bytes(raw[-8:], "little") == len(recs) - n_acc  # n_no_coor
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,args", [("se_s2", ["-s2"]), ("pe_u1", ["-s2", "-U1", "-d200", "-D600"])])
+def test_k4align_writes_the_unaligned_reads_as_fasta(golden_dir, tmp_path, base, args):
+    """-j / -J: the loaded reads whose NAR is EN or NL / ML as FASTA records `>lcl|na|<ReadID> <name> <ReadID>|1|<len>` (`lcl|ml`), the
+    read as loaded at 70 bases a line (ReportNoneAligned / ReportMultiAlign, KAligner.cpp:3833-4020) -- against the files
+    `ngskit4b kalign -j -J` wrote; the groups follow the sorted index (by NAR), within one group the reference's order is undefined"""
+    import lzma
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for flag, suffix in (("-i", "_1"), ("-u", "_2")) if base.startswith("pe_") else (("-i", ""),):
+        dst = str(tmp_path / ("r%s.fa" % suffix))
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, "sam_%s%s.fa.xz" % (base, suffix))).read())
+        files += [flag, dst]
+    none, multi = str(tmp_path / "none.fa"), str(tmp_path / "multi.fa")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", str(tmp_path / "o.sam"), "-j", none, "-J", multi]
+                       + args + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+
+    def records(text):
+        return [">" + r for r in text.split(">")[1:]]
+
+    for got_path, tag in ((none, "none"), (multi, "multi")):
+        got = records(open(got_path).read())
+        want = records(lzma.open(os.path.join(golden_dir, "unal_%s_%s.fa.xz" % (base, tag))).read().decode())
+        assert sorted(got) == sorted(want) and len(want) > 5, tag
+    # -j: the EN reads come before the NL reads (the sorted index); which is which: the -M1 golden of the same run
+    import samutil
+
+    _, all_recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s_M1.sam.xz" % base))
+    nar_of = {}
+    for l in all_recs:
+        if "YU:Z:" in l:
+            f = l.split("\t")
+            nar_of[(f[0], int(f[1]) & 0xC0)] = l.rsplit("YU:Z:", 1)[1]
+    order = []
+    for r in records(open(none).read()):
+        hdr = r.split("\n", 1)[0].split(" ")
+        rid = int(hdr[2].split("|")[0])
+        order.append(nar_of[(hdr[1], (0x40 if rid % 2 == 1 else 0x80) if base.startswith("pe_") else 0)])
+    assert order == sorted(order) and set(order) == {"EN", "NL"}
