@@ -1138,6 +1138,9 @@ int main(int argc, char** argv) {
   if (o.trim3 < 0 || o.trim3 > 50) { fprintf(stderr, "k4align: Trim 3' raw reads '-Y%d' specified outside of range 0..50\n", o.trim3); return 1; }
   if (o.align_strand < 0 || o.align_strand > 2) { fprintf(stderr, "k4align: Aligned to strand '-Q%d' specified outside of range 0..2\n", o.align_strand); return 1; }
   // kalign's argument rules for the alignment proper (KAlignerCL.cpp:546-553,645-657,789-821)
+  if (o.min_len < 15 || o.min_len > 2000) { fprintf(stderr, "k4align: minimum accepted read length '-l%d' specified outside of range 15..2000\n", o.min_len); return 1; }  // cMinSeqLen..cMaxSeqLen, :776-786
+  if (o.max_len < o.min_len || o.max_len > 2000) { fprintf(stderr, "k4align: maximum accepted read length '-L%d' specified outside of range %d..2000\n", o.max_len, o.min_len); return 1; }
+  if (o.pmode < 0 || o.pmode > 3) { fprintf(stderr, "k4align: Processing mode '-m%d' specified outside of range 0..3\n", o.pmode); return 1; }
   if (o.min_edit < 1 || o.min_edit > 2) { fprintf(stderr, "k4align: Minimum edit distance '-e%d' specified outside of range 1..2\n", o.min_edit); return 1; }
   if (o.max_subs < 0 || o.max_subs > 15) { fprintf(stderr, "k4align: Max allowed substitutions per 100bp read length '-s%d' specified outside of range 0..15\n", o.max_subs); return 1; }
   if (o.max_ns < 0 || o.max_ns > 5) { fprintf(stderr, "k4align: Allowed number of indeterminate bases in reads '-n%d' specified outside of range 0..5\n", o.max_ns); return 1; }

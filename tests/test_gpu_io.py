@@ -653,7 +653,7 @@ def test_k4align_argument_defaults_and_ranges(golden_dir, tmp_path):
     for name, n in meta["nar"].items():
         assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
     for extra, word in ((["-e3"], "-e3"), (["-s16"], "-s16"), (["-n6"], "-n6"), (["-U5"], "-U5"), (["-U1", "-d10"], "-d10"), (["-U1", "-d300", "-D200"], "-D200"),
-                        (["-U1", "-D100001"], "-D100001")):
+                        (["-U1", "-D100001"], "-D100001"), (["-l10"], "-l10"), (["-L3000"], "-L3000"), (["-l200", "-L100"], "-L100"), (["-m5"], "-m5")):
         p = subprocess.run(base + extra, capture_output=True, text=True, timeout=60)
         assert p.returncode == 1 and word in p.stderr, (extra, p.stderr)
     p = subprocess.run(base + ["-s2", "-U1", "-d1500"], capture_output=True, text=True, timeout=120)  # -D then defaults to 1500: accepted
