@@ -91,6 +91,22 @@ else:
 ix.close()
 del seq, sa, reads
 torch.cuda.empty_cache()
+if os.environ.get("K4_REF_FASTQ") == "1":  # the same reads as FASTQ (Illumina-like names with a comment, qualities), gzipped with K4_REF_GZ=1
+    def to_fastq(path, mate):
+        out = path[:-3] + ".fq"
+        with open(path) as f, open(out, "w") as g:
+            while True:
+                h = f.readline()
+                if not h:
+                    break
+                sq = f.readline().rstrip("\n")
+                g.write("@%s:7:1101:%d:%d %d:N:0:ACGT\n%s\n+\n%s\n" % (h[1:].rstrip("\n"), len(sq), mate, mate, sq, "F" * len(sq)))
+        os.remove(path)
+        if os.environ.get("K4_REF_GZ") == "1":
+            subprocess.run(["gzip", "-1", out], check=True)
+            out += ".gz"
+        return out
+    in_args = [to_fastq(a, 1 + (k > 1)) if a.endswith(".fa") else a for k, a in enumerate(in_args)]
 
 SNP = os.environ.get("K4_REF_SNP") == "1"  # both programs also call SNPs (-S): the CSV files are compared
 BAM = os.environ.get("K4_REF_BAM") == "1"  # both programs write BAM (+ .bai); the decoded records are compared
