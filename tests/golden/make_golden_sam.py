@@ -122,6 +122,10 @@ EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"]),
                "se_y7_Y12": ("se_s2", ["-s2", "-y7", "-Y12"]),
                # -4: with more reference sequences than this only those with alignments are declared in the SAM header
                "se_s2_sq2": ("se_s2", ["-s2", "-4", "2"]),
+               # -n: indeterminate bases allowed in a read (a percentage of the length for reads over 100 bases)
+               "se_n0": ("se_s2", ["-s2", "-n0"]), "se_n3": ("se_s2", ["-s2", "-n3"]), "pe_u1_n4": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-n4"]),
+               # -m: sensitivity (MaxIter, core sizes), -e2: two edits to the next best
+               "se_m2_e2": ("se_s2", ["-s3", "-m2", "-e2"]), "se_m3": ("se_s2", ["-s2", "-m3"]),
                # -#: every n-th read / pair of the file is loaded (the first included)
                "se_s2_nth3": ("se_s2", ["-s2", "-#3"]), "pe_u1_nth4": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-#4"]), "pe_u1_y5_Y20": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-y5", "-Y20", "-l120"])}
 

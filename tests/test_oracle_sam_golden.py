@@ -37,6 +37,7 @@ def kalign_args(args):
         elif a.startswith("-A"): kw["max_splice_junct_len"] = int(a[2:])
         elif a.startswith("-x"): pe["min_flank_exacts"] = int(a[2:])
         elif a.startswith("-Q"): kw["strand"] = int(a[2:])             # 0 either, 1 Watson, 2 Crick
+        elif a.startswith("-n"): kw["max_ns"] = int(a[2:])
     # `-A` without `-c` / `-x` forces the flank autotrim to -s exact bases (KAlignerCL.cpp:829-830)
     if kw.get("max_splice_junct_len") and not kw.get("min_chimeric_len") and not pe.get("min_flank_exacts"):
         pe["min_flank_exacts"] = kw["max_subs"]
@@ -245,7 +246,7 @@ def test_runs_with_other_arguments_match_reference_sam(oracle, golden_dir, case)
     base = meta["reads_of"]
     kw, pe = kalign_args(meta["args"])
     h = oracle.open(os.path.join(golden_dir, "g1.sfx"))
-    oracle.set_max_iter(h, 5000)
+    oracle.set_max_iter(h, {0: 5000, 1: 10000, 2: 20000, 3: 2500}[kw["pmode"]])  # -m: KAligner.cpp's MaxIter per sensitivity
     _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
     y = sum(int(a[2:]) for a in meta["args"] if a.startswith("-y"))
     Y = sum(int(a[2:]) for a in meta["args"] if a.startswith("-Y"))
