@@ -126,6 +126,9 @@ EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"]),
                "se_n0": ("se_s2", ["-s2", "-n0"]), "se_n3": ("se_s2", ["-s2", "-n3"]), "pe_u1_n4": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-n4"]),
                # -m: sensitivity (MaxIter, core sizes), -e2: two edits to the next best
                "se_m2_e2": ("se_s2", ["-s3", "-m2", "-e2"]), "se_m3": ("se_s2", ["-s2", "-m3"]),
+               # the remaining pairing modes: -U4 (unique ends, single-end fallback), -E (both ends on the same strand), -m1 with pairs
+               "pe_u4": ("pe_u1", ["-s2", "-U4", "-d200", "-D600"]), "pe_u1_E": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-E"]),
+               "pe_u3_E_m1": ("pe_u1", ["-s3", "-U3", "-d150", "-D800", "-E", "-m1"]),
                # -#: every n-th read / pair of the file is loaded (the first included)
                "se_s2_nth3": ("se_s2", ["-s2", "-#3"]), "pe_u1_nth4": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-#4"]), "pe_u1_y5_Y20": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-y5", "-Y20", "-l120"])}
 
