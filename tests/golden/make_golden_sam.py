@@ -131,6 +131,8 @@ EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"]),
                "pe_u3_E_m1": ("pe_u1", ["-s3", "-U3", "-d150", "-D800", "-E", "-m1"]),
                # flank autotrim with pairs (AutoTrimFlanks over both ends; the pair survives or not as a whole: KAligner.cpp:653-686)
                "pe_u1_x4": ("pe_u1", ["-s4", "-U1", "-d200", "-D600", "-x4"]),
+               # -r1: multi-aligned reads are looked at up to -R loci, for the statistics only
+               "se_r1_R8": ("se_s2", ["-s2", "-r1", "-R8"]),
                # -#: every n-th read / pair of the file is loaded (the first included)
                "se_s2_nth3": ("se_s2", ["-s2", "-#3"]), "pe_u1_nth4": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-#4"]), "pe_u1_y5_Y20": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-y5", "-Y20", "-l120"])}
 

@@ -29,7 +29,7 @@ def kalign_args(args):
         elif a.startswith("-R"): kw["max_ml"] = int(a[2:])
         elif a == "-r5": kw["pe_mode"] = max(kw.get("pe_mode", 0), 2)  # MLMode eMLall: every instance reported
         elif a == "-r2": kw["pe_mode"] = 2                              # MLMode eMLrand: ... then one of them picked
-        elif a in ("-r3", "-r4"): kw["pe_mode"] = 1                     # eMLuniq / eMLmulti: multi-aligned reads keep their loci
+        elif a in ("-r1", "-r3", "-r4"): kw["pe_mode"] = 1              # eMLdist / eMLuniq / eMLmulti: multi-aligned reads keep their loci
         elif a == "-X": kw["pe_mode"] = max(kw.get("pe_mode", 0), 3)   # ... reads over the -R limit clamped to it
         elif a == "-N": kw["pe_mode"] = 4                               # ... through LocateBestMatches
         elif a.startswith("-c"): kw["min_chimeric_len"] = int(a[2:])    # the optional AlignReads phases
