@@ -26,6 +26,8 @@ CASES = {
     "snp_pe_u1": dict(args=["-s3", "-U1", "-d200", "-D600", "-p6", "-P0.05"], n=5000, L=125, seed=79, pe=True),
     # three haplotypes (the genome itself, one with a substitution every ~60 bases, one with those and more): SNP loci close enough
     # for the DiSNP / TriSNP files to fill
+    # end trims and one strand only in front of the SNP stage (the pile-up starts from the trimmed reads)
+    "snp_se_y5_Y7_Q1": dict(args=["-s3", "-y5", "-Y7", "-Q1", "-p5", "-P0.05"], n=12000, L=100, seed=82, pe=False),
     "snp_se_hap": dict(args=["-s6", "-p5", "-P0.05"], n=9000, L=100, seed=80, pe=False, hap=True),
     "snp_pe_hap_c60": dict(args=["-s6", "-c60", "-U1", "-d200", "-D600", "-p5", "-P0.05"], n=3500, L=110, seed=81, pe=True, hap=True),
 }
@@ -94,7 +96,7 @@ def main():
                 g.write(f.read())  # the coverage WIG kalign writes beside the SNP file
             for ext in (".disnp.csv", ".trisnp.csv"):  # the haplotype files kalign writes beside the SNP file
                 open(os.path.join(HERE, name + ext), "w").write(open(os.path.join(tmp, name + ext)).read())
-            if name not in ("snp_se", "snp_se_hap"):  # the same calls as VCF (a SNP file name ending in .vcf)
+            if name not in ("snp_se", "snp_se_hap", "snp_se_y5_Y7_Q1"):  # the same calls as VCF (a SNP file name ending in .vcf)
                 vcf = os.path.join(tmp, name + ".vcf")
                 subprocess.run([NGS, "kalign", "-I", os.path.join(HERE, "g1.sfx"), "-o", sam, "-T", "4", "-F", os.path.join(tmp, name + ".log"),
                                 "-S", vcf] + c["args"] + files, check=True, capture_output=True, timeout=600)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import samutil
-from test_oracle_snp import SNP_CASES, snp_args
+from test_oracle_snp import SNP_CASES, snp_args, trim_reads
 from test_oracle_sam_golden import kalign_args
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +40,7 @@ def test_snp_csv_through_the_api(k4, golden_dir, case):
         files = ix.snp_files(reads, pe_recs=out, **snp_args(SNP_CASES[case]["args"]))
     else:
         _, reads = samutil.read_fasta_xz(os.path.join(golden_dir, case + ".fa.xz"))
+        reads = trim_reads(args, reads)
         r = ix.kalign_ext_batch(reads, **kw) if "min_chimeric_len" in kw else ix.kalign_batch(reads, **kw)
         text, n = ix.snp_csv(reads, out=r["out"], hits=r["hits"], **snp_args(SNP_CASES[case]["args"]))
         files = ix.snp_files(reads, out=r["out"], hits=r["hits"], **snp_args(SNP_CASES[case]["args"]))

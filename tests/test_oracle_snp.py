@@ -23,6 +23,13 @@ def snp_args(args):
     return o
 
 
+def trim_reads(args, reads):
+    """-y / -Y: bases taken off the reads' ends when loading (KAligner.cpp:12254-12260)"""
+    y = sum(int(a[2:]) for a in args if a.startswith("-y"))
+    Y = sum(int(a[2:]) for a in args if a.startswith("-Y"))
+    return [r[y:len(r) - Y] for r in reads] if y or Y else reads
+
+
 def rows(text):
     """CSV rows as tuples with the Rank column (index 8) split off: equal p-values have no defined order in the reference's sort"""
     out, ranks = [], []
@@ -49,6 +56,7 @@ def aligned_inputs(oracle, h, case):
         nar, hits = out["nar"].copy(), out["hit"].copy()
     else:
         names, reads = samutil.read_fasta_xz(os.path.join(GOLDEN, case + ".fa.xz"))
+        reads = trim_reads(args, reads)
         if "min_chimeric_len" in kw:
             r = oracle.kalign_ext_batch(h, reads, **kw)
         else:
