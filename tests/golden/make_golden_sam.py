@@ -33,6 +33,9 @@ CASES = {
     # MLMode eMLrand: one instance, picked by rand() in load order; the reference is run with ONE thread for this case (with
     # more its draws depend on thread timing)
     "se_r2_R8": (["-s2", "-r2", "-R8"], lambda ch: synth.make_reads(ch, 3000, 100, seed=4327, n_prob=0.02, edge_frac=0.05)[0]),
+    # reads of 50 .. 700 bases in one file (-L800): every length class of the kernels against the reference's own run
+    "se_lengths": (["-s3", "-l45", "-L800"], lambda ch: sum((synth.make_reads(ch, 250, L, seed=4400 + L, sub_lambda=1.0 + L / 100.0, n_prob=0.01, edge_frac=0.03)[0]
+                                                             for L in (50, 64, 100, 129, 160, 161, 256, 257, 300, 513, 700)), [])),
     "se_r5_R8_N": (["-s3", "-r5", "-R8", "-N"], lambda ch: synth.make_reads(ch, 3000, 110, seed=4326, sub_lambda=1.5, n_prob=0.02, edge_frac=0.05)[0]),
 }
 # MLMode eMLuniq / eMLmulti (`-r3` / `-r4`): AssignMultiMatches (KAligner.cpp:5092) gives a multi-aligned read the locus that
