@@ -136,6 +136,8 @@ EXTRA_CASES = {"pe_defaults": ("pe_u1", ["-s2"]),
                "pe_u1_x4": ("pe_u1", ["-s4", "-U1", "-d200", "-D600", "-x4"]),
                # -r1: multi-aligned reads are looked at up to -R loci, for the statistics only
                "se_r1_R8": ("se_s2", ["-s2", "-r1", "-R8"]),
+               # the length filter over a file of mixed lengths: 50-base reads under -l60, 513- and 700-base reads over -L300
+               "se_lengths_l60_L300": ("se_lengths", ["-s3", "-l60", "-L300"]),
                # -#: every n-th read / pair of the file is loaded (the first included)
                "se_s2_nth3": ("se_s2", ["-s2", "-#3"]), "pe_u1_nth4": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-#4"]), "pe_u1_y5_Y20": ("pe_u1", ["-s2", "-U1", "-d200", "-D600", "-y5", "-Y20", "-l120"])}
 

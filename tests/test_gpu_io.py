@@ -663,7 +663,7 @@ def test_k4align_argument_defaults_and_ranges(golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["se_Q1", "se_Q2", "pe_u1_Q1", "pe_u3_Q2", "se_y7_Y12", "pe_u1_y5_Y20", "se_s2_sq2", "se_s2_nth3", "pe_u1_nth4", "se_n0", "se_n3", "pe_u1_n4", "se_m2_e2", "se_m3", "pe_u4", "pe_u1_E", "pe_u3_E_m1", "pe_u1_x4", "se_r1_R8"])
+@pytest.mark.parametrize("case", ["se_Q1", "se_Q2", "pe_u1_Q1", "pe_u3_Q2", "se_y7_Y12", "pe_u1_y5_Y20", "se_s2_sq2", "se_s2_nth3", "pe_u1_nth4", "se_n0", "se_n3", "pe_u1_n4", "se_m2_e2", "se_m3", "pe_u4", "pe_u1_E", "pe_u3_E_m1", "pe_u1_x4", "se_r1_R8", "se_lengths_l60_L300"])
 def test_k4align_one_strand_only_and_end_trims(golden_dir, tmp_path, case):
     """-Q1 / -Q2: alignments to the sense / antisense strand only (Align2Strand of AlignReads, the paired-end flow's single-end pass
     included); -y / -Y: bases taken off the reads' ends when loading -- against what `ngskit4b kalign` wrote for the same reads"""
