@@ -775,3 +775,23 @@ def test_k4align_writes_the_unaligned_reads_as_fasta(golden_dir, tmp_path, base,
         rid = int(hdr[2].split("|")[0])
         order.append(nar_of[(hdr[1], (0x40 if rid % 2 == 1 else 0x80) if base.startswith("pe_") else 0)])
     assert order == sorted(order) and set(order) == {"EN", "NL"}
+
+
+@pytest.mark.gpu
+def test_k4align_streamed_mode_takes_the_loading_options(golden_dir, tmp_path):
+    """-b (bounded memory, parts merged on the host) with end trims and one strand only: the same SAM as the pipelined run"""
+    import lzma
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa = str(tmp_path / "r.fa")
+    open(fa, "wb").write(lzma.open(os.path.join(golden_dir, "sam_se_s2.fa.xz")).read())
+    base = [os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-i", fa, "-s2", "-y7", "-Y12", "-Q2", "-n2"]
+    outs = []
+    for tag, extra in (("p", []), ("b", ["-b", "0.03"])):
+        out = str(tmp_path / (tag + ".sam"))
+        p = subprocess.run(base + ["-o", out] + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        outs.append([l for l in open(out).read().splitlines() if not l.startswith("@PG")])
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
+    assert all(int(l.split("\t")[1]) & 16 for l in outs[0] if not l.startswith("@")) and all(len(l.split("\t")[9]) == 81 for l in outs[0] if not l.startswith("@"))
