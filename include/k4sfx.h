@@ -508,6 +508,9 @@ int k4_copy_to_host(k4_index* ix, void* dst, const void* d_src, uint64_t bytes);
  * number of launches since the last call, and resets. */
 int k4_enable_kernel_timing(k4_index* ix, int on);
 int k4_get_kernel_times(k4_index* ix, double* fast_kernel_ms, int32_t* launches);
+/* ... both parts of a batch: the step kernels (as above) and the general kernel's passes (k4k_align_slow) that follow them on
+ * the same stream; their sum is the device time of the batch's alignment */
+int k4_get_kernel_times_split(k4_index* ix, double* step_kernels_ms, double* general_kernel_ms, int32_t* launches);
 int k4_get_counters(k4_index* ix, k4_counters* out); /* synchronises the device */
 int k4_reset_counters(k4_index* ix);
 int k4_abi_version(void);

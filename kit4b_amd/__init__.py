@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
-    "k4_get_kernel_times", "k4_snp_csv_dev", "k4_snp_vcf_dev", "k4_snp_files_dev", "k4_snp_run_dev", "k4_free_host", "k4_format_bam_dev", "k4_format_sam_all_dev", "k4_pipeline_format_bam", "k4_pipeline_format_all", "k4_pipeline_format_bam_all", "k4_format_bam_all_dev", "k4_pipeline_set_trims", "k4_pipeline_set_sampling", "k4_unaligned_fasta_dev", "k4_prepare_reads_trim_dev", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
+    "k4_get_kernel_times", "k4_get_kernel_times_split", "k4_snp_csv_dev", "k4_snp_vcf_dev", "k4_snp_files_dev", "k4_snp_run_dev", "k4_free_host", "k4_format_bam_dev", "k4_format_sam_all_dev", "k4_pipeline_format_bam", "k4_pipeline_format_all", "k4_pipeline_format_bam_all", "k4_format_bam_all_dev", "k4_pipeline_set_trims", "k4_pipeline_set_sampling", "k4_unaligned_fasta_dev", "k4_prepare_reads_trim_dev", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
     "k4_copy_to_device", "k4_copy_to_host", "k4_best_matches_batch", "k4_best_matches_batch_dev",
     "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",
@@ -217,6 +217,34 @@ def lib():
     L.k4_alloc_device.argtypes = [vp, u64, C.POINTER(vp)]
     L.k4_copy_to_device.argtypes = [vp, vp, vp, u64]
     L.k4_copy_to_host.argtypes = [vp, vp, vp, u64]
+    # (every argument list is declared: ctypes would otherwise pass a Python int -- a device address -- as a 32-bit C int)
+    dbl, pvp, pu64 = C.c_double, C.POINTER(vp), C.POINTER(u64)
+    fmt_head = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(SamNames)]  # ix .. names of the *_all / *_ext formatters
+    L.k4_format_sam_all_dev.argtypes = fmt_head + [pvp, pu64, C.POINTER(SamStats), vp, vp]
+    L.k4_format_bam_all_dev.argtypes = fmt_head + [C.c_int32, pvp, pu64, C.POINTER(SamStats), vp, vp]
+    L.k4_pipeline_format_all.argtypes = [vp, C.POINTER(SamStats), vp, pu64]
+    L.k4_pipeline_format_bam_all.argtypes = [vp, C.c_int32, C.POINTER(SamStats), vp, pu64]
+    L.k4_pipeline_set_trims.argtypes = [vp, C.c_int32, C.c_int32]
+    L.k4_pipeline_set_sampling.argtypes = [vp, C.c_int32]
+    L.k4_unaligned_fasta_dev.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(SamNames), C.c_int32, pvp, pu64, pu64, vp]
+    L.k4_prepare_reads_trim_dev.argtypes = [vp, i32, i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i64, vp, vp, vp, vp, u64,
+                                            vp, vp, pu64, pu64, C.POINTER(u32), vp]
+    snp_head = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, C.c_int32, dbl, dbl]  # ix, pe .. snp_nonref_pcnt
+    L.k4_snp_csv_dev.argtypes = snp_head + [pvp, pu64, pu64, vp]
+    L.k4_snp_vcf_dev.argtypes = snp_head + [pvp, pu64, pu64, vp]
+    L.k4_snp_files_dev.argtypes = [vp, i32] + snp_head[1:] + [pvp, pu64, pu64, pvp, pu64, vp]
+    L.k4_snp_run_dev.argtypes = [vp, i32] + snp_head[1:] + [vp, vp]
+    L.k4_free_host.argtypes = [vp]
+    L.k4_free_host.restype = None
+    L.k4_sfx_map.argtypes = [C.c_char_p, vp]
+    L.k4_sfx_unmap.argtypes = [vp]
+    L.k4_sfx_unmap.restype = None
+    L.k4_set_raw_header.argtypes = [vp, vp]
+    L.k4_set_description.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.k4_get_sfx_header.argtypes = [vp, vp]
+    L.k4_abi_version.argtypes = []
+    L.k4_global_error.argtypes = []
+    L.k4_get_kernel_times_split.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -361,6 +389,12 @@ class SfxIndex:
         ms, n = C.c_double(0), C.c_int32(0)
         self._ck(lib().k4_get_kernel_times(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_times_split(self):
+        """(k4k_align_step ms, k4k_align_slow ms, batches) since the last call; synchronises."""
+        ms, g, n = C.c_double(0), C.c_double(0), C.c_int32(0)
+        self._ck(lib().k4_get_kernel_times_split(self.h, C.byref(ms), C.byref(g), C.byref(n)))
+        return ms.value, g.value, n.value
 
     def reserve(self, max_reads, max_read_len, max_hits):
         self._ck(lib().k4_reserve(self.h, max_reads, max_read_len, max_hits))
@@ -561,10 +595,6 @@ class SfxIndex:
         d_reads = torch.from_numpy(np.concatenate([cat, np.zeros(16, np.uint8)])).to(dev)
         d_offs, d_lens = t(offs), t(lens)
         L = lib()
-        L.k4_snp_csv_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
-                                     C.POINTER(C.c_uint64), C.c_void_p]
-        L.k4_free_host.argtypes = [C.c_void_p]
         csv, nb, ns = C.c_void_p(), C.c_uint64(), C.c_uint64()
         if pe_recs is not None:
             d_pe = t(pe_recs)
@@ -595,9 +625,6 @@ class SfxIndex:
         d_reads = torch.from_numpy(np.concatenate([cat, np.zeros(16, np.uint8)])).to(dev)
         d_offs, d_lens = t(offs), t(lens)
         L = lib()
-        L.k4_snp_run_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_int32, C.c_double, C.c_double, C.POINTER(SnpFiles), C.c_void_p]
-        L.k4_free_host.argtypes = [C.c_void_p]
         f = SnpFiles()
         if pe_recs is not None:
             d_pe = t(pe_recs)

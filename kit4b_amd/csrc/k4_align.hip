@@ -828,6 +828,12 @@ struct K4Slow {
   uint32_t* lhash;   // first general pass over 4-byte suffix elements: the dedupe table in LDS (ids only, cleared per strand pass)
   uint32_t lcap;     // its slots (power of two); lused: slots taken so far in this strand pass, retracted inserts included
   uint32_t lused;
+  // the batched LocateCoreMultiples (k4d_lcm_batched) looks at both strands in one go: the reverse complement of the probe sits
+  // behind the forward one -- bytes at probe + pstride, packed words at pk + pkstride -- and never changes while a read is worked on
+  uint32_t pstride, pkstride;
+  uint64_t* g_lb;    // LDS [K4_GROUP]: first suffix-array index of (strand, core) pair j's bucket / run
+  uint64_t* g_pre;   // LDS [K4_GROUP + 1]: slots in front of pair j; [pairs] = slots of the group
+  uint16_t* g_o;     // LDS [K4_GROUP]: core offset of pair j
 #ifdef K4_SLOW_PROF
   unsigned long long prof[16];
 #endif
@@ -1031,10 +1037,11 @@ K4_DEV void k4d_pack_probe_wave(K4Slow& sc, int len) {
   sc.packed = __ballot(bad) == 0;
   __syncthreads();
 }
-K4_DEV uint64_t k4d_probe_chunk(const K4Slow& sc, int j) {  // 32 probe bases from base j
+K4_DEV uint64_t k4d_probe_chunk(const K4Slow& sc, int j, int s = 0) {  // 32 probe bases from base j (s = 1: of the reverse complement)
+  const uint64_t* pk = sc.pk + (s ? sc.pkstride : 0u);
   const int w = j >> 5, sh = 2 * (j & 31);
-  const uint64_t hi = sc.pk[w];
-  return sh ? (hi << sh) | (sc.pk[w + 1] >> (64 - sh)) : hi;
+  const uint64_t hi = pk[w];
+  return sh ? (hi << sh) | (pk[w + 1] >> (64 - sh)) : hi;
 }
 
 // Hamming distance of the packed probe against the window [left, left + len) (no exception in it): two 16-byte loads per
@@ -1057,8 +1064,8 @@ K4_DEV int k4d_lane_hamming(const K4DevIndex& ix, const K4Slow& sc, int len, int
 
 // CmpProbeTarg (SfxArray.cpp:2508-2525) by one lane: core [o, o+cl) of the probe against the suffix at pos; 0 equal,
 // 1 probe greater, -1 probe smaller (a target EOS, or the end of the block, sorts above every probe symbol)
-K4_DEV int k4d_lane_cmp(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, uint64_t pos) {
-  const uint8_t* probe = sc.probe;
+K4_DEV int k4d_lane_cmp(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, uint64_t pos, int s = 0) {
+  const uint8_t* probe = sc.probe + (s ? sc.pstride : 0u);
   if (sc.packed && pos + (uint64_t)cl <= ix.n && !k4d_any_exc_sup(ix, sc.sup, (int64_t)pos, (int64_t)pos + cl)) {
     // XOR of packed chunks, MSB-first order == symbol order.  One 16-byte load holds the first 49 bases or more: most
     // comparisons end there.
@@ -1069,12 +1076,12 @@ K4_DEV int k4d_lane_cmp(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, u
       const uint32_t sh = 2 * (uint32_t)al;
       const uint64_t hi0 = ((uint64_t)w[0] << 32) | w[1], hi1 = ((uint64_t)w[2] << 32) | w[3];
       uint64_t m = k4d_range_mask(0, cl);
-      uint64_t rc = (sh ? (hi0 << sh) | (w[2] >> (32 - sh)) : hi0) & m, pc = k4d_probe_chunk(sc, o) & m;
+      uint64_t rc = (sh ? (hi0 << sh) | (w[2] >> (32 - sh)) : hi0) & m, pc = k4d_probe_chunk(sc, o, s) & m;
       if (rc != pc) return pc > rc ? 1 : -1;
       if (cl <= 32) return 0;
       if (cl <= 64 - al) {  // (what the fifth word would add lies behind the core)
         m = k4d_range_mask(0, cl - 32);
-        rc = (hi1 << sh) & m; pc = k4d_probe_chunk(sc, o + 32) & m;
+        rc = (hi1 << sh) & m; pc = k4d_probe_chunk(sc, o + 32, s) & m;
         return rc == pc ? 0 : pc > rc ? 1 : -1;
       }
     }
@@ -1086,7 +1093,7 @@ K4_DEV int k4d_lane_cmp(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, u
       for (int c = 0; c < 4; c++)
         if (32 * c < rem) {
           const uint64_t m = k4d_range_mask(0, rem - 32 * c);
-          const uint64_t rc = rc4[c] & m, pc = k4d_probe_chunk(sc, o + 32 * (c0 + c)) & m;
+          const uint64_t rc = rc4[c] & m, pc = k4d_probe_chunk(sc, o + 32 * (c0 + c), s) & m;
           if (rc != pc) return pc > rc ? 1 : -1;
         }
     }
@@ -1189,16 +1196,16 @@ K4_DEV int64_t k4d_first_exact_wave(const K4DevIndex& ix, const K4Slow& sc, int 
 // there is none or when it is closer than the core length to the end of the block, :5981-5985).
 template <int EL>
 K4_DEV void k4d_exact_run_wave(const K4DevIndex& ix, K4Slow& sc, int o, int cl, uint32_t& n_probe, int64_t& first,
-                               int64_t& last, bool& end_cmp) {
+                               int64_t& last, bool& end_cmp, int s = 0) {
   int64_t lo = 0, hi = (int64_t)ix.n - 1;
   const int kk = min((int)ix.k, cl);
   bool acgt = true;
   uint64_t code = 0;
   if (sc.packed)  // the k-mer straight from the packed probe (two LDS words instead of kk byte reads)
-    code = k4d_probe_chunk(sc, o) >> (64 - 2 * kk);
+    code = k4d_probe_chunk(sc, o, s) >> (64 - 2 * kk);
   else
     for (int j = 0; j < kk; j++) {  // uniform: every lane reads the same LDS bytes
-      const uint32_t b = sc.probe[o + j] & 0x0f;
+      const uint32_t b = sc.probe[(s ? sc.pstride : 0u) + o + j] & 0x0f;
       if (b > 3) { acgt = false; break; }
       code = (code << 2) | b;
     }
@@ -1218,7 +1225,7 @@ K4_DEV void k4d_exact_run_wave(const K4DevIndex& ix, K4Slow& sc, int o, int cl, 
     const int64_t pv = my_lo + (int64_t)hl * my_step;
     const bool have = (half ? open[1] : open[0]) && pv <= my_hi;
     int c = 1;
-    if (have) c = k4d_lane_cmp(ix, sc, o, cl, k4d_sa_at<EL>(ix, (uint64_t)pv));
+    if (have) c = k4d_lane_cmp(ix, sc, o, cl, k4d_sa_at<EL>(ix, (uint64_t)pv), s);
     const unsigned long long hm = __ballot(have);
     const unsigned long long pm = __ballot(have && (half ? c < 0 : c <= 0));
     n_probe += (uint32_t)__popcll(hm);
@@ -1930,11 +1937,13 @@ static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t s
   const bool timed = ix->timing && ix->ev_used < 4096;
   if (timed) {
     if (ix->ev_used == ix->ev0.size()) {
-      hipEvent_t e0, e1;
+      hipEvent_t e0, e1, e2;
       K4_HIP(ix, hipEventCreate(&e0));
       K4_HIP(ix, hipEventCreate(&e1));
+      K4_HIP(ix, hipEventCreate(&e2));
       ix->ev0.push_back(e0);
       ix->ev1.push_back(e1);
+      ix->ev2.push_back(e2);
     }
     K4_HIP(ix, hipEventRecord(ix->ev0[ix->ev_used], st));
   }
@@ -1959,10 +1968,7 @@ static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t s
     hipLaunchKernelGGL((k4k_align_step<EL, NCH, false, KT>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, t, w.ids[in], w.rows[in],
                        w.ctl + 2 + (t - 1), w.ids[out], w.rows[out], w.ctl + 2 + t);
   }
-  if (timed) {
-    K4_HIP(ix, hipEventRecord(ix->ev1[ix->ev_used], st));
-    ix->ev_used++;
-  }
+  if (timed) K4_HIP(ix, hipEventRecord(ix->ev1[ix->ev_used], st));  // (launch_all records ev2 behind the general kernel and counts the set)
   return K4_OK;
 }
 
@@ -2013,6 +2019,10 @@ static int launch_all(k4_index* ix, K4AlignArgs& a, int max_len, int n_steps, hi
     hipLaunchKernelGGL((k4k_align_slow<EL, false>), dim3(sw), dim3(64), slow_lds, st, a, sw, 0, small_base, (uint32_t)K4_SMALL_HASH,
                        gen_small, slow_len);
     hipLaunchKernelGGL((k4k_align_slow<EL, false>), dim3(hw), dim3(64), slow_lds, st, a, hw, 1, big_base, w.slow_hash_cap, gen_big, slow_len);
+  }
+  if (ix->timing && ix->ev_used < ix->ev0.size() && ix->ev_used < 4096) {
+    K4_HIP(ix, hipEventRecord(ix->ev2[ix->ev_used], st));
+    ix->ev_used++;
   }
   K4_HIP(ix, hipGetLastError());
   return K4_OK;
@@ -2353,20 +2363,27 @@ extern "C" int k4_enable_kernel_timing(k4_index* ix, int on) {
   return K4_OK;
 }
 
-extern "C" int k4_get_kernel_times(k4_index* ix, double* fast_ms, int32_t* launches) {
-  if (!ix || !fast_ms || !launches) return K4_ERR_PARAMS;
+extern "C" int k4_get_kernel_times_split(k4_index* ix, double* step_ms, double* general_ms, int32_t* launches) {
+  if (!ix || !step_ms || !general_ms || !launches) return K4_ERR_PARAMS;
   K4_HIP(ix, hipSetDevice(ix->device));
   K4_HIP(ix, hipDeviceSynchronize());
-  double tot = 0;
+  double tot = 0, tot_g = 0;
   for (size_t j = 0; j < ix->ev_used; j++) {
     float ms = 0;
     K4_HIP(ix, hipEventElapsedTime(&ms, ix->ev0[j], ix->ev1[j]));
     tot += ms;
+    K4_HIP(ix, hipEventElapsedTime(&ms, ix->ev1[j], ix->ev2[j]));
+    tot_g += ms;
   }
-  *fast_ms = tot;
+  *step_ms = tot;
+  *general_ms = tot_g;
   *launches = (int32_t)ix->ev_used;
   ix->ev_used = 0;
   return K4_OK;
+}
+extern "C" int k4_get_kernel_times(k4_index* ix, double* fast_ms, int32_t* launches) {
+  double g = 0;
+  return k4_get_kernel_times_split(ix, fast_ms, &g, launches);
 }
 
 extern "C" int k4_get_counters(k4_index* ix, k4_counters* out) {

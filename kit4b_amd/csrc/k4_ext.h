@@ -13,7 +13,7 @@
 #include "k4_trim.h"
 
 // the mismatch vector of the probe laid on [left, left+len) into this lane's column of mk (N == N is a match, :5618,5651)
-K4_DEV void k4d_build_mm_vector(const K4DevIndex& ix, const K4Slow& sc, int len, uint64_t left, uint32_t* mk) {
+K4_DEV void k4d_build_mm_vector(const K4DevIndex& ix, const K4Slow& sc, int len, uint64_t left, uint32_t* mk, int s = 0) {
   if (sc.packed && !k4d_any_exc_sup(ix, sc.sup, (int64_t)left, (int64_t)left + len)) {
     for (int c0 = 0; 32 * c0 < len; c0 += 4) {
       const int rem = len - 32 * c0;
@@ -21,7 +21,7 @@ K4_DEV void k4d_build_mm_vector(const K4DevIndex& ix, const K4Slow& sc, int len,
       k4d_ref_chunks4(ix, (int64_t)left, c0, rem + (int)(left & 15) <= 128, rc);
 #pragma unroll
       for (int c = 0; c < 4; c++)
-        if (32 * c < rem) mk[(c0 + c) * 64] = k4d_mm_bits((rc[c] ^ k4d_probe_chunk(sc, 32 * (c0 + c))) & k4d_range_mask(0, rem - 32 * c));
+        if (32 * c < rem) mk[(c0 + c) * 64] = k4d_mm_bits((rc[c] ^ k4d_probe_chunk(sc, 32 * (c0 + c), s)) & k4d_range_mask(0, rem - 32 * c));
     }
     return;
   }
@@ -30,7 +30,7 @@ K4_DEV void k4d_build_mm_vector(const K4DevIndex& ix, const K4Slow& sc, int len,
   for (int c = 0; 32 * c < len; c++) {
     uint32_t m = 0;
     for (int q = 0; q < 32 && 32 * c + q < len; q++)
-      if ((sc.probe[32 * c + q] & 0x0f) != t.get((int64_t)left + 32 * c + q)) m |= 1u << q;
+      if ((sc.probe[(s ? sc.pstride : 0u) + 32 * c + q] & 0x0f) != t.get((int64_t)left + 32 * c + q)) m |= 1u << q;
     mk[c * 64] = m;
   }
 }

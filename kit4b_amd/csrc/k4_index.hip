@@ -727,6 +727,7 @@ extern "C" void k4_close(k4_index* ix) {
   k4_pool_trim_current_device();  // the ingest / emit stages' cached scratch (k4_pool.h)
   for (hipEvent_t e : ix->ev0) hipEventDestroy(e);
   for (hipEvent_t e : ix->ev1) hipEventDestroy(e);
+  for (hipEvent_t e : ix->ev2) hipEventDestroy(e);
   delete ix;
 }
 

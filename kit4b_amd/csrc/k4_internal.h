@@ -125,7 +125,7 @@ struct k4_index {
   size_t rs_cap_tasks = 0, rs_cap_reads = 0;
   hipStream_t stream = nullptr; // internal stream for the host-pointer entry points
   bool timing = false;          // bracket k4k_align_fast with events
-  std::vector<hipEvent_t> ev0, ev1;
+  std::vector<hipEvent_t> ev0, ev1, ev2;  // before the step kernels, behind them, behind the general kernel's passes
   size_t ev_used = 0;
 };
 

@@ -56,7 +56,7 @@ class OracleEngine:
 
     def timing_end(self):
         k = self.n_steps - self.n_timed0
-        return 1.0 * k, k, {"n_reads": self.n_reads * k, "n_lookup": 0, "n_probe": 0, "n_cand": 0, "n_slow": 0}
+        return (1.0 * k, 0.0), k, {"n_reads": self.n_reads * k, "n_lookup": 0, "n_probe": 0, "n_cand": 0, "n_slow": 0}
 
     def results(self):
         out = torch.from_numpy(self.r["out"].view(np.int32).reshape(self.n_reads, 6).copy())

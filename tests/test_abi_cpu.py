@@ -27,6 +27,21 @@ def test_header_symbols_all_exported(L):
     assert L.k4_abi_version() == 2
 
 
+def test_every_abi_symbol_has_its_argument_types_declared(L):
+    """ctypes passes an undeclared Python int as a 32-bit C int: a device address would be truncated.  Every symbol of the
+    ABI carries argtypes, and their number equals the parameter count of the header's declaration."""
+    hdr = open(os.path.join(ROOT, "include", "k4sfx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for s in kit4b_amd.ABI_SYMBOLS:
+        fn = getattr(L, s)
+        assert fn.argtypes is not None, s
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % s, hdr, flags=re.S)
+        assert m, s
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert len(fn.argtypes) == n, (s, len(fn.argtypes), n)
+
+
 def test_struct_sizes_match_header():
     assert C.sizeof(kit4b_amd.AlignParams) == 44  # ABI 2: + MinChimericLen, microInDelLen, MaxSpliceJunctLen
     assert C.sizeof(kit4b_amd.KalignParams) == 48

@@ -59,7 +59,7 @@ def main():
         eng.step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        fast_ms, _, _ = eng.timing_end()
+        (fast_ms, _g_ms), _, _ = eng.timing_end()
     L.k4i_debug_prof(ix.h, buf)
     v = [int(x) for x in buf]
     names = ["run_search", "walk", "hamming", "replay", "read_total", "read_setup"]
