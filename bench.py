@@ -406,7 +406,7 @@ def kernel_src_sha256():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("k4_align.hip", "k4_device.h", "k4_internal.h"):  # (k4_ext.h holds the optional phases of the general kernel only)
+    for f in ("k4_align.hip", "k4_general.hip", "k4_align_common.h", "k4_device.h", "k4_internal.h"):  # (k4_ext.h: the optional phases only)
         h.update(open(os.path.join(ROOT, "kit4b_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -5,7 +5,7 @@ Build the instrumented library first, in the container (it travels with the snap
     make -C kit4b_amd/csrc EXTRA_HIPFLAGS=-DK4_SLOW_PROF OBJDIR=../_build_prof OUT=../libk4sfx_prof.so ../libk4sfx_prof.so
 then on the GPU box:
     python tools/slow_prof.py [--reads 20000000] [--chrom-mbp 125] [--repeats 40000]
-Prints one JSON line: cycles per section summed over waves (the sections of k4d_lcm_slow, see K4_SLOW_PROF in k4_align.hip),
+Prints one JSON line: cycles per section summed over waves (the sections of k4d_lcm_batched, see K4_SLOW_PROF in k4_general.hip),
 their shares, and per-read / per-run averages.  A development tool: not part of the test suite, the bench or the product."""
 import argparse
 import ctypes as C
@@ -62,27 +62,29 @@ def main():
         (fast_ms, _g_ms), _, _ = eng.timing_end()
     L.k4i_debug_prof(ix.h, buf)
     v = [int(x) for x in buf]
-    names = ["run_search", "walk", "hamming", "replay", "read_total", "read_setup"]
+    # slots of K4_SLOW_PROF in k4_general.hip (k4d_lcm_batched): cycles 0 lookup (k-mer table, deep-bucket searches, prefix sums),
+    # 1 slots (suffix elements + windows: member? distance?), 2 replay, 4 whole reads, 5 read set-up; counts 6 (strand, core)
+    # pairs, 7 slots evaluated, 8 groups, 9 steps, 10 in-bounds members, 11 reads, 12 members, 13..15 reads by phases done before
+    names = ["lookup", "slots", "replay", "unused", "read_total", "read_setup"]
     cyc = dict(zip(names, v[:6]))
-    n_runs, n_steps, n_lcm, n_reads, n_members = v[8], v[9], v[10], v[11], v[12]
+    n_pairs, n_slots, n_groups, n_steps, n_inb, n_reads, n_members = v[6], v[7], v[8], v[9], v[10], v[11], v[12]
     tot = max(cyc["read_total"], 1)
     ctr = ix.counters()
-    # random touches of the general kernel: every pivot of a run search reads one suffix element and one window, every
-    # in-bounds run member probes its wave's dedupe table (load + compare-and-swap) and fetches one window (two 16-byte
-    # loads of one or two adjacent lines: counted once).  The members' suffix elements are consecutive: not random.
-    slow_ms = dt * 1e3 - fast_ms
-    touches = 2 * v[7] + 3 * v[10]
+    slow_ms = _g_ms
     print(json.dumps({
-        "step_kernels_ms": fast_ms, "general_kernel_ms_est": slow_ms,
-        "general_kernel_random_touches": touches, "general_kernel_Gtouches_s": touches / max(slow_ms, 1e-9) / 1e6,
-        "calibration_Gtouches_s": 49.0,
+        "step_kernels_ms": fast_ms, "general_kernel_ms": slow_ms,
         "lib": a.lib, "reads": a.reads, "batch_ms": dt * 1e3, "slow_reads": n_reads, "cycles": cyc,
-        "share_of_read_total": {k: round(cyc[k] / tot, 3) for k in names if k != "read_total"},
-        "per_slow_read": {"cycles": tot / max(n_reads, 1), "lookups": v[6] / max(n_reads, 1), "runs": n_runs / max(n_reads, 1),
-                          "walk_steps": n_steps / max(n_reads, 1), "run_members": n_members / max(n_reads, 1)},
-        "from_phase_hist": v[13:16], "search_cycles_per_lookup": cyc["run_search"] / max(v[6], 1),
-        "per_run": { "members": n_members / max(n_runs, 1), "steps": n_steps / max(n_runs, 1)},
-        "per_step_cycles": {"walk": cyc["walk"] / max(n_steps, 1), "hamming": cyc["hamming"] / max(n_steps, 1), "replay": cyc["replay"] / max(n_steps, 1)},
+        "share_of_read_total": {k: round(cyc[k] / tot, 3) for k in names if k not in ("read_total", "unused")},
+        "per_slow_read": {"cycles": tot / max(n_reads, 1), "pairs": n_pairs / max(n_reads, 1), "groups": n_groups / max(n_reads, 1),
+                          "steps": n_steps / max(n_reads, 1), "slots": n_slots / max(n_reads, 1), "members": n_members / max(n_reads, 1),
+                          "in_bounds_members": n_inb / max(n_reads, 1)},
+        "from_phase_hist": v[13:16],
+        "per_group_cycles": {"lookup": cyc["lookup"] / max(n_groups, 1)},
+        "per_step_cycles": {"slots": cyc["slots"] / max(n_steps, 1), "replay": cyc["replay"] / max(n_steps, 1)},
+        "slots_per_s_G": n_slots / max(slow_ms, 1e-9) / 1e6,
+        "replay_parts_per_step_cycles": {"open": v[16] / max(n_steps, 1), "filters_insert": v[17] / max(n_steps, 1), "limits_unclean": v[18] / max(n_steps, 1),
+                                         "fold": v[19] / max(n_steps, 1)},
+        "per_step": {"segments": v[21] / max(n_steps, 1), "fold_iterations": v[22] / max(n_steps, 1), "unclean_candidates": v[20] / max(n_steps, 1)},
         "counters": {k: int(ctr[k]) for k in ("n_lookup", "n_probe", "n_cand", "n_slow")},
     }))
 
