@@ -189,6 +189,6 @@ extern "C" void k4_comm_close(k4_comm* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->comm) ncclCommDestroy(c->comm);
-  if (c->st) hipStreamDestroy(c->st);
+  if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }

@@ -160,6 +160,43 @@ K4_DEV uint32_t k4d_ref_base(const K4DevIndex& ix, uint64_t pos) {
   return (w >> (30 - 2 * (uint32_t)(pos & 15))) & 3;
 }
 
+// Exact target symbols for a lane that walks along the reference: one packed word per 16 bases; the exception bitmap is
+// consulted once per 256-base block, and inside a flagged block the block's place in the nibble store is looked up ONCE
+// (k4d_ref_base searches the block list for every symbol: eleven dependent loads at 2000 flagged blocks) and its nibbles come
+// eight per load.  Beyond the block: a separator.
+struct K4Tb {
+  const K4DevIndex* ix;
+  int64_t cw, cblk;   // the cached word (packed word / nibble word of the cached block), the cached block
+  uint32_t word, exr; // exr: rank of the cached block among the flagged ones
+  bool flagged;
+  K4_DEV void init(const K4DevIndex& x) { ix = &x; cw = -1; cblk = -1; word = 0; exr = 0; flagged = false; }
+  K4_DEV uint32_t get(int64_t pos) {
+    if (pos < 0 || (uint64_t)pos >= ix->n) return 7u;
+    const int64_t blk = pos >> K4_EXC_SHIFT;
+    if (blk != cblk) {
+      cblk = blk;
+      cw = -1;
+      flagged = (ix->excbm[blk >> 5] >> (blk & 31)) & 1;
+      if (flagged) {
+        uint32_t lo = 0, hi = ix->n_exc;  // lower_bound over the sorted flagged-block list
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (ix->excblk[mid] < (uint32_t)blk) lo = mid + 1; else hi = mid;
+        }
+        exr = lo;
+      }
+    }
+    if (flagged) {
+      const int64_t w = pos >> 3;
+      if (w != cw) { cw = w; word = ix->excnib[(uint64_t)exr * (K4_EXC_BLOCK / 8) + (uint32_t)((pos & (K4_EXC_BLOCK - 1)) >> 3)]; }
+      return (word >> (4 * (uint32_t)(pos & 7))) & 0xF;
+    }
+    const int64_t w = pos >> 4;
+    if (w != cw) { cw = w; word = ix->ref2[w]; }
+    return (word >> (30 - 2 * (uint32_t)(pos & 15))) & 3;
+  }
+};
+
 // MapChunkHit2Entry (libkit4b/SfxArray.cpp:2609-2654): index of the entry holding concat offset ofs, -1 on a separator
 K4_DEV int k4d_map_entry(const K4DevIndex& ix, uint64_t ofs) {
   int lo = 0, hi = (int)ix.n_entries - 1;

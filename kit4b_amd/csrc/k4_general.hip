@@ -201,9 +201,10 @@ K4_DEV void k4d_lane_range(const K4DevIndex& ix, const uint8_t* probe, int jlo, 
     }
     return;
   }
+  K4Tb tb;
+  tb.init(ix);
   for (int j = jlo; j < jhi; j++) {
-    const uint64_t g = left + (uint64_t)j;
-    const uint32_t t = g < ix.n ? k4d_ref_base(ix, g) : 7u;
+    const uint32_t t = tb.get((int64_t)(left + (uint64_t)j));
     if (t == 7) eos = true;
     if ((probe[j] & 0x0f) != t) {  // (a target EOS never equals a probe symbol)
       all_eq = false;
@@ -332,9 +333,10 @@ K4_DEV int k4d_lane_cmp(const K4DevIndex& ix, const K4Slow& sc, int o, int cl, u
     }
     return 0;
   }
+  K4Tb tb;
+  tb.init(ix);
   for (int j = 0; j < cl; j++) {
-    const uint64_t g = pos + (uint64_t)j;
-    const uint32_t t = g < ix.n ? k4d_ref_base(ix, g) : 7u;
+    const uint32_t t = tb.get((int64_t)(pos + (uint64_t)j));
     const uint32_t pb = probe[o + j] & 0x0f;
     if (t == 7) return -1;
     if (pb != t) return pb > t ? 1 : -1;

@@ -1,26 +1,6 @@
-// kit4b_amd/csrc/k4_trim.h -- CSfxArray::AdaptiveTrim (libkit4b/SfxArray.cpp:5561-5795) on a mismatch bit vector, and the exact
-// target-symbol reader it is fed from; shared by the chimeric pass of AlignReads (k4_ext.h, general kernel) and the chimeric mate
+// kit4b_amd/csrc/k4_trim.h -- CSfxArray::AdaptiveTrim (libkit4b/SfxArray.cpp:5561-5795) on a mismatch bit vector; shared by the chimeric pass of AlignReads (k4_ext.h, general kernel) and the chimeric mate
 // rescue of AlignPairedRead (k4_pe.hip).  gfx950 only; needs k4_device.h.
 #pragma once
-
-// ---- exact target symbols for a lane that walks along the reference: one packed word per 16 bases, the exception bitmap
-// consulted once per 256-base block; beyond the block: a separator ---------------------------------------------------------
-struct K4Tb {
-  const K4DevIndex* ix;
-  int64_t cw, cblk;
-  uint32_t word;
-  bool flagged;
-  K4_DEV void init(const K4DevIndex& x) { ix = &x; cw = -1; cblk = -1; word = 0; flagged = false; }
-  K4_DEV uint32_t get(int64_t pos) {
-    if (pos < 0 || (uint64_t)pos >= ix->n) return 7u;
-    const int64_t blk = pos >> K4_EXC_SHIFT;
-    if (blk != cblk) { cblk = blk; flagged = (ix->excbm[blk >> 5] >> (blk & 31)) & 1; }
-    if (flagged) return k4d_ref_base(*ix, (uint64_t)pos);
-    const int64_t w = pos >> 4;
-    if (w != cw) { cw = w; word = ix->ref2[w]; }
-    return (word >> (30 - 2 * (uint32_t)(pos & 15))) & 3;
-  }
-};
 
 // ---- AdaptiveTrim (SfxArray.cpp:5561-5795) over a mismatch bit vector: bit j of word j >> 5 (LSB first) is set when read
 // base j differs from the target.  The vector of lane l sits at mk[w * 64 + l] (LDS).  The reference's regions are the runs
