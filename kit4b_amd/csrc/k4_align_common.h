@@ -72,6 +72,7 @@ struct K4AlignArgs {
   int32_t mode;       // 0: AlignReads with uniform parameters, 1: CKAligner::AlignRead
   int32_t sparse_hits; // hit slots that hold no reported instance are left as they are (internal callers that never read them)
   int32_t best;       // mode 0 only: LocateBestMatches instead of AlignReads (every read runs in the general kernel)
+  int32_t deep_general; // a read that meets a k-mer bucket deeper than K4_DEFER_BUCKET leaves the step kernels for the general one (repeat-rich indexes)
   k4_align_params ap;
   k4_kalign_params kp;  // min_core_len / max_num_slides already resolved
   int32_t* rslt;
