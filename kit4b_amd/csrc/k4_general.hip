@@ -49,6 +49,8 @@ struct K4Slow {
   uint64_t* g_lb;    // LDS [K4_GROUP]: first suffix-array index of (strand, core) pair j's bucket / run
   uint64_t* g_pre;   // LDS [K4_GROUP + 1]: slots in front of pair j; [pairs] = slots of the group
   uint16_t* g_o;     // LDS [K4_GROUP]: core offset of pair j
+  uint64_t* g_cm;    // LDS [K4_GROUP][4]: pair j's core as masks over the four 32-base chunks of a read of up to 128 bases
+  uint64_t* g_lm;    // LDS [4]: the read's own bases, likewise
 #ifdef K4_SLOW_PROF
   unsigned long long prof[24];
 #endif
@@ -532,6 +534,26 @@ K4_DEV void k4d_lane_window(const K4DevIndex& ix, const K4Slow& sc, int s, int o
   core_eq = diff == 0;
 }
 
+// ... for a read of up to 128 bases from its nine words (fetched before the exception test, so that the test's own memory
+// access runs beside them): chunk masks of the core (cm) and of the read (lm) come from LDS, the 64-bit funnel shifts from two
+// 32-bit v_alignbit each
+K4_DEV void k4d_lane_window128(const K4Slow& sc, const uint32_t (&wv)[9], int64_t left, int s, const uint64_t* cm, bool& core_eq, int& mm) {
+  const uint32_t sh = (uint32_t)(left & 15) * 2;
+  const uint64_t* pk = sc.pk + (s ? sc.pkstride : 0u);
+  uint64_t diff = 0;
+  mm = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    // 64 bits of the window from bit offset sh of the words 2c, 2c+1, 2c+2 (sh < 32): alignbit(hi, lo, 32 - sh) = (hi:lo) >> (32 - sh)
+    const uint32_t hi = sh ? __builtin_amdgcn_alignbit(wv[2 * c], wv[2 * c + 1], 32 - sh) : wv[2 * c];
+    const uint32_t lo = sh ? __builtin_amdgcn_alignbit(wv[2 * c + 1], wv[2 * c + 2], 32 - sh) : wv[2 * c + 1];
+    const uint64_t x = ((((uint64_t)hi << 32) | lo) ^ pk[c]) & sc.g_lm[c];
+    mm += (int)k4d_mm_count(x);
+    diff |= x & cm[c];
+  }
+  core_eq = diff == 0;
+}
+
 K4_DEV uint64_t k4d_wave_excl_scan(uint64_t v, int lane, uint64_t& total) {
   unsigned long long x = v;
   for (int d = 1; d < 64; d <<= 1) {
@@ -607,6 +629,10 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
       }
     }
     if (np == 0) break;
+    if (len <= 128 && lane < np) {  // (lane j made pair j)
+#pragma unroll
+      for (int c = 0; c < 4; c++) sc.g_cm[4 * lane + c] = k4d_range_mask(my_o - 32 * c, my_o + cl - 32 * c);
+    }
     K4_PROF_T(pg0);
     K4_PROF_ADD(8, 1);
     K4_PROF_ADD(6, np);
@@ -689,9 +715,15 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
         o = (int)sc.g_o[pj];
         s = (int)((smask >> pj) & 1ull);
         left = (int64_t)pos - o;
-        clean = sc.packed && left >= 0 && (uint64_t)left + (uint64_t)len <= ix.n && !k4d_any_exc_sup(ix, sc.sup, left, left + len);
-        if (clean) k4d_lane_window(ix, sc, s, o, cl, len, left, core_eq, mm);
-        else core_eq = k4d_lane_cmp(ix, sc, o, cl, pos, s) == 0;
+        const bool inside = sc.packed && left >= 0 && (uint64_t)left + (uint64_t)len <= ix.n;
+        uint32_t wv[9];
+        if (inside && len <= 128) k4d_ref_words9(ix, left, 0, len + (int)(left & 15) <= 128, wv);  // on their way during the test below
+        clean = inside && !k4d_any_exc_sup(ix, sc.sup, left, left + len);
+        if (clean) {
+          if (len <= 128) k4d_lane_window128(sc, wv, left, s, sc.g_cm + 4 * pj, core_eq, mm);
+          else k4d_lane_window(ix, sc, s, o, cl, len, left, core_eq, mm);
+        } else
+          core_eq = k4d_lane_cmp(ix, sc, o, cl, pos, s) == 0;
       }
       const unsigned long long validm = __ballot(valid);
       n_probe += (uint32_t)__popcll(validm);
@@ -1054,9 +1086,11 @@ __host__ __device__ static inline size_t k4_slow_shared_lds(uint32_t n_entries) 
 __host__ __device__ static inline size_t k4_slow_wave_lds(int max_len, bool chim) {
   const size_t tail = chim ? (size_t)64 * 4 * ((max_len + 31) / 32 + 1) : 0;
   return 2 * k4_slow_pk_words(max_len) * 8 + 2 * k4_slow_probe_bytes(max_len) + (size_t)K4_GROUP * 8 + (size_t)(K4_GROUP + 2) * 8 + (size_t)K4_GROUP * 2 +
+         (size_t)K4_GROUP * 4 * 8 + 4 * 8 +
          (tail > (size_t)K4_LDS_HASH * 4 ? tail : (size_t)K4_LDS_HASH * 4);
 }
-template <int EL, bool EXT>
+// BEST: the instantiation for LocateBestMatches (-N) only -- a different walk with its own registers, kept out of the other two
+template <int EL, bool EXT, bool BEST = false>
 __global__ void __launch_bounds__(64 * K4_SLOW_WPB) __attribute__((amdgpu_waves_per_eu(EXT ? K4_SLOW_WAVES_PER_EU_EXT : K4_SLOW_WAVES_PER_EU))) k4k_align_slow(K4AlignArgs a, uint32_t n_waves, int pass, uint64_t* hash_base,
                                                      uint32_t hash_cap, uint32_t* gen_base, int max_len, int chim) {
   extern __shared__ uint64_t slow_lds[];
@@ -1071,7 +1105,9 @@ __global__ void __launch_bounds__(64 * K4_SLOW_WPB) __attribute__((amdgpu_waves_
   uint8_t* probe_s = reinterpret_cast<uint8_t*>(pk_s + 2 * k4_slow_pk_words(max_len));
   uint64_t* glb_s = reinterpret_cast<uint64_t*>(probe_s + 2 * k4_slow_probe_bytes(max_len));
   uint64_t* gpre_s = glb_s + K4_GROUP;
-  uint16_t* go_s = reinterpret_cast<uint16_t*>(gpre_s + K4_GROUP + 2);
+  uint64_t* gcm_s = gpre_s + K4_GROUP + 2;
+  uint64_t* glm_s = gcm_s + 4 * K4_GROUP;
+  uint16_t* go_s = reinterpret_cast<uint16_t*>(glm_s + 4);
   // (chimeric phase only) one mismatch bit vector per lane, word w of lane l at mk_s[w * 64 + l]; the pass-0 dedupe table
   // (EL == 4, lean instantiation) sits in the same place
   uint32_t* lhash_s = reinterpret_cast<uint32_t*>(go_s + K4_GROUP);
@@ -1090,7 +1126,7 @@ __global__ void __launch_bounds__(64 * K4_SLOW_WPB) __attribute__((amdgpu_waves_
     K4Slow sc;
     sc.sup = sup_s;
     sc.ent_id = ent_in_lds ? entid_s : a.ix.ent_id;
-    sc.lhash = (EL == 4 && !EXT && pass == 0) ? lhash_s : nullptr;
+    sc.lhash = (EL == 4 && !EXT && !BEST && pass == 0) ? lhash_s : nullptr;
     sc.lcap = K4_LDS_HASH;
     sc.lused = 0;
 #ifdef K4_SLOW_PROF
@@ -1104,6 +1140,8 @@ __global__ void __launch_bounds__(64 * K4_SLOW_WPB) __attribute__((amdgpu_waves_
     sc.g_lb = glb_s;
     sc.g_pre = gpre_s;
     sc.g_o = go_s;
+    sc.g_cm = gcm_s;
+    sc.g_lm = glm_s;
     sc.packed = false;
     sc.hash = hash_base + (size_t)wave * hash_cap;
     sc.cap = hash_cap;
@@ -1139,9 +1177,10 @@ __global__ void __launch_bounds__(64 * K4_SLOW_WPB) __attribute__((amdgpu_waves_
       K4_WSYNC();
       k4d_pack_probe_wave(sc, len);
       k4d_make_rc_wave(sc, len);
+      if (lane < 4) sc.g_lm[lane] = k4d_range_mask(0, len - 32 * lane);  // (k4d_lcm_batched's first K4_WSYNC comes before any use)
       K4_PROF_T(pr1);
       K4_PROF_ADD(5, pr1 - pr0);
-      if ((a.mode == 1 && a.kp.pe_mode == 4) || a.best) {  // -N (KAligner.cpp:9776-9796): LocateBestMatches instead of AlignReads
+      if (BEST) {  // -N (KAligner.cpp:9776-9796): LocateBestMatches instead of AlignReads (launch_general picks the instantiation)
         const int r = k4d_best_slow<EL>(a, sc, len, rp.tot_mm, rp.core_len, rp.core_delta, rp, &inst, hits, n_lookup, n_probe, n_cand);
         if (r == K4_NEED_SLOW) {
           n_lookup = r0; n_probe = r1; n_cand = r2;
@@ -1246,12 +1285,16 @@ static int launch_general(k4_index* ix, K4AlignArgs& a, int max_len, hipStream_t
   if (slow_lds > 48 * 1024) {
     K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_slow<EL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slow_lds));
     K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_slow<EL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slow_lds));
+    K4_HIP(ix, hipFuncSetAttribute((const void*)k4k_align_slow<EL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slow_lds));
   }
   // (no more waves than reads: a batch of one -- the facade's AlignReads -- should not pay for 8192 idle waves)
   const uint32_t sw = (uint32_t)std::min<int64_t>(K4_SLOW_WAVES, std::max<int64_t>(a.n_reads, 1));
   const uint32_t hw = (uint32_t)std::min<int64_t>(K4_HUGE_WAVES, std::max<int64_t>(a.n_reads, 1));
   const dim3 sblk(64 * K4_SLOW_WPB), sgrid((sw + K4_SLOW_WPB - 1) / K4_SLOW_WPB), hgrid((hw + K4_SLOW_WPB - 1) / K4_SLOW_WPB);
-  if (a.ext_on) {
+  if ((a.mode == 1 && a.kp.pe_mode == 4) || a.best) {
+    hipLaunchKernelGGL((k4k_align_slow<EL, false, true>), sgrid, sblk, slow_lds, st, a, sw, 0, small_base, (uint32_t)K4_SMALL_HASH, gen_small, slow_len, 0);
+    hipLaunchKernelGGL((k4k_align_slow<EL, false, true>), hgrid, sblk, slow_lds, st, a, hw, 1, big_base, w.slow_hash_cap, gen_big, slow_len, 0);
+  } else if (a.ext_on) {
     hipLaunchKernelGGL((k4k_align_slow<EL, true>), sgrid, sblk, slow_lds, st, a, sw, 0, small_base, (uint32_t)K4_SMALL_HASH, gen_small, slow_len, chim ? 1 : 0);
     hipLaunchKernelGGL((k4k_align_slow<EL, true>), hgrid, sblk, slow_lds, st, a, hw, 1, big_base, w.slow_hash_cap, gen_big, slow_len, chim ? 1 : 0);
   } else {
