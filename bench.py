@@ -214,7 +214,7 @@ def write_fasta(reads, path, dev):
     text.cpu().numpy().tofile(path)
 
 
-def time_reference(ix, reads, pe, L, max_subs, cores, sample, dev, log_fn):
+def time_reference(ix, reads, pe, L, max_subs, cores, sample, dev, log_fn, extra=()):
     """The REAL reference (`oracle/_ref/ngskit4b kalign`, built from /root/reference by oracle/Makefile and shipped with the
     snapshot) on the host cores, same index written as a .sfx file, first `sample` reads.  Returns the cpu_baseline dict
     or None.  Alignment time = the log interval "Now aligning" -> "Alignment of ... completed" (KAligner.cpp:9393-9470);
@@ -250,7 +250,7 @@ def time_reference(ix, reads, pe, L, max_subs, cores, sample, dev, log_fn):
         logf = os.path.join(tmp, "ref.log")
         t0 = time.time()
         r = subprocess.run([ngs, "kalign", "-I", sfx, "-o", os.path.join(tmp, "ref.sam"), "-T", str(cores), "-F", logf,
-                            "-s%d" % max_subs] + files, capture_output=True, timeout=900)
+                            "-s%d" % max_subs] + list(extra) + files, capture_output=True, timeout=900)
         wall = time.time() - t0
         if r.returncode != 0:
             log_fn("reference baseline failed: rc %d" % r.returncode)
@@ -271,9 +271,9 @@ def time_reference(ix, reads, pe, L, max_subs, cores, sample, dev, log_fn):
             return None
         t_al = (t_end - t_start).total_seconds()
         return {"value": sample / t_al / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "reference",
-                "sample": "first %d reads, oracle/_ref/ngskit4b kalign -s%d -T%d on the same index as a %.1f GB .sfx file; "
-                          "align phase %.1f s by its log (includes kit4b's 5 s start-up sleep, worker threads already "
-                          "running), whole run %.1f s" % (sample, max_subs, cores, os.path.getsize(sfx) / 1e9, t_al, wall),
+                "sample": ("first %d reads, oracle/_ref/ngskit4b kalign -s%d" + "".join(" " + e for e in extra) + " -T%d on the same index as a %.1f GB .sfx file; "
+                           "align phase %.1f s by its log (includes kit4b's 5 s start-up sleep, worker threads already "
+                           "running), whole run %.1f s") % (sample, max_subs, cores, os.path.getsize(sfx) / 1e9, t_al, wall),
                 "align_s": t_al, "wall_s": wall,
                 # the same interval net of the fixed 5 s sleep (an upper bound on the reference's rate: its
                 # workers do align during the sleep)
@@ -318,6 +318,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="upper bound on reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--ref-sample", type=int, default=8_000_000,
                     help="reads given to the real reference binary (oracle/_ref/ngskit4b) when it is present (0 = skip)")
+    ap.add_argument("--ext", default="",
+                    help="optional AlignReads phases (SURVEY 8(f4)), a secondary line on the workload's genome: c<pct> chimeric trimming "
+                         "(kalign -c), a<len> microInDels (-a), A<len> splice junctions (-A), comma separated, e.g. c50 or a12,A3000")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000,
                     help="reads of the end-to-end leg (FASTQ text in host memory -> SAM text in host memory; C2 at N=1 only, 0 = skip)")
     args = ap.parse_args(argv)
@@ -329,6 +332,14 @@ def parse_args(argv=None):
     args.pe = wl[4]
     args.chrom_mbp = wl[5] if args.chrom_mbp is None else args.chrom_mbp
     args.repeats = wl[6] if args.repeats is None else args.repeats
+    args.ext_kw = {}
+    for tok in filter(None, args.ext.split(",")):
+        key = {"c": "min_chimeric_len", "a": "micro_indel_len", "A": "max_splice_junct_len"}.get(tok[0])
+        if key is None or not tok[1:].isdigit():
+            ap.error("--ext: c<pct>, a<len>, A<len>")
+        args.ext_kw[key] = int(tok[1:])
+    if args.ext_kw and args.pe:
+        ap.error("--ext: the optional phases are single-end (kalign refuses -a / -A with paired ends)")
     args.std_cfg = ((args.chroms, args.reads, args.read_len, args.max_subs) == wl[:4] and args.chrom_mbp == wl[5]
                     and args.n_frac == 0 and args.repeats == wl[6])
     return args
@@ -444,8 +455,9 @@ class GpuEngine:
         self.ix.set_max_iter(5000)  # cDfltKASensCoreIters, KAligner.cpp:373-388
         log_fn("index packed: k=%d, %.1f GB in HBM, %.1fs" % (self.info["kmer_k"], self.info["device_bytes"] / 1e9, time.time() - t0))
 
-    def prepare(self, reads, n_units, L, pe, max_subs):
+    def prepare(self, reads, n_units, L, pe, max_subs, ext_kw=None):
         dev = reads.device
+        self.ext_kw = dict(ext_kw or {})
         n_reads = reads.shape[0]
         self.pe, self.n_units, self.n_reads, self.L = pe, n_units, n_reads, L
         self.reads = reads
@@ -456,7 +468,9 @@ class GpuEngine:
         else:
             self.out = torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
             self.hits = torch.zeros((n_reads, 4), dtype=torch.int32, device=dev)
-        self.kp = k4.KalignParams(max_subs, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+        self.kp = k4.KalignParams(max_subs, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0, self.ext_kw.get("min_chimeric_len", 0),
+                                  self.ext_kw.get("micro_indel_len", 0), self.ext_kw.get("max_splice_junct_len", 0))
+        self.seg2 = torch.zeros((n_reads, 4), dtype=torch.int32, device=dev) if self.ext_kw else None  # k4_seg2 records (16 B)
         self.pp = k4.PeParams(2, 200, 600, 0)  # -U2 -d200 -D600
         self.ix.reserve(n_reads, L, 10 if pe else 1)
         self.stream = torch.cuda.current_stream().cuda_stream
@@ -465,6 +479,9 @@ class GpuEngine:
         if self.pe:
             self.ix.kalign_pe_batch_dev(self.kp, self.pp, self.n_units, self.L, self.reads.data_ptr(), self.offs.data_ptr(),
                                         self.lens.data_ptr(), self.out_pe.data_ptr(), self.stream)
+        elif self.ext_kw:
+            self.ix.kalign_ext_batch_dev(self.kp, self.n_reads, self.L, self.reads.data_ptr(), self.offs.data_ptr(),
+                                         self.lens.data_ptr(), self.out.data_ptr(), self.hits.data_ptr(), self.seg2.data_ptr(), self.stream)
         else:
             self.ix.kalign_batch_dev(self.kp, self.n_reads, self.L, self.reads.data_ptr(), self.offs.data_ptr(),
                                      self.lens.data_ptr(), self.out.data_ptr(), self.hits.data_ptr(), self.stream)
@@ -576,7 +593,7 @@ def run(args, engine):
         sel = torch.nonzero(torch.rand(n_reads, device=dev, generator=g2) < args.n_frac).flatten()
         reads[sel, torch.randint(0, L, (sel.numel(),), device=dev, generator=g2)] = 4
         truth[sel, 3] = 99  # excluded from the truth property below
-    engine.prepare(reads, n_units, L, pe, args.max_subs)
+    engine.prepare(reads, n_units, L, pe, args.max_subs, args.ext_kw) if args.ext_kw else engine.prepare(reads, n_units, L, pe, args.max_subs)
     engine.sync()
     log(rank, "%d reads x %d bp synthesised in %.1fs" % (n_reads, L, time.time() - t0))
 
@@ -607,6 +624,9 @@ def run(args, engine):
     if pe:
         good &= torch.where(ok, out_pe[:, 4] == 1, out_pe[:, 4] == 0)  # FlgPEAligned
     truth_viol = int((~good).sum().item()) if args.repeats == 0 else None  # (the property needs an i.i.d. genome)
+    if args.ext_kw:  # with the optional phases a read beyond MaxTotMM may still align (trimmed, or in two segments): the weaker form
+        ok_reads = ok & (truth[:, 3] != 99)
+        truth_viol = int((ok_reads & ~((out[:, 4] == k4.NAR_ACCEPTED) & (h_chrom == truth[:, 0]) & (h_loci == truth[:, 1]))).sum().item()) if args.repeats == 0 else None
 
     # (2) CPU baseline = the oracle on all host cores over a bounded sample, same index, same reads (rank 0, N=1 only)
     cpu = None
@@ -616,7 +636,7 @@ def run(args, engine):
 
     # (3) end to end: FASTQ text in host memory -> SAM text in host memory through the overlapped pipeline (never `value`)
     e2e = None
-    if rank == 0 and world == 1 and engine.is_gpu and args.e2e_reads > 0 and not pe and hasattr(engine, "e2e"):
+    if rank == 0 and world == 1 and engine.is_gpu and args.e2e_reads > 0 and not pe and not args.ext_kw and hasattr(engine, "e2e"):
         e2e = engine.e2e(reads, min(args.e2e_reads, n_reads), L, args.max_subs, lambda *a: log(rank, *a))
 
     if rank == 0:
@@ -639,7 +659,7 @@ def run(args, engine):
         # named configuration and only while the record was taken on exactly the kernel sources of this run
         traffic = None
         traffic_source = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_hbm_%s.json" % args.workload)
+        pmc = os.path.join(ROOT, "profiles", "pmc_hbm_%s%s.json" % (args.workload, "_" + args.ext.replace(",", "_") if args.ext_kw else ""))
         if os.path.exists(pmc) and engine.is_gpu:
             rec = json.load(open(pmc))
             cur = kernel_src_sha256()
@@ -650,7 +670,7 @@ def run(args, engine):
             if match and args.std_cfg:
                 traffic = rec.get("hbm_bytes_per_launch")
         line = {
-            "metric": "Mreads/sec aligned (100 bp SE vs 3 Gbp .sfx)" if args.workload == "c2" else
+            "metric": "Mreads/sec aligned (100 bp SE vs 3 Gbp .sfx)" if args.workload == "c2" and not args.ext_kw else
                       "Mreads/sec aligned (%s%d bp %s vs %.0f Gbp .sfx%s)" % ("2x" if pe else "", L, "PE" if pe else "SE",
                                                                             n_chrom * chrom_len / 1e9, "; both ends counted" if pe else ""),
             "value": value,
@@ -669,9 +689,10 @@ def run(args, engine):
                              % (args.workload.upper(), n_units, "2x" if pe else "", L, "pairs" if pe else "SE reads",
                                 n_chrom * chrom_len / 1e9, n_chrom, chrom_len,
                                 ", %d implanted repeat copies + N runs" % args.repeats if args.repeats else "", args.max_subs,
-                                " -U2 -d200 -D600" if pe else ""))
+                                (" -U2 -d200 -D600" if pe else "") + "".join(" -%s%d" % (f, args.ext_kw[k]) for f, k in
+                                                                             (("c", "min_chimeric_len"), ("a", "micro_indel_len"), ("A", "max_splice_junct_len")) if k in args.ext_kw)))
                 + ("" if args.std_cfg else " [REDUCED: not the named configuration]")
-                + ("" if args.workload == "c2" else " [not the BASELINE metric's configuration, which is C2]"),
+                + ("" if args.workload == "c2" and not args.ext_kw else " [not the BASELINE metric's configuration, which is C2]"),
                 "reads_per_gpu": n_reads, "read_len": L, "genome_bp": n_chrom * chrom_len, "sfx_el_size": el,
                 "kmer_table_k": info["kmer_k"], "index_hbm_gb": round(info["device_bytes"] / 1e9, 2),
                 "parallelism": "reads sharded per GPU, index replicated, RCCL all-reduce of NAR counts only",
@@ -755,7 +776,10 @@ def cpu_baseline(args, engine, seq, reads, out, hits, out_pe, n, el, n_chrom, ch
         cat = reads[a:b].cpu().numpy().reshape(-1)
         o_h = (np.arange(b - a, dtype=np.uint64) * L)
         t0 = time.perf_counter()
-        r = O.kalign_batch(ho, (cat, o_h, l_all[: b - a]), max_subs=args.max_subs, threads=cores)
+        if args.ext_kw:
+            r = O.kalign_ext_batch(ho, (cat, o_h, l_all[: b - a]), max_subs=args.max_subs, threads=cores, **args.ext_kw)
+        else:
+            r = O.kalign_batch(ho, (cat, o_h, l_all[: b - a]), max_subs=args.max_subs, threads=cores)
         return r, time.perf_counter() - t0
 
     # pilot on 50k reads (also warms the page cache of the 15 GB index), then a sample sized for ~15 s of CPU work
@@ -779,21 +803,51 @@ def cpu_baseline(args, engine, seq, reads, out, hits, out_pe, n, el, n_chrom, ch
         o_hits = ro["hits"][:, 0].view(np.uint8).reshape(S, 16)
         parity_sample = {"reads": S, "result_mismatches": int((g_out != o_out).any(axis=1).sum()),
                          "hit_mismatches": int((g_hits != o_hits).any(axis=1).sum())}
+        if args.ext_kw:  # the second segments of microInDel / splice alignments
+            g_s2 = engine.seg2[:S].cpu().numpy().view(np.uint8).reshape(S, 16)
+            parity_sample["seg2_mismatches"] = int((g_s2 != ro["seg2"].view(np.uint8).reshape(S, 16)).any(axis=1).sum())
     O.close(ho)
     del seq_h, sa_h
     # the reference itself, when its binary travelled with the snapshot: that number becomes cpu_baseline, the
     # port's stays beside it (and is what the read-for-read comparison above ran against)
     if args.ref_sample > 0 and n_reads >= 1_000_000:  # (kit4b's fixed 5 s start-up sleep would swamp a small sample)
         Sr = min(args.ref_sample, n_reads) & ~1
-        ref = time_reference(ix, reads, pe, L, args.max_subs, cores, Sr, dev, lambda *a: log(rank, *a))
+        ext_flags = ["-%s%d" % (f, args.ext_kw[k]) for f, k in (("c", "min_chimeric_len"), ("a", "micro_indel_len"), ("A", "max_splice_junct_len"))
+                     if k in args.ext_kw]
+        ref = time_reference(ix, reads, pe, L, args.max_subs, cores, Sr, dev, lambda *a: log(rank, *a), extra=ext_flags)
         if ref is not None:
-            g_nar = torch.bincount(out[:Sr, 4].to(torch.int64), minlength=20).tolist()
-            codes = (("AA", 1), ("EN", 2), ("NL", 3), ("MH", 4), ("ML", 5), ("UP", 15))
+            nar_col = out[:Sr, 4]
+            if args.ext_kw:  # what kalign runs behind the alignment of a RUN (here: of these Sr reads), KAligner.cpp:653-686
+                nar_col = post_stages_nar(engine, Sr, L, args)
+            g_nar = torch.bincount(nar_col.to(torch.int64), minlength=20).tolist()
+            codes = (("AA", 1), ("EN", 2), ("NL", 3), ("MH", 4), ("ML", 5), ("ET", 6), ("OJ", 7), ("OM", 8), ("UP", 15))
             ref["nar_gpu_same_reads"] = {k: g_nar[c] for k, c in codes if g_nar[c]}
             ref["nar_equal_to_gpu"] = all(ref["nar"].get(k, 0) == g_nar[c] for k, c in codes)
             ref["port"] = cpu
             cpu = ref
     return cpu, parity_sample
+
+
+def post_stages_nar(engine, S, L, args):
+    """NAR column of the first S reads after the stages kalign runs behind the alignment when -c / -a / -A are given: flank autotrim
+    (`-A` without `-c` forces it to -s exact bases, KAlignerCL.cpp:829-830) and the orphan-junction filters -- on copies, the
+    timed buffers stay as they are"""
+    rr = engine.out[:S].clone()
+    hits = engine.hits[:S].clone()
+    seg2 = engine.seg2[:S].clone()
+    L4 = k4.lib()
+    cnt = C.c_int64(0)
+    kw = args.ext_kw
+    flank = args.max_subs if kw.get("max_splice_junct_len") and not kw.get("min_chimeric_len") else 0
+    if flank > 0:
+        engine.ix._ck(L4.k4_auto_trim_flanks_dev(engine.ix.h, min(flank, 7), 0, S, 1, rr.data_ptr(), hits.data_ptr(), engine.reads.data_ptr(),
+                                                 engine.offs.data_ptr(), engine.lens.data_ptr(), C.byref(cnt), engine.stream))
+    for on, which in ((kw.get("max_splice_junct_len"), k4.EXT_SPLICE), (kw.get("micro_indel_len"), k4.EXT_INDEL)):
+        if on:
+            engine.ix._ck(L4.k4_remove_orphan_juncts_dev(engine.ix.h, which, S, 1, rr.data_ptr(), hits.data_ptr(), seg2.data_ptr(),
+                                                         C.byref(cnt), engine.stream))
+    torch.cuda.synchronize()
+    return rr[:, 4]
 
 
 def main(argv=None, engine=None):

@@ -767,6 +767,10 @@ class SfxIndex:
         self._ck(lib().k4_kalign_batch_dev(self.h, C.byref(params), n, max_read_len, d_reads, d_offs, d_lens, d_out,
                                            d_hits, stream))
 
+    def kalign_ext_batch_dev(self, params, n, max_read_len, d_reads, d_offs, d_lens, d_out, d_hits, d_seg2, stream=0):
+        self._ck(lib().k4_kalign_ext_batch_dev(self.h, C.byref(params), n, max_read_len, d_reads, d_offs, d_lens, d_out, d_hits,
+                                               d_seg2, stream))
+
     def align_reads_batch_dev(self, params, n, max_read_len, d_reads, d_offs, d_lens, d_rslt, d_inst, d_low, d_nxt,
                               d_hits, stream=0):
         self._ck(lib().k4_align_reads_batch_dev(self.h, C.byref(params), n, max_read_len, d_reads, d_offs, d_lens,

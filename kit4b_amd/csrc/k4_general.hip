@@ -477,7 +477,7 @@ K4_DEV void k4d_exact_run_wave(const K4DevIndex& ix, K4Slow& sc, int o, int cl, 
 
 // ---- the batched LocateCoreMultiples of the general kernel ------------------------------------------------------------
 #ifndef K4_SCAN_MAX
-#define K4_SCAN_MAX 512  // k-mer buckets up to this many suffixes are laid on the read whole; deeper ones are searched for the run's bounds first
+#define K4_SCAN_MAX 128  // k-mer buckets up to this many suffixes are laid on the read whole; deeper ones are searched for the run's bounds first
 #endif
 #define K4_GROUP 64      // (strand, core) pairs looked up together
 
