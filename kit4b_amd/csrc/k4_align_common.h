@@ -39,7 +39,7 @@
 #define K4_SLOW_WAVES_PER_EU 4
 #endif
 #ifndef K4_SLOW_WAVES_PER_EU_EXT
-#define K4_SLOW_WAVES_PER_EU_EXT 2
+#define K4_SLOW_WAVES_PER_EU_EXT 3
 #endif
 // A read whose first phase meets a k-mer bucket deeper than this (a repeat family: the lower-bound search alone costs
 // log2(depth) dependent probes where its 63 wave mates need one or two) is set aside by the first launch and taken in a

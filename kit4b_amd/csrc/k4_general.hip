@@ -480,6 +480,7 @@ K4_DEV void k4d_exact_run_wave(const K4DevIndex& ix, K4Slow& sc, int o, int cl, 
 #define K4_SCAN_MAX 128  // k-mer buckets up to this many suffixes are laid on the read whole; deeper ones are searched for the run's bounds first
 #endif
 #define K4_GROUP 64      // (strand, core) pairs looked up together
+#define K4_TRIM_MAX_LEN 2048  // AdaptiveTrim turns longer reads down (:5601-5605): no mismatch vector is kept for them
 
 // the reverse complement of the probe behind the forward one (bytes as k4d_revcomp_wave would leave them, then packed)
 K4_DEV void k4d_make_rc_wave(K4Slow& sc, int len) {
@@ -537,7 +538,9 @@ K4_DEV void k4d_lane_window(const K4DevIndex& ix, const K4Slow& sc, int s, int o
 // ... for a read of up to 128 bases from its nine words (fetched before the exception test, so that the test's own memory
 // access runs beside them): chunk masks of the core (cm) and of the read (lm) come from LDS, the 64-bit funnel shifts from two
 // 32-bit v_alignbit each
-K4_DEV void k4d_lane_window128(const K4Slow& sc, const uint32_t (&wv)[9], int64_t left, int s, const uint64_t* cm, bool& core_eq, int& mm) {
+template <bool MK>
+K4_DEV void k4d_lane_window128(const K4Slow& sc, const uint32_t (&wv)[9], int64_t left, int s, const uint64_t* cm, bool& core_eq, int& mm,
+                               uint32_t* mk = nullptr) {
   const uint32_t sh = (uint32_t)(left & 15) * 2;
   const uint64_t* pk = sc.pk + (s ? sc.pkstride : 0u);
   uint64_t diff = 0;
@@ -550,6 +553,7 @@ K4_DEV void k4d_lane_window128(const K4Slow& sc, const uint32_t (&wv)[9], int64_
     const uint64_t x = ((((uint64_t)hi << 32) | lo) ^ pk[c]) & sc.g_lm[c];
     mm += (int)k4d_mm_count(x);
     diff |= x & cm[c];
+    if (MK) mk[c * 64] = k4d_mm_bits(x);  // the chimeric pass trims from the mismatch vector (k4d_build_mm_vector's form)
   }
   core_eq = diff == 0;
 }
@@ -720,10 +724,19 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
         if (inside && len <= 128) k4d_ref_words9(ix, left, 0, len + (int)(left & 15) <= 128, wv);  // on their way during the test below
         clean = inside && !k4d_any_exc_sup(ix, sc.sup, left, left + len);
         if (clean) {
-          if (len <= 128) k4d_lane_window128(sc, wv, left, s, sc.g_cm + 4 * pj, core_eq, mm);
+          if (len <= 128) k4d_lane_window128<CHIM>(sc, wv, left, s, sc.g_cm + 4 * pj, core_eq, mm, mk);
           else k4d_lane_window(ix, sc, s, o, cl, len, left, core_eq, mm);
         } else
           core_eq = k4d_lane_cmp(ix, sc, o, cl, pos, s) == 0;
+      }
+      // CHIM: AdaptiveTrim (:6097: ProbeLen, probe, target, MinProbeChimericLen, MaxTotMM, 3 flank matches) depends on the locus
+      // alone, not on the walk's state: every member's trim is worked out here, all lanes side by side, instead of pair after
+      // pair in the replay (a short chimeric core gives a dozen pairs with one or two members each)
+      K4Trim trim;
+      trim.len = trim.t5 = trim.t3 = trim.mms = 0;
+      if (CHIM && valid && core_eq && left >= 0 && len <= K4_TRIM_MAX_LEN) {
+        if (!(clean && len <= 128)) k4d_build_mm_vector(ix, sc, len, (uint64_t)left, mk, s);
+        if (k4d_trim_possible(mk, len, min_probe_chim, allow_mm)) trim = k4d_adaptive_trim(mk, len, min_probe_chim, allow_mm, 3);
       }
       const unsigned long long validm = __ballot(valid);
       n_probe += (uint32_t)__popcll(validm);
@@ -796,14 +809,7 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
           }
           const bool is_cand = (newm >> lane) & 1ull;
           bool eos = false;
-          K4Trim trim;
-          trim.len = trim.t5 = trim.t3 = trim.mms = 0;
-          if (CHIM) {  // :6097 AdaptiveTrim(ProbeLen, probe, target, MinProbeChimericLen, MaxTotMM, 3 flank matches)
-            if (is_cand) {
-              k4d_build_mm_vector(ix, sc, len, (uint64_t)left, mk, cs);
-              trim = k4d_adaptive_trim(mk, len, min_probe_chim, allow_mm, 3);
-            }
-          } else if (is_cand && !clean) {  // the Hamming extension (:6200-6261) over exact symbols
+          if (!CHIM && is_cand && !clean) {  // the Hamming extension (:6200-6261) over exact symbols
             bool all_eq;
             k4d_lane_range(ix, sc.probe + (cs ? sc.pstride : 0u), 0, len, (uint64_t)left, false, all_eq, eos, mm);
           }
@@ -1084,10 +1090,10 @@ __host__ __device__ static inline size_t k4_slow_shared_lds(uint32_t n_entries) 
   return (size_t)(n_entries <= K4_LDS_ENTRIES ? 2 * K4_LDS_ENTRIES * 8 + K4_LDS_ENTRIES * 4 : 0) + (size_t)K4_SUP_WORDS * 4;
 }
 __host__ __device__ static inline size_t k4_slow_wave_lds(int max_len, bool chim) {
-  const size_t tail = chim ? (size_t)64 * 4 * ((max_len + 31) / 32 + 1) : 0;
+  const int mk_len = max_len < K4_TRIM_MAX_LEN ? max_len : K4_TRIM_MAX_LEN;
   return 2 * k4_slow_pk_words(max_len) * 8 + 2 * k4_slow_probe_bytes(max_len) + (size_t)K4_GROUP * 8 + (size_t)(K4_GROUP + 2) * 8 + (size_t)K4_GROUP * 2 +
-         (size_t)K4_GROUP * 4 * 8 + 4 * 8 +
-         (tail > (size_t)K4_LDS_HASH * 4 ? tail : (size_t)K4_LDS_HASH * 4);
+         (size_t)K4_GROUP * 4 * 8 + 4 * 8 + (size_t)K4_LDS_HASH * 4 +
+         (chim ? (size_t)64 * 4 * ((mk_len + 31) / 32 + 1 < 4 ? 4 : (mk_len + 31) / 32 + 1) : 0);  // (k4d_lane_window128 writes four words whatever the length)
 }
 // BEST: the instantiation for LocateBestMatches (-N) only -- a different walk with its own registers, kept out of the other two
 template <int EL, bool EXT, bool BEST = false>
@@ -1108,10 +1114,10 @@ __global__ void __launch_bounds__(64 * K4_SLOW_WPB) __attribute__((amdgpu_waves_
   uint64_t* gcm_s = gpre_s + K4_GROUP + 2;
   uint64_t* glm_s = gcm_s + 4 * K4_GROUP;
   uint16_t* go_s = reinterpret_cast<uint16_t*>(glm_s + 4);
-  // (chimeric phase only) one mismatch bit vector per lane, word w of lane l at mk_s[w * 64 + l]; the pass-0 dedupe table
-  // (EL == 4, lean instantiation) sits in the same place
+  // the pass-0 dedupe table (4-byte suffix elements), then -- chimeric phase only -- one mismatch bit vector per lane, word w of
+  // lane l at mk_s[w * 64 + l]
   uint32_t* lhash_s = reinterpret_cast<uint32_t*>(go_s + K4_GROUP);
-  uint32_t* mk_s = lhash_s + lane;
+  uint32_t* mk_s = lhash_s + K4_LDS_HASH + lane;
   const uint32_t wave = blockIdx.x * K4_SLOW_WPB + (uint32_t)wib;
   uint32_t n_lookup = 0, n_probe = 0, n_cand = 0;
   if (ent_in_lds)
@@ -1126,7 +1132,7 @@ __global__ void __launch_bounds__(64 * K4_SLOW_WPB) __attribute__((amdgpu_waves_
     K4Slow sc;
     sc.sup = sup_s;
     sc.ent_id = ent_in_lds ? entid_s : a.ix.ent_id;
-    sc.lhash = (EL == 4 && !EXT && !BEST && pass == 0) ? lhash_s : nullptr;
+    sc.lhash = (EL == 4 && !BEST && pass == 0) ? lhash_s : nullptr;
     sc.lcap = K4_LDS_HASH;
     sc.lused = 0;
 #ifdef K4_SLOW_PROF

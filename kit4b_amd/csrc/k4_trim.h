@@ -91,6 +91,29 @@ K4_DEV K4Trim k4d_adaptive_trim(const uint32_t* mk, int L, int min_trim, int max
   return r;
 }
 
+// A cheap NECESSARY condition for k4d_adaptive_trim to return anything: what it returns is a stretch of cur_len >= min_trim bases
+// with cur_mm mismatches where 100 cur_mm < (max_mm + 1) cur_len (the rate test of :5763-5775; the untrimmed form allows
+// (L max_mm + 99) / 100).  A stretch that long holds a whole block of B = (min_trim + 1) / 2 bases aligned to a multiple of B,
+// and the block has no more mismatches than the stretch -- so if every aligned block holds more than the largest admissible
+// count, nothing can come back.  A chance locus of a short chimeric core fails this after a few popcounts instead of walking
+// its fifty-odd runs of equal bits three times.
+K4_DEV bool k4d_trim_possible(const uint32_t* mk, int L, int min_trim, int max_mm) {
+  if (min_trim < 2 || min_trim > L) return true;  // (k4d_adaptive_trim sorts the odd parameters out itself)
+  const int B = (min_trim + 1) / 2;
+  const int thr = max(((max_mm + 1) * L - 1) / 100, (L * max_mm + 99) / 100);
+  for (int lo = 0; lo + B <= L; lo += B) {
+    const int hi = lo + B;
+    int c = 0;
+    for (int w = lo >> 5; w <= (hi - 1) >> 5; w++) {
+      const int a = max(lo - 32 * w, 0), b = min(hi - 32 * w, 32);
+      const uint32_t m = (b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1u)) & ~((1u << a) - 1u);
+      c += __popc(mk[w * 64] & m);
+    }
+    if (c <= thr) return true;
+  }
+  return false;
+}
+
 // 32 bases of a 2-bit XOR (MSB first, two bits per base) -> one bit per base, base 0 in bit 0
 K4_DEV uint32_t k4d_mm_bits(uint64_t x) {
   uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
