@@ -361,23 +361,26 @@ K4_DEV uint64_t k4x_shfl64(uint64_t v, int src) {
   const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
   return ((uint64_t)hi << 32) | lo;
 }
-K4_DEV K4XHit k4x_from_lane(const K4XHit& x, int src) {
+K4_DEV K4XHit k4x_from_lane(const K4XHit& x, int src) {  // (every lane gets lane src's record: wave-uniform)
   K4XHit r;
-  r.l0 = k4x_shfl64(x.l0, src); r.l1 = k4x_shfl64(x.l1, src);
-  r.len0 = (uint32_t)__shfl((int)x.len0, src, 64); r.len1 = (uint32_t)__shfl((int)x.len1, src, 64);
-  r.ofs1 = (uint32_t)__shfl((int)x.ofs1, src, 64); r.mm0 = (uint32_t)__shfl((int)x.mm0, src, 64);
-  r.mm1 = (uint32_t)__shfl((int)x.mm1, src, 64); r.score = (uint32_t)__shfl((int)x.score, src, 64);
-  r.fl = (uint32_t)__shfl((int)x.fl, src, 64);
+  r.l0 = k4d_uni(k4x_shfl64(x.l0, src)); r.l1 = k4d_uni(k4x_shfl64(x.l1, src));
+  r.len0 = k4d_uni((uint32_t)__shfl((int)x.len0, src, 64)); r.len1 = k4d_uni((uint32_t)__shfl((int)x.len1, src, 64));
+  r.ofs1 = k4d_uni((uint32_t)__shfl((int)x.ofs1, src, 64)); r.mm0 = k4d_uni((uint32_t)__shfl((int)x.mm0, src, 64));
+  r.mm1 = k4d_uni((uint32_t)__shfl((int)x.mm1, src, 64)); r.score = k4d_uni((uint32_t)__shfl((int)x.score, src, 64));
+  r.fl = k4d_uni((uint32_t)__shfl((int)x.fl, src, 64));
   return r;
 }
 
 // ---- LocateInDels (SfxArray.cpp:7526-7832) / LocateSpliceJuncts (:7208-7523): two cores per strand -- the read's first and
 // last core_len bases -- every suffix of the core's run explored to the right / to the left.  MaxHits is 1 in both calls
-// (:7903,7918): only pHits[0] is ever written, a tie in score only counts. --------------------------------------------------------
+// (:7903,7918): only pHits[0] is ever written, a tie in score only counts.
+// The four (strand, core) pairs are looked up TOGETHER (k4d_group_lookup: one round of k-mer table loads, the buckets as one
+// sequence of slots) and walked 64 slots a step, pair by pair in the reference's order; the microInDel and the splice call of
+// one read use the same cores, so the second call walks the slots the first one laid out (reuse_lookup). --------------------
 template <int EL>
 K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_len, int max_tot_mm, int core_len, int strand,
                        int len, int* p_inst, int* p_low, int* p_nxt, k4_hit* hit0, k4_seg2* seg2, uint32_t& n_lookup,
-                       uint32_t& n_probe, uint32_t& n_cand) {
+                       uint32_t& n_probe, uint32_t& n_cand, bool reuse_lookup) {
   const K4DevIndex& ix = a.ix;
   const int64_t n = (int64_t)ix.n;
   const int max_iter = ix.max_iter;
@@ -391,30 +394,78 @@ K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_
   K4XHit best;
   k4x_zero(best);
   int best_inst = 0;
-  char cur_strand = '+';
-  if (strand == K4_STRAND_CRICK) { k4d_revcomp_wave(sc, len); cur_strand = '-'; }
-  do {
-    for (int phase = 0; phase < 2; phase++) {
-      const int ofs = phase == 0 ? 0 : len - core_len;
-      n_lookup++;
-      int64_t t = k4d_first_exact_wave<EL>(ix, sc, ofs, core_len, n_probe);
-      if (t == 0) continue;
-      t -= 1;
-      int iter = 0;
-      bool run_over = false;
-      for (int64_t base = t; !run_over; base += 64) {
-        const int64_t idx = base + lane;
-        const bool have = idx < n;
-        const uint64_t pos = have ? k4d_sa_at<EL>(ix, (uint64_t)idx) : 0;
-        bool fits = have;
-        if (have && idx != t) fits = splice ? !(((int64_t)pos + (phase == 0 ? len : core_len)) >= n) : !(((int64_t)pos + core_len) > n);
-        bool core_ok = have && idx == t;
-        if (!core_ok && fits) core_ok = k4d_lane_cmp(ix, sc, ofs, core_len, pos) == 0;
-        const unsigned long long bad = __ballot(!(fits && core_ok));
-        const int r = bad ? __ffsll((long long)bad) - 1 : 64;
-        n_probe += (uint32_t)(r < 64 ? r + 1 : 64);
+  if (core_len > len) return K4_HR_NONE;
+  // pair j: strand s_first + (j >> 1), core at the read's start (j even) or end (j odd)
+  const int s_first = strand == K4_STRAND_CRICK ? 1 : 0, s_last = strand == K4_STRAND_WATSON ? 0 : 1;
+  const int np = 2 * (s_last - s_first + 1);
+  unsigned long long smask = 0;
+  for (int j = 0; j < np; j++)
+    if (s_first + (j >> 1)) smask |= 1ull << j;
+  const int my_o = (lane & 1) ? len - core_len : 0;
+  const uint64_t total = reuse_lookup ? k4d_uni(sc.g_pre[np]) : k4d_group_lookup<EL>(ix, sc, np, smask, my_o, core_len, n_probe);
+  int opened = 0, iter = 0;
+  bool pair_done = false, seen_first = false, stop_all = false;
+  bool v_n = false, reload = true;
+  int pj_n = 0;
+  uint64_t pos_n = 0, base = 0;
+  while (base < total) {
+    if (reload) {
+      const uint64_t q = base + lane;
+      v_n = q < total;
+      if (v_n) {
+        while (q >= sc.g_pre[pj_n + 1]) pj_n++;
+        pos_n = k4d_sa_at<EL>(ix, sc.g_lb[pj_n] + (q - sc.g_pre[pj_n]));
+      }
+      reload = false;
+    }
+    const bool valid = v_n;
+    const int pj = pj_n;
+    const uint64_t pos = pos_n;
+    {  // the next step's suffix elements are fetched during this one
+      const uint64_t q = base + 64 + lane;
+      v_n = q < total;
+      if (v_n) {
+        while (q >= sc.g_pre[pj_n + 1]) pj_n++;
+        pos_n = k4d_sa_at<EL>(ix, sc.g_lb[pj_n] + (q - sc.g_pre[pj_n]));
+      }
+    }
+    bool core_eq = false;
+    if (valid) core_eq = k4d_lane_cmp(ix, sc, (pj & 1) ? len - core_len : 0, core_len, pos, (int)((smask >> pj) & 1ull)) == 0;
+    const unsigned long long validm = __ballot(valid);
+    n_probe += (uint32_t)__popcll(validm);
+    const int j_lo = k4d_uni(__shfl(pj, 0, 64)), j_hi = k4d_uni(__shfl(pj, 63 - __clzll(validm), 64));
+    uint64_t next_base = base + 64;
+    for (int jj = j_lo; jj <= j_hi; jj++) {
+      const unsigned long long seg = __ballot(valid && pj == jj);
+      if (!seg) continue;
+      for (; opened <= jj; opened++) {  // behind a core's walk: a full score cannot be beaten (:7469 / :7776), nothing further is looked at
+        if (best_inst >= 1 && best.score >= 1000) { stop_all = true; break; }
+        n_lookup++;
+        iter = 0;
+        pair_done = false;
+        seen_first = false;
+      }
+      if (stop_all) break;
+      if (!pair_done) {
+        const int cs = (int)((smask >> jj) & 1ull), phase = jj & 1;
+        const char cur_strand = cs ? '-' : '+';
+        const int ofs = phase ? len - core_len : 0;
+        const bool in_seg = (seg >> lane) & 1ull;
+        unsigned long long memberm = __ballot(in_seg && core_eq);
+        // the run's first suffix is taken as LocateFirstExact gives it; each further one must leave room behind its start
+        // (:7355-7362 / :7666-7672), else the walk over this core ends there
+        bool fits = true;
+        if (in_seg && core_eq) fits = splice ? !(((int64_t)pos + (phase == 0 ? len : core_len)) >= n) : !(((int64_t)pos + core_len) > n);
+        unsigned long long unfit = memberm & __ballot(!fits);
+        if (!seen_first && memberm) unfit &= ~(memberm & (0ull - memberm));
+        if (memberm) seen_first = true;
+        bool walk_ends = false;
+        if (unfit) {
+          memberm &= (unfit & (0ull - unfit)) - 1ull;
+          walk_ends = true;
+        }
         // filters in front of the exploration, :7368-7383 / :7679-7693 (the entry is looked up at the CORE's position)
-        bool inb = lane < r && pos >= (uint64_t)ofs;
+        bool inb = ((memberm >> lane) & 1ull) && pos >= (uint64_t)ofs;
         const int64_t left = (int64_t)pos - ofs;
         uint64_t e_start = 0, e_end = 0;
         if (inb) {
@@ -440,24 +491,25 @@ K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_
         K4XHit x;
         k4x_zero(x);
         int xr = 0;
-        if ((inm >> lane) & 1) {
+        if ((inm >> lane) & 1ull) {
           K4Tb tb;
           tb.init(ix);
+          const uint8_t* probe = sc.probe + (cs ? sc.pstride : 0u);
           if (!splice)
-            xr = phase == 0 ? k4x_indel_right(tb, sc.probe, limit_len, max_tot_mm, len, e_start, e_end, left, x)
-                            : k4x_indel_left(tb, sc.probe, limit_len, max_tot_mm, len, e_start, e_end, left, x);
+            xr = phase == 0 ? k4x_indel_right(tb, probe, limit_len, max_tot_mm, len, e_start, e_end, left, x)
+                            : k4x_indel_left(tb, probe, limit_len, max_tot_mm, len, e_start, e_end, left, x);
           else if (phase == 0) {  // :7392-7426
             int lim = (int)(n - left);
             if (lim > 35) {
               lim -= 35;
               if (lim > limit_len) lim = limit_len;
-              xr = k4x_splice_right(tb, sc.probe, cur_strand, lim, max_tot_mm, core_len, len, left, n, x);
+              xr = k4x_splice_right(tb, probe, cur_strand, lim, max_tot_mm, core_len, len, left, n, x);
             }
           } else if ((uint64_t)left >= (uint32_t)(ofs + 10)) {  // :7429-7461
             int lim = min((int32_t)left, (int32_t)limit_len);
             if (lim >= 35) {
               lim -= 10;
-              xr = k4x_splice_left(tb, sc.probe, cur_strand, lim, max_tot_mm, core_len, len, left, x);
+              xr = k4x_splice_left(tb, probe, cur_strand, lim, max_tot_mm, core_len, len, left, x);
             }
           }
         }
@@ -467,28 +519,31 @@ K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_
         while (todo) {
           const int c = __ffsll((long long)todo) - 1;
           todo &= todo - 1;
-          const uint32_t xs = (uint32_t)__shfl((int)x.score, c, 64);
+          const uint32_t xs = k4d_uni((uint32_t)__shfl((int)x.score, c, 64));
           if (xs < best.score) continue;
           if (xs == best.score) {
-            if (best.l0 == k4x_shfl64(x.l0, c)) continue;
+            if (best.l0 == k4d_uni(k4x_shfl64(x.l0, c))) continue;
             if (++best_inst > 1) continue;
           } else
             best_inst = 0;
           best = k4x_from_lane(x, c);
           best_inst++;
         }
-        run_over = hit_limit || r < 64;
+        if (hit_limit || walk_ends) pair_done = true;
       }
-      if (best_inst >= 1 && best.score >= 1000) { strand = 3; break; }
+      if (pair_done && jj == j_hi && k4d_uni(sc.g_pre[jj + 1]) > base + 64) {  // on to the next pair's slots
+        next_base = k4d_uni(sc.g_pre[jj + 1]);
+        reload = true;
+      }
     }
-    if (cur_strand == '+' && strand == K4_STRAND_BOTH) {
-      k4d_revcomp_wave(sc, len);
-      cur_strand = '-';
-      strand = K4_STRAND_CRICK;
-    } else
-      strand = 3;
-  } while (!(best_inst >= 1 && best.score >= 1000) && strand != 3);
-  if (cur_strand == '-') k4d_revcomp_wave(sc, len);
+    if (stop_all) break;
+    base = next_base;
+  }
+  if (!stop_all)
+    for (; opened < np; opened++) {  // the pairs behind the last slot (no suffix starts with their core) are reached as well
+      if (best_inst >= 1 && best.score >= 1000) break;
+      n_lookup++;
+    }
   if (best_inst == 0) return K4_HR_NONE;
   if (best.score > 1000) best.score = 1000;
   // concat offsets -> chromosome + locus, :7501-7516 / :7800-7825

@@ -473,14 +473,72 @@ K4_DEV void k4d_exact_run_wave(const K4DevIndex& ix, K4Slow& sc, int o, int cl, 
   if (END_CMP && last >= first && last + 1 < (int64_t)ix.n) end_cmp = (int64_t)k4d_sa_at<EL>(ix, (uint64_t)last + 1) + cl <= (int64_t)ix.n;
 }
 
-#include "k4_ext.h"
-
-// ---- the batched LocateCoreMultiples of the general kernel ------------------------------------------------------------
 #ifndef K4_SCAN_MAX
 #define K4_SCAN_MAX 128  // k-mer buckets up to this many suffixes are laid on the read whole; deeper ones are searched for the run's bounds first
 #endif
 #define K4_GROUP 64      // (strand, core) pairs looked up together
 #define K4_TRIM_MAX_LEN 2048  // AdaptiveTrim turns longer reads down (:5601-5605): no mismatch vector is kept for them
+K4_DEV uint64_t k4d_wave_excl_scan(uint64_t v, int lane, uint64_t& total) {
+  unsigned long long x = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long y = __shfl_up(x, (unsigned)d, 64);
+    if (lane >= d) x += y;
+  }
+  total = k4d_uni((uint64_t)__shfl(x, 63, 64));
+  return x - v;
+}
+
+// The buckets / runs of up to K4_GROUP (strand, core) pairs as ONE sequence of slots in LDS (g_lb: first suffix-array index of
+// pair j, g_pre: slots in front of it, g_pre[np]: all of them): lane j holds pair j's strand and core offset.  One round of
+// k-mer table loads for all pairs; a bucket of up to K4_SCAN_MAX suffixes is taken whole (the walk's own window fetch tells the
+// members), a deeper one has the two bounds of its run searched (k4d_exact_run_wave), one pair after the other.
+template <int EL>
+K4_DEV uint64_t k4d_group_lookup(const K4DevIndex& ix, K4Slow& sc, int np, unsigned long long smask, int my_o, int cl, uint32_t& n_probe) {
+  const int lane = sc.lane;
+  const int kk = min((int)ix.k, cl);
+  const int ksh = 2 * ((int)ix.k - kk);
+  uint64_t lb0 = 0, size = 0;
+  bool big = false;
+  if (lane < np) {
+    const int my_s = (int)((smask >> lane) & 1ull);
+    bool acgt = true;
+    uint64_t code = 0;
+    if (sc.packed)
+      code = k4d_probe_chunk(sc, my_o, my_s) >> (64 - 2 * kk);
+    else {
+      const uint8_t* pb = sc.probe + (my_s ? sc.pstride : 0u) + my_o;
+      for (int j = 0; j < kk; j++) {
+        const uint32_t b = pb[j] & 0x0f;
+        if (b > 3) { acgt = false; break; }
+        code = (code << 2) | b;
+      }
+    }
+    if (acgt) {
+      lb0 = k4d_ktab_lb(ix, code << ksh);
+      size = k4d_ktab_lb(ix, (code + 1) << ksh) - lb0;
+    } else
+      size = ix.n;  // (a core that holds N: the whole array is searched, as LocateFirstExact would)
+    big = size > K4_SCAN_MAX;
+  }
+  for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1) {
+    const int j = __ffsll((long long)bigm) - 1;
+    const int o_j = k4d_uni(__shfl(my_o, j, 64));
+    int64_t first, last;
+    bool end_cmp;
+    k4d_exact_run_wave<EL, false>(ix, sc, o_j, cl, n_probe, first, last, end_cmp, (int)((smask >> j) & 1ull));
+    if (lane == j) { lb0 = (uint64_t)first; size = last >= first ? (uint64_t)(last - first + 1) : 0ull; }
+  }
+  uint64_t total;
+  const uint64_t pre = k4d_wave_excl_scan(lane < np ? size : 0ull, lane, total);
+  if (lane < np) { sc.g_lb[lane] = lb0; sc.g_pre[lane] = pre; }
+  if (lane == 63) sc.g_pre[np] = total;
+  K4_WSYNC();
+  return total;
+}
+
+#include "k4_ext.h"
+
+// ---- the batched LocateCoreMultiples of the general kernel ------------------------------------------------------------
 
 // the reverse complement of the probe behind the forward one (bytes as k4d_revcomp_wave would leave them, then packed)
 K4_DEV void k4d_make_rc_wave(K4Slow& sc, int len) {
@@ -558,15 +616,6 @@ K4_DEV void k4d_lane_window128(const K4Slow& sc, const uint32_t (&wv)[9], int64_
   core_eq = diff == 0;
 }
 
-K4_DEV uint64_t k4d_wave_excl_scan(uint64_t v, int lane, uint64_t& total) {
-  unsigned long long x = v;
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned long long y = __shfl_up(x, (unsigned)d, 64);
-    if (lane >= d) x += y;
-  }
-  total = k4d_uni((uint64_t)__shfl(x, 63, 64));
-  return x - v;
-}
 
 // One LocateCoreMultiples call (SfxArray.cpp:5806-6369) by one wave, every memory-bound part of it batched.  The cores of a
 // call depend only on (ProbeLen, CoreLen, CoreDelta, MaxNumCoreSlides) (:5948-5959) and both strands use the same offsets,
@@ -608,8 +657,6 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
   // cMaxNumIdentNodes (SfxArray.h:15); additionally bounded by the scratch table so an insert always terminates.
   // A pass that fills a small table before the reference's own limit is redone with a big one (K4_NEED_SLOW).
   const uint32_t node_cap = min((uint32_t)K4_MAX_IDENT_NODES, sc.lhash ? sc.lcap * 3 / 4 : sc.cap / 2 - 1);
-  const int kk = min((int)ix.k, cl);
-  const int ksh = 2 * ((int)ix.k - kk);
   // generator of the (strand, core) pairs in the reference's order: '+' cores, then '-' cores (:5925-5934,5948-5959,6323-6336)
   int gs = rp.strand == K4_STRAND_CRICK ? 1 : 0;
   const int gs_end = rp.strand == K4_STRAND_WATSON ? 0 : 1;
@@ -640,45 +687,8 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
     K4_PROF_T(pg0);
     K4_PROF_ADD(8, 1);
     K4_PROF_ADD(6, np);
-    // ---- 1. the k-mer table, a lane per pair ----------------------------------------------------------------------
-    uint64_t lb0 = 0, size = 0;
-    bool big = false;
-    if (lane < np) {
-      const int my_s = (int)((smask >> lane) & 1ull);
-      bool acgt = true;
-      uint64_t code = 0;
-      if (sc.packed)
-        code = k4d_probe_chunk(sc, my_o, my_s) >> (64 - 2 * kk);
-      else {
-        const uint8_t* pb = sc.probe + (my_s ? sc.pstride : 0u) + my_o;
-        for (int j = 0; j < kk; j++) {
-          const uint32_t b = pb[j] & 0x0f;
-          if (b > 3) { acgt = false; break; }
-          code = (code << 2) | b;
-        }
-      }
-      if (acgt) {
-        lb0 = k4d_ktab_lb(ix, code << ksh);
-        size = k4d_ktab_lb(ix, (code + 1) << ksh) - lb0;
-      } else
-        size = ix.n;  // (a core that holds N: the whole array is searched, as LocateFirstExact would)
-      big = size > K4_SCAN_MAX;
-    }
-    // ---- 2. deep buckets: the run's two bounds by search, one pair after the other ------------------------------------
-    for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1) {
-      const int j = __ffsll((long long)bigm) - 1;
-      const int o_j = k4d_uni(__shfl(my_o, j, 64));
-      int64_t first, last;
-      bool end_cmp;
-      k4d_exact_run_wave<EL, false>(ix, sc, o_j, cl, n_probe, first, last, end_cmp, (int)((smask >> j) & 1ull));
-      if (lane == j) { lb0 = (uint64_t)first; size = last >= first ? (uint64_t)(last - first + 1) : 0ull; }
-    }
-    // ---- 3. the slots of the group ------------------------------------------------------------------------------------
-    uint64_t total;
-    const uint64_t pre = k4d_wave_excl_scan(lane < np ? size : 0ull, lane, total);
-    if (lane < np) { sc.g_lb[lane] = lb0; sc.g_pre[lane] = pre; }
-    if (lane == 63) sc.g_pre[np] = total;
-    K4_WSYNC();
+    // ---- 1.-3. the k-mer table (a lane per pair), deep buckets searched, the slots of the group --------------------------
+    const uint64_t total = k4d_group_lookup<EL>(ix, sc, np, smask, my_o, cl, n_probe);
     K4_PROF_T(pg1);
     K4_PROF_ADD(0, pg1 - pg0);
     int opened = 0;  // pairs of this group the walk has reached so far
@@ -1049,12 +1059,12 @@ K4_DEV int k4d_ext_phases(const K4AlignArgs& a, K4Slow& sc, int len, const K4Rea
     for (int q = 0; q < rp.max_hits; q++) *reinterpret_cast<uint4*>(&hits[q]) = make_uint4(0, 0, 0, 0);
   if (rp.micro_indel_len > 0) {
     rslt = k4d_two_seg<EL>(a, sc, false, rp.micro_indel_len, min(rp.tot_mm, 2), rp.core_len, rp.strand, len, inst, low, nxt, &hits[0],
-                           seg2, n_lookup, n_probe, n_cand);
+                           seg2, n_lookup, n_probe, n_cand, false);
     if (rslt != 0) return rslt;
   }
   if (rp.max_splice_junct_len > 0) {
     rslt = k4d_two_seg<EL>(a, sc, true, rp.max_splice_junct_len, min(rp.tot_mm, 2), rp.core_len, rp.strand, len, inst, low, nxt,
-                           &hits[0], seg2, n_lookup, n_probe, n_cand);
+                           &hits[0], seg2, n_lookup, n_probe, n_cand, rp.micro_indel_len > 0 && rp.core_len <= len);  // (same cores: the slots are laid out)
     if (rslt != 0) return rslt;
   }
   if (rp.min_chimeric_len > 0) {

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=40_000)
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--max-subs", type=int, default=2)
+    ap.add_argument("--ext", default="", help="as bench.py --ext: the EXT instantiation's profile")
     a = ap.parse_args()
     eng = bench.GpuEngine()
     dev = eng.device(0)
@@ -47,7 +48,10 @@ def main():
     eng.build_index(seq, a.chroms, chrom_len, 0, lambda *x: print("[prof]", *x, file=sys.stderr))
     ix = eng.ix
     reads, _ = bench.make_reads(seq, a.chroms, chrom_len, a.reads, a.read_len, 4321, dev)
-    eng.prepare(reads, a.reads, a.read_len, False, a.max_subs)
+    ext_kw = {}
+    for tok in filter(None, a.ext.split(",")):
+        ext_kw[{"c": "min_chimeric_len", "a": "micro_indel_len", "A": "max_splice_junct_len"}[tok[0]]] = int(tok[1:])
+    eng.prepare(reads, a.reads, a.read_len, False, a.max_subs, ext_kw)
     L = k4.lib()
     L.k4i_debug_prof.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     buf = (C.c_uint64 * 32)()
