@@ -166,10 +166,11 @@ K4_DEV uint32_t k4d_ref_base(const K4DevIndex& ix, uint64_t pos) {
 // eight per load.  Beyond the block: a separator.
 struct K4Tb {
   const K4DevIndex* ix;
-  int64_t cw, cblk;   // the cached word (packed word / nibble word of the cached block), the cached block
-  uint32_t word, exr; // exr: rank of the cached block among the flagged ones
+  int64_t cw, cblk;   // the cached unit (64 bases of packed words / one nibble word of the cached block), the cached block
+  uint32_t w4[4];     // four packed words = 64 bases, one 16-byte load (a lane that walks 100 bases waits for two loads, not seven)
+  uint32_t exr;       // rank of the cached block among the flagged ones
   bool flagged;
-  K4_DEV void init(const K4DevIndex& x) { ix = &x; cw = -1; cblk = -1; word = 0; exr = 0; flagged = false; }
+  K4_DEV void init(const K4DevIndex& x) { ix = &x; cw = -1; cblk = -1; w4[0] = w4[1] = w4[2] = w4[3] = 0; exr = 0; flagged = false; }
   K4_DEV uint32_t get(int64_t pos) {
     if (pos < 0 || (uint64_t)pos >= ix->n) return 7u;
     const int64_t blk = pos >> K4_EXC_SHIFT;
@@ -188,11 +189,17 @@ struct K4Tb {
     }
     if (flagged) {
       const int64_t w = pos >> 3;
-      if (w != cw) { cw = w; word = ix->excnib[(uint64_t)exr * (K4_EXC_BLOCK / 8) + (uint32_t)((pos & (K4_EXC_BLOCK - 1)) >> 3)]; }
-      return (word >> (4 * (uint32_t)(pos & 7))) & 0xF;
+      if (w != cw) { cw = w; w4[0] = ix->excnib[(uint64_t)exr * (K4_EXC_BLOCK / 8) + (uint32_t)((pos & (K4_EXC_BLOCK - 1)) >> 3)]; }
+      return (w4[0] >> (4 * (uint32_t)(pos & 7))) & 0xF;
     }
-    const int64_t w = pos >> 4;
-    if (w != cw) { cw = w; word = ix->ref2[w]; }
+    const int64_t w = pos >> 6;
+    if (w != cw) {
+      cw = w;
+      const k4_u32x4_a4 v = *reinterpret_cast<const k4_u32x4_a4*>(ix->ref2 + 4 * w);  // (the pads cover the last unit's tail)
+      w4[0] = v.x; w4[1] = v.y; w4[2] = v.z; w4[3] = v.w;
+    }
+    const uint32_t q = (uint32_t)(pos >> 4) & 3u;
+    const uint32_t word = q == 0 ? w4[0] : q == 1 ? w4[1] : q == 2 ? w4[2] : w4[3];
     return (word >> (30 - 2 * (uint32_t)(pos & 15))) & 3;
   }
 };

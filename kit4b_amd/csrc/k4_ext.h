@@ -48,9 +48,34 @@ K4_DEV void k4x_one_seg(K4XHit& h, int len, int64_t targ_ofs, int n_mm) {  // th
   h.score = (uint32_t)(500 + len * 3 - n_mm * 5) & 0xFFFFu;
 }
 
+
+// The explorations begin by listing the first mismatches of the read laid on its locus.  With the locus' packed window in
+// registers that list comes from the mismatch bit vector (bit j of word j >> 5: base j differs) by find-first-set, instead of
+// a walk over every base through LDS bytes and cached target words: a read of 100 bases took ~100 dependent LDS reads there.
+struct K4XMask {
+  uint32_t w[4];
+  bool have;  // the window was clean and the probe packed (no N anywhere): w is valid and no symbol above T can turn up
+};
+K4_DEV int k4x_next_up(const K4XMask& m, int from, int end) {  // lowest set bit in [from, end), or end
+  for (int j = from; j < end;) {
+    const uint32_t v = m.w[j >> 5] >> (j & 31);
+    if (v) { const int r = j + (__ffs((int)v) - 1); return r < end ? r : end; }
+    j = (j | 31) + 1;
+  }
+  return end;
+}
+K4_DEV int k4x_next_down(const K4XMask& m, int from, int end) {  // highest set bit in (end, from], or end
+  for (int j = from; j > end;) {
+    const uint32_t v = m.w[j >> 5] << (31 - (j & 31));
+    if (v) { const int r = j - __clz((int)v); return r > end ? r : end; }
+    j = (j & ~31) - 1;
+  }
+  return end;
+}
+
 // ExploreInDelMatchRight, SfxArray.cpp:9277-9495
 K4_DEV int k4x_indel_right(K4Tb& t, const uint8_t* probe, int micro_indel_len, int max_tot_mm, int len, uint64_t e_start,
-                           uint64_t e_end, int64_t targ_ofs, K4XHit& hit) {
+                           uint64_t e_end, int64_t targ_ofs, K4XHit& hit, const K4XMask& mk) {
   k4x_zero(hit);
   if (targ_ofs < (int64_t)e_start || (targ_ofs + len - 1) > (int64_t)e_end) return 0;
   const uint32_t targ_seq_len = (uint32_t)((e_end - e_start + 1) - ((uint64_t)targ_ofs - e_start));
@@ -58,12 +83,15 @@ K4_DEV int k4x_indel_right(K4Tb& t, const uint8_t* probe, int micro_indel_len, i
   int n_mm = 0;
   uint32_t pb = 0, tv = 0;
   const int lim = max(max_tot_mm, 7);
-  for (int idx = 0; idx < len && n_mm <= lim; idx++) {
-    pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
-    if (tv > 4 || pb > 4) return 0;
-    if (pb == tv && pb <= 3) continue;
-    mm_ofs[n_mm++] = idx;
-  }
+  if (mk.have)
+    for (int idx = k4x_next_up(mk, 0, len); idx < len && n_mm <= lim; idx = k4x_next_up(mk, idx + 1, len)) mm_ofs[n_mm++] = idx;
+  else
+    for (int idx = 0; idx < len && n_mm <= lim; idx++) {
+      pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
+      if (tv > 4 || pb > 4) return 0;
+      if (pb == tv && pb <= 3) continue;
+      mm_ofs[n_mm++] = idx;
+    }
   if (n_mm < 7 || 7 > (len - mm_ofs[0])) {
     if (n_mm > max_tot_mm) return 0;
     k4x_one_seg(hit, len, targ_ofs, n_mm);
@@ -113,19 +141,22 @@ K4_DEV int k4x_indel_right(K4Tb& t, const uint8_t* probe, int micro_indel_len, i
 
 // ExploreInDelMatchLeft, SfxArray.cpp:9506-9735
 K4_DEV int k4x_indel_left(K4Tb& t, const uint8_t* probe, int micro_indel_len, int max_tot_mm, int len, uint64_t e_start,
-                          uint64_t e_end, int64_t targ_ofs, K4XHit& hit) {
+                          uint64_t e_end, int64_t targ_ofs, K4XHit& hit, const K4XMask& mk) {
   k4x_zero(hit);
   if (targ_ofs < (int64_t)e_start || (targ_ofs + len - 1) > (int64_t)e_end) return 0;
   int mm_ofs[K4X_MAX_OFSS];
   int n_mm = 0, idx;
   uint32_t pb = 0, tv = 0;
   const int lim = max(max_tot_mm, 7);
-  for (idx = len - 1; idx >= 0 && n_mm <= lim; idx--) {
-    pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
-    if (tv > 4 || pb > 4) return 0;
-    if (pb == tv && pb <= 3) continue;
-    mm_ofs[n_mm++] = idx;
-  }
+  if (mk.have)
+    for (idx = k4x_next_down(mk, len - 1, -1); idx >= 0 && n_mm <= lim; idx = k4x_next_down(mk, idx - 1, -1)) mm_ofs[n_mm++] = idx;
+  else
+    for (idx = len - 1; idx >= 0 && n_mm <= lim; idx--) {
+      pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
+      if (tv > 4 || pb > 4) return 0;
+      if (pb == tv && pb <= 3) continue;
+      mm_ofs[n_mm++] = idx;
+    }
   if (n_mm < 7 || 7 > mm_ofs[0]) {
     if (n_mm > max_tot_mm) return 0;
     k4x_one_seg(hit, len, targ_ofs, n_mm);
@@ -190,7 +221,7 @@ K4_DEV uint32_t k4x_splice_bonus(char cur_strand, uint32_t d0, uint32_t d1, uint
 
 // ExploreSpliceRight, SfxArray.cpp:8771-9011
 K4_DEV int k4x_splice_right(K4Tb& t, const uint8_t* probe, char cur_strand, int max_junct_len, int max_tot_mm, int core_len,
-                            int len, int64_t targ_ofs, int64_t targ_len, K4XHit& hit) {
+                            int len, int64_t targ_ofs, int64_t targ_len, K4XHit& hit, const K4XMask& mk) {
   k4x_zero(hit);
   if ((targ_ofs + len + 25) > targ_len) return 0;
   if (max_tot_mm > 2) max_tot_mm = 2;
@@ -198,12 +229,15 @@ K4_DEV int k4x_splice_right(K4Tb& t, const uint8_t* probe, char cur_strand, int 
   int n_mm = 0;
   uint32_t pb = 0, tv = 0, idx;
   const int lim = max(max_tot_mm, 10);
-  for (idx = (uint32_t)core_len; idx < (uint32_t)len && n_mm <= lim; idx++) {
-    pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
-    if (tv > 4 || pb > 4) return 0;
-    if (pb == tv && pb <= 3) continue;
-    mm_ofs[n_mm++] = (int)idx;
-  }
+  if (mk.have)
+    for (int j = k4x_next_up(mk, core_len, len); j < len && n_mm <= lim; j = k4x_next_up(mk, j + 1, len)) mm_ofs[n_mm++] = j;
+  else
+    for (idx = (uint32_t)core_len; idx < (uint32_t)len && n_mm <= lim; idx++) {
+      pb = probe[idx] & 7; tv = t.get(targ_ofs + idx);
+      if (tv > 4 || pb > 4) return 0;
+      if (pb == tv && pb <= 3) continue;
+      mm_ofs[n_mm++] = (int)idx;
+    }
   if (n_mm < 8 || 10 > (len - mm_ofs[0])) {
     if (n_mm > max_tot_mm) return 0;
     k4x_one_seg(hit, len, targ_ofs, n_mm);
@@ -276,7 +310,7 @@ K4_DEV int k4x_splice_right(K4Tb& t, const uint8_t* probe, char cur_strand, int 
 
 // ExploreSpliceLeft, SfxArray.cpp:9022-9265
 K4_DEV int k4x_splice_left(K4Tb& t, const uint8_t* probe, char cur_strand, int max_junct_len, int max_tot_mm, int core_len,
-                           int len, int64_t targ_ofs, K4XHit& hit) {
+                           int len, int64_t targ_ofs, K4XHit& hit, const K4XMask& mk) {
   k4x_zero(hit);
   if ((uint64_t)targ_ofs < 35u) return 0;
   if (max_tot_mm > 2) max_tot_mm = 2;
@@ -286,12 +320,15 @@ K4_DEV int k4x_splice_left(K4Tb& t, const uint8_t* probe, char cur_strand, int m
   int n_mm = 0;
   uint32_t pb = 0, tv = 0, idx;
   const int lim = max(max_tot_mm, 10);
-  for (idx = (uint32_t)core_len; idx < (uint32_t)len && n_mm <= lim; idx++) {
-    pb = probe[p3 - (int)idx] & 7; tv = t.get(t3 - idx);
-    if (tv > 4 || pb > 4) return 0;
-    if (pb == tv && pb <= 3) continue;
-    mm_ofs[n_mm++] = (int)idx;
-  }
+  if (mk.have)  // (offset idx counts from the read's end: base p3 - idx)
+    for (int j = k4x_next_down(mk, p3 - core_len, -1); j >= 0 && n_mm <= lim; j = k4x_next_down(mk, j - 1, -1)) mm_ofs[n_mm++] = p3 - j;
+  else
+    for (idx = (uint32_t)core_len; idx < (uint32_t)len && n_mm <= lim; idx++) {
+      pb = probe[p3 - (int)idx] & 7; tv = t.get(t3 - idx);
+      if (tv > 4 || pb > 4) return 0;
+      if (pb == tv && pb <= 3) continue;
+      mm_ofs[n_mm++] = (int)idx;
+    }
   if (n_mm < 8 || 10 > (len - mm_ofs[0])) {
     if (n_mm > max_tot_mm) return 0;
     k4x_one_seg(hit, len, targ_ofs, n_mm);
@@ -402,7 +439,11 @@ K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_
   for (int j = 0; j < np; j++)
     if (s_first + (j >> 1)) smask |= 1ull << j;
   const int my_o = (lane & 1) ? len - core_len : 0;
+  K4_PROF_T(px0);
   const uint64_t total = reuse_lookup ? k4d_uni(sc.g_pre[np]) : k4d_group_lookup<EL>(ix, sc, np, smask, my_o, core_len, n_probe);
+  K4_PROF_T(px1);
+  K4_PROF_ADD(16, px1 - px0);
+  K4_PROF_ADD(21, 1);
   int opened = 0, iter = 0;
   bool pair_done = false, seen_first = false, stop_all = false;
   bool v_n = false, reload = true;
@@ -429,8 +470,12 @@ K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_
         pos_n = k4d_sa_at<EL>(ix, sc.g_lb[pj_n] + (q - sc.g_pre[pj_n]));
       }
     }
+    K4_PROF_T(py0);
     bool core_eq = false;
     if (valid) core_eq = k4d_lane_cmp(ix, sc, (pj & 1) ? len - core_len : 0, core_len, pos, (int)((smask >> pj) & 1ull)) == 0;
+    K4_PROF_T(py1);
+    K4_PROF_ADD(17, py1 - py0);
+    K4_PROF_ADD(22, 1);
     const unsigned long long validm = __ballot(valid);
     n_probe += (uint32_t)__popcll(validm);
     const int j_lo = k4d_uni(__shfl(pj, 0, 64)), j_hi = k4d_uni(__shfl(pj, 63 - __clzll(validm), 64));
@@ -488,6 +533,7 @@ K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_
         const int took = (int)__popcll(inm);
         iter += took;
         n_cand += (uint32_t)took;
+        K4_PROF_T(py2);
         K4XHit x;
         k4x_zero(x);
         int xr = 0;
@@ -495,24 +541,37 @@ K4_DEV int k4d_two_seg(const K4AlignArgs& a, K4Slow& sc, bool splice, int limit_
           K4Tb tb;
           tb.init(ix);
           const uint8_t* probe = sc.probe + (cs ? sc.pstride : 0u);
+          K4XMask xm;
+          xm.w[0] = xm.w[1] = xm.w[2] = xm.w[3] = 0;
+          xm.have = sc.packed && len <= 128 && (uint64_t)left + (uint64_t)len <= ix.n && !k4d_any_exc_sup(ix, sc.sup, left, left + len);
+          if (xm.have) {  // the locus' window in one round of loads; read and window as mismatch bits
+            uint64_t rc[4];
+            k4d_ref_chunks4(ix, left, 0, len + (int)(left & 15) <= 128, rc);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              if (32 * c < len) xm.w[c] = k4d_mm_bits((rc[c] ^ k4d_probe_chunk(sc, 32 * c, cs)) & k4d_range_mask(0, len - 32 * c));
+          }
           if (!splice)
-            xr = phase == 0 ? k4x_indel_right(tb, probe, limit_len, max_tot_mm, len, e_start, e_end, left, x)
-                            : k4x_indel_left(tb, probe, limit_len, max_tot_mm, len, e_start, e_end, left, x);
+            xr = phase == 0 ? k4x_indel_right(tb, probe, limit_len, max_tot_mm, len, e_start, e_end, left, x, xm)
+                            : k4x_indel_left(tb, probe, limit_len, max_tot_mm, len, e_start, e_end, left, x, xm);
           else if (phase == 0) {  // :7392-7426
             int lim = (int)(n - left);
             if (lim > 35) {
               lim -= 35;
               if (lim > limit_len) lim = limit_len;
-              xr = k4x_splice_right(tb, probe, cur_strand, lim, max_tot_mm, core_len, len, left, n, x);
+              xr = k4x_splice_right(tb, probe, cur_strand, lim, max_tot_mm, core_len, len, left, n, x, xm);
             }
           } else if ((uint64_t)left >= (uint32_t)(ofs + 10)) {  // :7429-7461
             int lim = min((int32_t)left, (int32_t)limit_len);
             if (lim >= 35) {
               lim -= 10;
-              xr = k4x_splice_left(tb, probe, cur_strand, lim, max_tot_mm, core_len, len, left, x);
+              xr = k4x_splice_left(tb, probe, cur_strand, lim, max_tot_mm, core_len, len, left, x, xm);
             }
           }
         }
+        K4_PROF_T(py3);
+        K4_PROF_ADD(18, py3 - py2);
+        K4_PROF_ADD(20, took);
         if (xr > 0 && cur_strand == '-') x.fl |= 8u;
         // replay in suffix order: `>=` the best score so far; an equal score at another locus only counts
         unsigned long long todo = __ballot(xr > 0);

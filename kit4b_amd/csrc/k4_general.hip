@@ -1057,6 +1057,7 @@ K4_DEV int k4d_ext_phases(const K4AlignArgs& a, K4Slow& sc, int len, const K4Rea
   // phase counts but never writes is its own stale memory)
   if (sc.lane == 0)
     for (int q = 0; q < rp.max_hits; q++) *reinterpret_cast<uint4*>(&hits[q]) = make_uint4(0, 0, 0, 0);
+  K4_PROF_T(pe0);
   if (rp.micro_indel_len > 0) {
     rslt = k4d_two_seg<EL>(a, sc, false, rp.micro_indel_len, min(rp.tot_mm, 2), rp.core_len, rp.strand, len, inst, low, nxt, &hits[0],
                            seg2, n_lookup, n_probe, n_cand, false);
@@ -1067,6 +1068,8 @@ K4_DEV int k4d_ext_phases(const K4AlignArgs& a, K4Slow& sc, int len, const K4Rea
                            &hits[0], seg2, n_lookup, n_probe, n_cand, rp.micro_indel_len > 0 && rp.core_len <= len);  // (same cores: the slots are laid out)
     if (rslt != 0) return rslt;
   }
+  K4_PROF_T(pe1);
+  K4_PROF_ADD(19, pe1 - pe0);
   if (rp.min_chimeric_len > 0) {
     if (rp.max_slides <= 1) return K4_ERR_PARAMS;  // (the reference divides by MaxNumCoreSlides - 1, :7926)
     const int cl = max(rp.min_core_len, len / (rp.tot_mm + 4));

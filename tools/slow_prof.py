@@ -89,6 +89,8 @@ def main():
         "replay_parts_per_step_cycles": {"open": v[16] / max(n_steps, 1), "filters_insert": v[17] / max(n_steps, 1), "limits_unclean": v[18] / max(n_steps, 1),
                                          "fold": v[19] / max(n_steps, 1)},
         "per_step": {"segments": v[21] / max(n_steps, 1), "fold_iterations": v[22] / max(n_steps, 1), "unclean_candidates": v[20] / max(n_steps, 1)},
+        "ext_two_seg": {"calls": v[21], "steps": v[22], "candidates_explored": v[20], "cycles_lookup": v[16], "cycles_core_cmp": v[17],
+                        "cycles_explorers": v[18], "cycles_both_calls": v[19]} if a.ext else None,
         "counters": {k: int(ctr[k]) for k in ("n_lookup", "n_probe", "n_cand", "n_slow")},
     }))
 
