@@ -754,6 +754,19 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
       K4_PROF_ADD(12, __popcll(__ballot(core_eq)));
       K4_PROF_T(ps1);
       K4_PROF_ADD(1, ps1 - ps0);
+      // filters that precede the dedupe (:6019-6036: before the core offset, on a separator, over the entry end): for every
+      // slot of the step at once, not pair by pair
+      uint32_t loci = 0, ent_id_l = 0;
+      bool in_bounds_all = false;
+      {
+        uint64_t e_start = 0, e_end = 0;
+        int e = -1;
+        const bool member = valid && core_eq && pos >= (uint64_t)o;
+        if (member) e = k4d_map_entry_slow(ix, sc.ent, (uint64_t)left, e_start, e_end);
+        in_bounds_all = member && e >= 0 && (uint64_t)left + (uint64_t)len - 1 <= e_end;
+        loci = (uint32_t)((uint64_t)left - e_start);
+        if (in_bounds_all) ent_id_l = sc.ent_id[e];
+      }
       // ---- 4. replay, pair by pair in the reference's order ------------------------------------------------------------
       const int j_lo = k4d_uni(__shfl(pj, 0, 64)), j_hi = k4d_uni(__shfl(pj, 63 - __clzll(validm), 64));
       uint64_t next_base = base + 64;
@@ -786,13 +799,7 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
           const int cs = (int)((smask >> jj) & 1ull);
           const char cur_strand = cs ? '-' : '+';
           const bool in_seg = (seg >> lane) & 1ull;
-          // filters that precede the dedupe (:6019-6036: before the core offset, on a separator, over the entry end)
-          uint64_t e_start = 0, e_end = 0;
-          int e = -1;
-          const bool member = in_seg && core_eq && pos >= (uint64_t)o;
-          if (member) e = k4d_map_entry_slow(ix, sc.ent, (uint64_t)left, e_start, e_end);
-          const bool in_bounds = member && e >= 0 && (uint64_t)left + (uint64_t)len - 1 <= e_end;
-          const uint32_t loci = (uint32_t)((uint64_t)left - e_start);
+          const bool in_bounds = in_seg && in_bounds_all;
           K4_PROF_ADD(10, __popcll(__ballot(in_bounds)));
           // the LDS table must keep room for this step's inserts (slots of retracted inserts count): else the pass with the big tables
           if (sc.lhash && sc.lused + 64 + 1 > sc.lcap) return K4_NEED_SLOW;
@@ -829,7 +836,6 @@ K4_DEV int k4d_lcm_batched(const K4AlignArgs& a, K4Slow& sc, int len, int allow_
           // only candidates that pass the order-independent part of the acceptance test can change the state; the rest just count
           const bool cand = CHIM ? is_cand && trim.len >= min_probe_chim && trim.len > 0 : is_cand && !eos && mm <= allow_mm;
           unsigned long long todo = __ballot(cand);
-          const uint32_t ent_id_l = cand ? sc.ent_id[e] : 0u;  // (looked up by all lanes at once, not per candidate in the loop below)
           int stop_lane = -1;
           while (todo) {
             K4_PROF_ADD(22, 1);
