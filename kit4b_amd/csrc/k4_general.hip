@@ -571,6 +571,63 @@ K4_DEV void k4d_make_rc_wave(K4Slow& sc, int len) {
   K4_WSYNC();
 }
 
+// bit k of x -> bit 2k (the even bits of the result)
+K4_DEV uint64_t k4d_spread32(uint32_t v) {
+  uint64_t x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+// A read into the wave's LDS: its bytes and those of its reverse complement (for the exact-symbol paths), and both as packed
+// words.  64 bases a round, a lane per base: the two bit planes of the symbols are wave ballots, a packed word is their
+// interleave (scalar arithmetic, no per-base loop); the reverse complement's words come from the forward ones (complement,
+// order of the 2-bit groups reversed) as the step kernels make theirs.  Same results as k4d_pack_probe_wave + k4d_make_rc_wave.
+K4_DEV void k4d_load_read_wave(K4Slow& sc, const uint8_t* __restrict__ src, int len) {
+  uint8_t* prc = sc.probe + sc.pstride;
+  const int lane = sc.lane;
+  int stop = len;  // CSeqTrans::ReverseComplement (SeqTrans.cpp:497-545) complements up to the first symbol above 6
+  bool bad = false;
+  const int nw = (len + 31) >> 5;
+  for (int j0 = 0; j0 < len; j0 += 64) {
+    const int j = j0 + lane;
+    const uint32_t b = j < len ? (uint32_t)(src[j] & 7) : 0u;
+    const unsigned long long m6 = __ballot(b > 6);
+    if (m6 && stop == len) stop = j0 + __ffsll((long long)m6) - 1;
+    if (j < len) {
+      sc.probe[j] = (uint8_t)b;
+      prc[len - 1 - j] = (uint8_t)((j < stop && b <= 3) ? 3 - b : b);
+    }
+    if (__ballot(b > 3)) bad = true;
+    const unsigned long long m0 = __ballot((b & 1u) && b <= 3), m1 = __ballot((b & 2u) && b <= 3);  // (symbols above T pack as 0)
+    // base i of the round (bit i of the planes) goes to bits (63 - 2i, 62 - 2i) of its word: reverse, spread, interleave
+    const uint64_t w_lo = (k4d_spread32(__brev((uint32_t)m1)) << 1) | k4d_spread32(__brev((uint32_t)m0));
+    const uint64_t w_hi = (k4d_spread32(__brev((uint32_t)(m1 >> 32))) << 1) | k4d_spread32(__brev((uint32_t)(m0 >> 32)));
+    if (lane == 0) {
+      sc.pk[j0 >> 5] = w_lo;
+      sc.pk[(j0 >> 5) + 1] = w_hi;  // (the word behind the read's last one is zero: pk has nw + 1 words at least)
+    }
+  }
+  if (lane == 0 && (nw & 1) == 0) sc.pk[nw] = 0;  // (an odd nw had its pad word written as the round's upper half)
+  sc.packed = !bad;
+  K4_WSYNC();
+  for (int c = lane; c <= nw; c += 64) {  // reverse complement words from the forward ones
+    uint64_t r = 0;
+    if (c < nw) {
+      const int o = len - 32 * (c + 1);
+      uint64_t f;
+      if (o >= 0) f = k4d_probe_chunk(sc, o);
+      else f = sc.pk[0] >> (2 * (-o));  // fewer than 32 bases left: they sit at the low end, zeros above
+      const uint64_t y = __brevll(~f);
+      r = (((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull)) & k4d_range_mask(0, len - 32 * c);
+    }
+    sc.pk[sc.pkstride + c] = r;
+  }
+  K4_WSYNC();
+}
+
 // One lane: the read (strand s) laid on the clean window [left, left + len): does its core [o, o + cl) equal the reference
 // there, and the Hamming distance of the whole read -- both from the same 16-byte loads (two per 113 bases).
 K4_DEV void k4d_lane_window(const K4DevIndex& ix, const K4Slow& sc, int s, int o, int cl, int len, int64_t left, bool& core_eq, int& mm) {
@@ -1198,10 +1255,7 @@ __global__ void __launch_bounds__(64 * K4_SLOW_WPB) __attribute__((amdgpu_waves_
       }
       const uint8_t* src = a.reads + k4d_uni(a.offs[i]);
       K4_WSYNC();
-      for (int j = lane; j < len; j += 64) probe_s[j] = src[j] & 7;
-      K4_WSYNC();
-      k4d_pack_probe_wave(sc, len);
-      k4d_make_rc_wave(sc, len);
+      k4d_load_read_wave(sc, src, len);
       if (lane < 4) sc.g_lm[lane] = k4d_range_mask(0, len - 32 * lane);  // (k4d_lcm_batched's first K4_WSYNC comes before any use)
       K4_PROF_T(pr1);
       K4_PROF_ADD(5, pr1 - pr0);
