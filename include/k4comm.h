@@ -25,6 +25,15 @@ extern "C" {
 #define K4_COMM_ID_BYTES 128 /* ncclUniqueId */
 typedef struct k4_comm k4_comm;
 
+/* The exchange k4_comm_open_index runs for each of the two big arrays, as data: who sends which byte range to whom in which of
+ * its two phases (0: the root deals piece r to rank r, every direct link of the root busy; 1: every rank passes its own piece to
+ * each peer that lacks it).  A pure function of (n_ranks, bytes) -- the RCCL calls are issued from exactly this list, and a CPU
+ * test checks it for every rank count: all bytes reach all ranks, nobody sends what it does not hold yet, no (src, dst) link
+ * carries more than one piece per phase.  Returns the number of transfers (<= 2 * n_ranks * n_ranks); cap too small: the count
+ * needed, nothing written beyond cap. */
+typedef struct { int32_t phase, src, dst; uint64_t off, len; } k4_comm_xfer;
+int k4_comm_bcast_schedule(int n_ranks, uint64_t bytes, k4_comm_xfer* out, int cap);
+
 int k4_comm_unique_id(uint8_t id[K4_COMM_ID_BYTES]);  /* one rank calls it and hands the bytes to the others (pipe, file, shared memory) */
 int k4_comm_init(int device, int rank, int n_ranks, const uint8_t id[K4_COMM_ID_BYTES], k4_comm** out);
 int k4_comm_rank(const k4_comm* c);

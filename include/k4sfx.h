@@ -502,6 +502,9 @@ void k4_free_device(void* p);
 int k4_alloc_device(k4_index* ix, uint64_t bytes, void** d_ptr);
 int k4_copy_to_device(k4_index* ix, void* d_dst, const void* src, uint64_t bytes);
 int k4_copy_to_host(k4_index* ix, void* dst, const void* d_src, uint64_t bytes);
+/* pageable or file-mapped host memory -> device memory through pinned pieces filled by several host threads (the way k4_open
+ * itself uploads the two big arrays of an .sfx file); for callers that place an index themselves, e.g. libk4comm's rank 0 */
+int k4_upload_pageable(int device, void* d_dst, const void* h_src, uint64_t bytes);
 
 /* kernel timing for roofline measurement: when enabled, every batch brackets the dominant kernel (k4k_align_step, one launch per AlignReads phase) with
  * HIP events on the stream it is launched on; k4_get_kernel_times synchronises, returns the summed duration and the

@@ -41,32 +41,33 @@ int fail(k4_comm* c, int code, const char* fmt, ...) {
 
 // A device buffer that only rank 0 holds -> every rank, with every direct xGMI link in use: the root deals piece r to rank r
 // (N-1 concurrent point-to-point sends over N-1 different links), then every rank passes its piece to each peer that lacks it
-// (the root, which has everything, only gives its own piece 0).  Per link: two transfers of bytes / N.
+// (the root, which has everything, only gives its own piece 0).  Per link: two transfers of bytes / N.  The list of transfers
+// is k4_comm_bcast_schedule's (a pure function, tested on the CPU for every rank count); here it is only issued.
 int bcast_all_links(k4_comm* c, uint8_t* buf, uint64_t bytes) {
   const int N = c->n, me = c->rank;
   if (N == 1 || bytes == 0) return K4_OK;
-  const uint64_t piece = ((bytes + N - 1) / N + 255) & ~255ull;
-  auto off = [&](int r) { return std::min<uint64_t>((uint64_t)r * piece, bytes); };
-  auto len = [&](int r) { return off(r + 1) - off(r); };
-  CK_NCCL(c, ncclGroupStart());
-  if (me == 0) {
-    for (int r = 1; r < N; r++)
-      if (len(r)) CK_NCCL(c, ncclSend(buf + off(r), len(r), ncclUint8, r, c->comm, c->st));
-  } else if (len(me))
-    CK_NCCL(c, ncclRecv(buf + off(me), len(me), ncclUint8, 0, c->comm, c->st));
-  CK_NCCL(c, ncclGroupEnd());
-  CK_NCCL(c, ncclGroupStart());
-  for (int p = 1; p < N; p++) {  // receivers: everyone but the root
-    if (p == me) {
-      for (int s = 0; s < N; s++)
-        if (s != me && len(s)) CK_NCCL(c, ncclRecv(buf + off(s), len(s), ncclUint8, s, c->comm, c->st));
-    } else if (len(me))
-      CK_NCCL(c, ncclSend(buf + off(me), len(me), ncclUint8, p, c->comm, c->st));
+  std::vector<k4_comm_xfer> xf((size_t)2 * N * N);
+  const int nx = k4_comm_bcast_schedule(N, bytes, xf.data(), (int)xf.size());
+  for (int phase = 0; phase < 2; phase++) {
+    CK_NCCL(c, ncclGroupStart());
+    for (int k = 0; k < nx; k++) {
+      const k4_comm_xfer& x = xf[(size_t)k];
+      if (x.phase != phase) continue;
+      if (x.src == me) CK_NCCL(c, ncclSend(buf + x.off, x.len, ncclUint8, x.dst, c->comm, c->st));
+      if (x.dst == me) CK_NCCL(c, ncclRecv(buf + x.off, x.len, ncclUint8, x.src, c->comm, c->st));
+    }
+    CK_NCCL(c, ncclGroupEnd());
   }
-  CK_NCCL(c, ncclGroupEnd());
   CK_HIP(c, hipStreamSynchronize(c->st));
   return K4_OK;
 }
+
+// device allocations of k4_comm_open_index: released on every way out unless handed on
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  void* release() { void* q = p; p = nullptr; return q; }
+};
 
 struct Meta {  // what the peers need before they can size their buffers
   uint64_t n;
@@ -77,6 +78,26 @@ struct Meta {  // what the peers need before they can size their buffers
 };
 
 }  // namespace
+
+extern "C" int k4_comm_bcast_schedule(int n_ranks, uint64_t bytes, k4_comm_xfer* out, int cap) {
+  if (n_ranks < 1 || (!out && cap > 0)) return K4_ERR_PARAMS;
+  const int N = n_ranks;
+  if (N == 1 || bytes == 0) return 0;
+  const uint64_t piece = ((bytes + N - 1) / N + 255) & ~255ull;  // 256-byte aligned pieces; the last ones may be short or empty
+  auto off = [&](int r) { return std::min<uint64_t>((uint64_t)r * piece, bytes); };
+  auto len = [&](int r) { return off(r + 1) - off(r); };
+  int n = 0;
+  auto put = [&](int phase, int src, int dst, int pc) {
+    if (!len(pc)) return;
+    if (n < cap) { out[n].phase = phase; out[n].src = src; out[n].dst = dst; out[n].off = off(pc); out[n].len = len(pc); }
+    n++;
+  };
+  for (int r = 1; r < N; r++) put(0, 0, r, r);  // the root deals piece r to rank r
+  for (int p = 1; p < N; p++)                   // receivers: everyone but the root, which holds everything
+    for (int s = 0; s < N; s++)
+      if (s != p) put(1, s, p, s);              // rank s passes its own piece (the root: piece 0) to p
+  return n;
+}
 
 extern "C" int k4_comm_unique_id(uint8_t id[K4_COMM_ID_BYTES]) {
   if (!id) return K4_ERR_PARAMS;
@@ -124,45 +145,49 @@ extern "C" int k4_comm_open_index(k4_comm* c, const char* sfx_path, int kmer_k, 
       c->err = k4_global_error();
   }
   // geometry first (a small ncclBroadcast), then the entries table, then the two big arrays over every link
-  Meta* d_m = nullptr;
-  CK_HIP(c, hipMalloc(&d_m, sizeof(Meta)));
-  if (c->rank == 0) CK_HIP(c, hipMemcpy(d_m, &m, sizeof(m), hipMemcpyHostToDevice));
-  CK_NCCL(c, ncclBroadcast(d_m, d_m, sizeof(Meta), ncclUint8, 0, c->comm, c->st));
-  CK_HIP(c, hipStreamSynchronize(c->st));
-  CK_HIP(c, hipMemcpy(&m, d_m, sizeof(m), hipMemcpyDeviceToHost));
-  hipFree(d_m);
+  struct Unmap {  // rank 0's mapping: released on every way out
+    k4_sfx_file* f;
+    bool on;
+    ~Unmap() { if (on) k4_sfx_unmap(f); }
+  } unmap{&f, c->rank == 0 && m.rc == K4_OK};
+  {
+    DevBuf d_m;
+    CK_HIP(c, hipMalloc(&d_m.p, sizeof(Meta)));
+    if (c->rank == 0) CK_HIP(c, hipMemcpy(d_m.p, &m, sizeof(m), hipMemcpyHostToDevice));
+    CK_NCCL(c, ncclBroadcast(d_m.p, d_m.p, sizeof(Meta), ncclUint8, 0, c->comm, c->st));
+    CK_HIP(c, hipStreamSynchronize(c->st));
+    CK_HIP(c, hipMemcpy(&m, d_m.p, sizeof(m), hipMemcpyDeviceToHost));
+  }
   if (m.rc != K4_OK) {  // every rank learns that the root could not read the file
-    if (c->rank == 0) k4_sfx_unmap(&f);
-    else fail(c, m.rc, "rank 0 could not read the index");
+    if (c->rank != 0) fail(c, m.rc, "rank 0 could not read the index");
     return m.rc;
   }
   std::vector<k4_entry> ents(m.ne);
   {
-    k4_entry* d_e = nullptr;
+    DevBuf d_e;
     const size_t eb = (size_t)m.ne * sizeof(k4_entry);
-    CK_HIP(c, hipMalloc(&d_e, eb));
-    if (c->rank == 0) CK_HIP(c, hipMemcpy(d_e, f.entries, eb, hipMemcpyHostToDevice));
-    CK_NCCL(c, ncclBroadcast(d_e, d_e, eb, ncclUint8, 0, c->comm, c->st));
+    CK_HIP(c, hipMalloc(&d_e.p, eb));
+    if (c->rank == 0) CK_HIP(c, hipMemcpy(d_e.p, f.entries, eb, hipMemcpyHostToDevice));
+    CK_NCCL(c, ncclBroadcast(d_e.p, d_e.p, eb, ncclUint8, 0, c->comm, c->st));
     CK_HIP(c, hipStreamSynchronize(c->st));
-    CK_HIP(c, hipMemcpy(ents.data(), d_e, eb, hipMemcpyDeviceToHost));
-    hipFree(d_e);
+    CK_HIP(c, hipMemcpy(ents.data(), d_e.p, eb, hipMemcpyDeviceToHost));
   }
-  uint8_t *d_seq = nullptr, *d_sa = nullptr;
-  CK_HIP(c, hipMalloc(&d_seq, m.n + 64));
-  CK_HIP(c, hipMalloc(&d_sa, m.n * m.el + 16));
-  if (c->rank == 0) {
-    CK_HIP(c, hipMemcpy(d_seq, f.seq, m.n, hipMemcpyHostToDevice));
-    CK_HIP(c, hipMemcpy(d_sa, f.sa, m.n * m.el, hipMemcpyHostToDevice));
-    k4_sfx_unmap(&f);
+  DevBuf d_seq, d_sa;
+  CK_HIP(c, hipMalloc(&d_seq.p, m.n + 64));
+  CK_HIP(c, hipMalloc(&d_sa.p, m.n * m.el + 16));
+  if (c->rank == 0) {  // the mapped file goes up through pinned pieces filled by several threads (k4_open's own way)
+    int urc = k4_upload_pageable(c->device, d_seq.p, f.seq, m.n);
+    if (urc == K4_OK) urc = k4_upload_pageable(c->device, d_sa.p, f.sa, m.n * m.el);
+    if (urc != K4_OK) return fail(c, urc, "%s", k4_global_error());  // (the peers wait in the exchange: the caller's job to end them)
   }
-  int rc = bcast_all_links(c, d_seq, m.n);
-  if (rc == K4_OK) rc = bcast_all_links(c, d_sa, m.n * m.el);
-  if (rc != K4_OK) { hipFree(d_seq); hipFree(d_sa); return rc; }
+  int rc = bcast_all_links(c, (uint8_t*)d_seq.p, m.n);
+  if (rc == K4_OK) rc = bcast_all_links(c, (uint8_t*)d_sa.p, m.n * m.el);
+  if (rc != K4_OK) return rc;
   // the suffix array stays where it arrived (adopted; released with the index), the byte sequence is only the source of the
   // packed form
-  rc = k4_open_device(m.n, m.el, d_seq, d_sa, 1, m.ne, ents.data(), m.dataset, c->device, kmer_k, out);
-  hipFree(d_seq);
-  if (rc != K4_OK) { hipFree(d_sa); return fail(c, rc, "%s", k4_global_error()); }
+  rc = k4_open_device(m.n, m.el, d_seq.p, d_sa.p, 1, m.ne, ents.data(), m.dataset, c->device, kmer_k, out);
+  if (rc != K4_OK) return fail(c, rc, "%s", k4_global_error());
+  d_sa.release();
   k4_set_raw_header(*out, m.header);
   return K4_OK;
 }
@@ -170,13 +195,12 @@ extern "C" int k4_comm_open_index(k4_comm* c, const char* sfx_path, int kmer_k, 
 extern "C" int k4_comm_allreduce_sum_u64(k4_comm* c, uint64_t* vals, int n) {
   if (!c || !vals || n < 1) return K4_ERR_PARAMS;
   CK_HIP(c, hipSetDevice(c->device));
-  uint64_t* d = nullptr;
-  CK_HIP(c, hipMalloc(&d, (size_t)n * 8));
-  CK_HIP(c, hipMemcpy(d, vals, (size_t)n * 8, hipMemcpyHostToDevice));
-  CK_NCCL(c, ncclAllReduce(d, d, (size_t)n, ncclUint64, ncclSum, c->comm, c->st));
+  DevBuf d;
+  CK_HIP(c, hipMalloc(&d.p, (size_t)n * 8));
+  CK_HIP(c, hipMemcpy(d.p, vals, (size_t)n * 8, hipMemcpyHostToDevice));
+  CK_NCCL(c, ncclAllReduce(d.p, d.p, (size_t)n, ncclUint64, ncclSum, c->comm, c->st));
   CK_HIP(c, hipStreamSynchronize(c->st));
-  CK_HIP(c, hipMemcpy(vals, d, (size_t)n * 8, hipMemcpyDeviceToHost));
-  hipFree(d);
+  CK_HIP(c, hipMemcpy(vals, d.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   return K4_OK;
 }
 

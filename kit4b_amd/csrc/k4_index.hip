@@ -574,6 +574,15 @@ static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void
   return K4_OK;
 }
 
+// pageable (or file-mapped) host memory -> device through pinned 128 MB pieces filled by several threads: what k4_open does with
+// the two big arrays of an .sfx file (10 GB/s where one pageable hipMemcpy gives 6), for callers that place an index themselves
+extern "C" int k4_upload_pageable(int device, void* d_dst, const void* h_src, uint64_t bytes) {
+  if (!d_dst || (!h_src && bytes)) return K4_ERR_PARAMS;
+  int rc = k4_check_hip(nullptr, hipSetDevice(device), "hipSetDevice");
+  if (rc != K4_OK) return rc;
+  return k4i_upload_pageable(nullptr, d_dst, (const uint8_t*)h_src, (size_t)bytes);
+}
+
 extern "C" int k4_open_host(uint64_t n, uint32_t el, const uint8_t* seq, const uint8_t* sa, uint32_t ne,
                             const k4_entry* entries, const char* dataset, int device, int kmer_k, k4_index** out) {
   if (!seq || !sa) return K4_ERR_PARAMS;

@@ -11,7 +11,9 @@
 //   SAM                  CKAligner::WriteBAMReadHits :5718-5914, ReportBAMread :5957-6320, SortHitMatch :10969,
 //                        CSAMfile::AddAlignment libkit4b/SAMfile.cpp:2194-2377 -> k4_format_sam_dev; header :1615,1667-1669,1799
 // Options follow kalign's letters: -i -u -I -o -s -e -m -n -U -d -D -E -l -L -r -R -X -N -c -a -A -x (plus -g <gpu>, -S <i/N> read slice).
+#include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -25,6 +27,7 @@
 #include <cstring>
 #include <map>
 #include <queue>
+#include <memory>
 #include <string>
 #include <vector>
 #include <sys/mman.h>
@@ -279,27 +282,25 @@ int feed_end(k4_pipeline* pl, int end, const std::vector<std::string>& files, in
 
 // ---- k4align -G: one rank process per GPU ---------------------------------------------------------------------------------------
 #define K4_MAX_RANKS 64
+#define K4_MAX_FILES 64  // reads files per end a -G run may name
 struct MultiShared {  // an anonymous shared mapping the parent creates before it forks the ranks
   uint8_t id[K4_COMM_ID_BYTES];
   std::atomic<int> id_ready, slices_ready, failed;
-  uint64_t slice_off[2][K4_MAX_RANKS + 1];  // byte offsets of the ranks' contiguous record slices in each reads file
+  // byte offsets of the ranks' record slices in every reads file of each end: rank r reads [off[r], off[r + 1]) of file f
+  uint64_t slice_off[2][K4_MAX_FILES][K4_MAX_RANKS + 1];
   uint64_t n_records;
 };
 
-// Byte offsets of the records r * R / N (r = 0..N) of an uncompressed FASTA / FASTQ file: reads are independent units, every
-// rank takes one contiguous slice (pairs stay together: both files are cut at the same record numbers).  Two parallel passes
-// over the mapped file: record starts per range, then the positions of the N - 1 inner boundaries.
-bool slice_records(const std::string& path, int n_ranks, uint64_t want_records, uint64_t* offs, uint64_t* n_records, int nt) {
-  const int fd = open(path.c_str(), O_RDONLY);
-  if (fd < 0) return false;
-  const uint64_t len = file_size(path);
-  if (len == 0) { close(fd); for (int r = 0; r <= n_ranks; r++) offs[r] = 0; *n_records = 0; return true; }
-  const uint8_t* t = (const uint8_t*)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
-  close(fd);
-  if (t == MAP_FAILED) return false;
-  const bool fastq = t[0] == '@';
-  // a "mark" is what starts a record: FASTA -- a '>' at the start of a line; FASTQ -- every 4th line start
-  auto count = [&](uint64_t a, uint64_t b) -> uint64_t {  // FASTA: header lines starting in [a, b); FASTQ: newlines in [a, b)
+// One uncompressed FASTA / FASTQ file mapped, its record starts counted per range (pass 1, parallel); byte offsets of given
+// record numbers come from a second look at the one range each falls into (pass 2).
+struct RecIndex {
+  const uint8_t* t = nullptr;
+  uint64_t len = 0, R = 0;
+  bool fastq = false;
+  int nt = 1;
+  std::vector<uint64_t> part;  // marks in front of range k (a mark starts a record: FASTA -- '>' at a line start; FASTQ -- every line)
+  ~RecIndex() { if (t && len) munmap((void*)t, len); }
+  uint64_t count(uint64_t a, uint64_t b) const {  // FASTA: header lines starting in [a, b); FASTQ: newlines in [a, b)
     uint64_t c = 0;
     if (fastq) {
       const uint8_t* p = t + a;
@@ -314,69 +315,208 @@ bool slice_records(const std::string& path, int n_ranks, uint64_t want_records, 
       }
     }
     return c;
-  };
-  std::vector<uint64_t> part((size_t)nt + 1, 0);
-  {
-    std::vector<std::thread> th;
-    for (int k = 0; k < nt; k++) th.emplace_back([&, k] { part[(size_t)k + 1] = count(len * k / nt, len * (k + 1) / nt); });
-    for (std::thread& x : th) x.join();
   }
-  for (int k = 0; k < nt; k++) part[(size_t)k + 1] += part[(size_t)k];
-  uint64_t R;
-  if (fastq) { const uint64_t lines = part[(size_t)nt] + (t[len - 1] != '\n' ? 1 : 0); R = lines / 4; }
-  else R = part[(size_t)nt];
-  if (want_records != UINT64_MAX && R != want_records) { munmap((void*)t, len); *n_records = R; return false; }
-  *n_records = R;
-  offs[0] = 0;
-  offs[n_ranks] = len;
-  for (int r = 1; r < n_ranks; r++) {
-    const uint64_t rec = R * (uint64_t)r / (uint64_t)n_ranks;  // the slice of rank r starts at record `rec`
-    if (rec == 0) { offs[r] = 0; continue; }
-    if (rec >= R) { offs[r] = len; continue; }
+  bool open_file(const std::string& path, int threads) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    len = file_size(path);
+    nt = std::max(threads, 1);
+    part.assign((size_t)nt + 1, 0);
+    if (len == 0) { close(fd); R = 0; return true; }
+    t = (const uint8_t*)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (t == MAP_FAILED) { t = nullptr; return false; }
+    fastq = t[0] == '@';
+    std::vector<std::thread> th;
+    for (int k = 0; k < nt; k++) th.emplace_back([this, k] { part[(size_t)k + 1] = count(len * k / nt, len * (k + 1) / nt); });
+    for (std::thread& x : th) x.join();
+    for (int k = 0; k < nt; k++) part[(size_t)k + 1] += part[(size_t)k];
+    if (fastq) { const uint64_t lines = part[(size_t)nt] + (t[len - 1] != '\n' ? 1 : 0); R = lines / 4; }
+    else R = part[(size_t)nt];
+    return true;
+  }
+  uint64_t offset_of(uint64_t rec) const {  // where record `rec` (0-based) starts; R and beyond: the end of the file
+    if (rec == 0) return 0;
+    if (rec >= R) return len;
     // FASTQ: the byte behind newline number 4 * rec; FASTA: the position of header number rec (0-based)
     const uint64_t target = fastq ? 4 * rec : rec + 1;  // the target-th mark (1-based) of the file
     int k = 0;
     while (k + 1 < nt && part[(size_t)k + 1] < target) k++;
     uint64_t seen = part[(size_t)k], p = len * k / nt;
     const uint64_t end = len * (k + 1) / nt;
-    uint64_t at = len;
     if (fastq) {
-      while (p < end) { const void* q = memchr(t + p, '\n', (size_t)(end - p)); if (!q) break; p = (uint64_t)((const uint8_t*)q - t) + 1; if (++seen == target) { at = p; break; } }
+      while (p < end) { const void* q = memchr(t + p, '\n', (size_t)(end - p)); if (!q) break; p = (uint64_t)((const uint8_t*)q - t) + 1; if (++seen == target) return p; }
     } else {
       while (p < end) {
         const void* q = memchr(t + p, '>', (size_t)(end - p));
         if (!q) break;
         const uint64_t a2 = (uint64_t)((const uint8_t*)q - t);
-        if ((a2 == 0 || t[a2 - 1] == '\n') && ++seen == target) { at = a2; break; }
+        if ((a2 == 0 || t[a2 - 1] == '\n') && ++seen == target) return a2;
         p = a2 + 1;
       }
     }
-    offs[r] = at;
+    return len;
   }
-  munmap((void*)t, len);
+};
+
+// The records of all files of one end, taken as one sequence, cut into n_ranks contiguous slices: rank r gets the records
+// [R r / N, R (r + 1) / N) (pairs stay together: both ends are cut at the same record numbers, file by file -- the two ends'
+// files must hold the same numbers of records, as kalign demands of them).  offs[f][r]: where rank r starts in file f.
+// counts: records per file (filled for end 0, compared for end 1).
+bool slice_files(const std::vector<std::string>& files, int n_ranks, std::vector<uint64_t>& counts, bool compare_counts,
+                 uint64_t (*offs)[K4_MAX_RANKS + 1], uint64_t* n_records, int nt, std::string* why) {
+  std::vector<std::unique_ptr<RecIndex>> ri;
+  uint64_t R = 0;
+  for (size_t f = 0; f < files.size(); f++) {
+    ri.emplace_back(new RecIndex);
+    if (!ri.back()->open_file(files[f], nt)) { *why = "unable to read " + files[f]; return false; }
+    if (compare_counts && (f >= counts.size() || counts[f] != ri.back()->R)) {
+      *why = "the PE1 and PE2 files hold different numbers of reads (" + std::to_string(f < counts.size() ? counts[f] : 0) + ", " + std::to_string(ri.back()->R) + ")";
+      return false;
+    }
+    if (!compare_counts) counts.push_back(ri.back()->R);
+    R += ri.back()->R;
+  }
+  *n_records = R;
+  uint64_t start = 0;  // records in front of file f
+  for (size_t f = 0; f < files.size(); f++) {
+    for (int r = 0; r <= n_ranks; r++) {
+      const uint64_t g = r == n_ranks ? R : R * (uint64_t)r / (uint64_t)n_ranks;  // first record of rank r, over all files
+      const uint64_t local = g <= start ? 0 : std::min<uint64_t>(g - start, ri[f]->R);
+      offs[f][r] = ri[f]->offset_of(local);  // (behind the file's last record: its length, a missing final newline included)
+    }
+    start += ri[f]->R;
+  }
   return true;
 }
 
-// the byte range [a, b) of one uncompressed file into the pipeline
-int feed_range(k4_pipeline* pl, int end, const std::string& path, uint64_t a, uint64_t b, int io_threads, double* secs_read) {
-  const int fd = open(path.c_str(), O_RDONLY);
-  if (fd < 0) return K4_ERR_OPEN_FILE;
+// the byte ranges [a, b) of uncompressed files, one after the other, into the pipeline; a range that ends a file which lacks its
+// last newline gets one (the next file's first record starts on a line of its own)
+struct FileRange { std::string path; uint64_t a, b, file_len; };
+int feed_ranges(k4_pipeline* pl, int end, const std::vector<FileRange>& ranges, int io_threads, double* secs_read) {
   double busy = 0;
-  uint64_t pos = a;
+  void* buf = nullptr;
+  uint64_t cap = 0, used = 0;
   int rc = K4_OK;
-  do {
-    void* buf = nullptr;
-    uint64_t cap = 0;
-    if ((rc = k4_pipeline_acquire(pl, end, &buf, &cap)) != K4_OK) break;
-    const uint64_t len = std::min<uint64_t>(cap, b - pos);
-    auto t0 = std::chrono::steady_clock::now();
-    if (len && !pread_parallel(fd, pos, (uint8_t*)buf, len, io_threads)) { rc = K4_ERR_FILE_ACCESS; break; }
-    busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    pos += len;
-    rc = k4_pipeline_submit(pl, end, len, pos == b);
-  } while (rc == K4_OK && pos < b);
-  close(fd);
+  auto flush = [&](int fin) { const int r = k4_pipeline_submit(pl, end, used, fin); buf = nullptr; used = 0; return r; };
+  for (size_t k = 0; k < ranges.size() && rc == K4_OK; k++) {
+    const FileRange& fr = ranges[k];
+    if (fr.b <= fr.a) continue;
+    const int fd = open(fr.path.c_str(), O_RDONLY);
+    if (fd < 0) return K4_ERR_OPEN_FILE;
+    uint64_t pos = fr.a;
+    uint8_t last = '\n';
+    while (pos < fr.b && rc == K4_OK) {
+      if (!buf) { if ((rc = k4_pipeline_acquire(pl, end, &buf, &cap)) != K4_OK) break; used = 0; }
+      const uint64_t len = std::min<uint64_t>(cap - used, fr.b - pos);
+      auto t0 = std::chrono::steady_clock::now();
+      if (len && !pread_parallel(fd, pos, (uint8_t*)buf + used, len, io_threads)) { rc = K4_ERR_FILE_ACCESS; break; }
+      busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      pos += len;
+      used += len;
+      if (len) last = ((uint8_t*)buf)[used - 1];
+      if (used == cap) rc = flush(0);
+    }
+    close(fd);
+    if (rc == K4_OK && fr.b == fr.file_len && last != '\n') {
+      bool more = false;
+      for (size_t q = k + 1; q < ranges.size(); q++) more |= ranges[q].b > ranges[q].a;
+      if (more) {
+        if (!buf) { if ((rc = k4_pipeline_acquire(pl, end, &buf, &cap)) != K4_OK) break; used = 0; }
+        ((uint8_t*)buf)[used++] = '\n';
+        if (used == cap) rc = flush(0);
+      }
+    }
+  }
+  if (rc == K4_OK) {
+    if (!buf) { if ((rc = k4_pipeline_acquire(pl, end, &buf, &cap)) != K4_OK) return rc; used = 0; }
+    rc = flush(1);  // the final (possibly empty) chunk
+  }
   if (secs_read) *secs_read = busy;
+  return rc;
+}
+
+// Compressed input cannot be cut by byte offsets: every rank inflates the whole stream and keeps the record blocks dealt to it --
+// block number (record number / K4_DEAL_RECORDS) modulo the rank count; both ends are dealt by the same record numbers, so
+// mates stay together.  (Equal sort keys then come out in block order, not in load order: the reference leaves that order open.)
+#define K4_DEAL_RECORDS (1u << 18)
+int feed_dealt(k4_pipeline* pl, int end, const std::vector<std::string>& files, int rank, int n_ranks, double* secs_read) {
+  void* buf = nullptr;
+  uint64_t cap = 0, used = 0;
+  int rc = K4_OK;
+  auto t00 = std::chrono::steady_clock::now();
+  double waited = 0;
+  auto put = [&](const uint8_t* p, uint64_t n) {  // bytes of this rank's records into the pipeline
+    while (n && rc == K4_OK) {
+      if (!buf) {
+        auto w0 = std::chrono::steady_clock::now();
+        rc = k4_pipeline_acquire(pl, end, &buf, &cap);
+        waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+        used = 0;
+        if (rc != K4_OK) return;
+      }
+      const uint64_t take = std::min<uint64_t>(n, cap - used);
+      memcpy((uint8_t*)buf + used, p, take);
+      used += take; p += take; n -= take;
+      if (used == cap) { rc = k4_pipeline_submit(pl, end, used, 0); buf = nullptr; used = 0; }
+    }
+  };
+  std::vector<uint8_t> chunk((size_t)16 << 20);
+  uint64_t rec = 0;      // records begun so far, over all files
+  uint32_t lines = 0;    // FASTQ: lines of the current record seen so far
+  int fastq = -1;
+  bool at_line_start = true;
+  uint8_t last = '\n';
+  for (size_t f = 0; f < files.size() && rc == K4_OK; f++) {
+    gzFile g = gzopen(files[f].c_str(), "rb");  // (reads plain files as they are)
+    if (!g) return K4_ERR_OPEN_FILE;
+    gzbuffer(g, 4u << 20);
+    for (;;) {
+      const int got = gzread(g, chunk.data(), (unsigned)chunk.size());
+      if (got < 0) { gzclose(g); return K4_ERR_FILE_ACCESS; }
+      if (got == 0) break;
+      if (fastq < 0) fastq = chunk[0] == '@' ? 1 : 0;
+      // runs of bytes that belong to one record block go out (or not) together
+      int run_start = 0;
+      bool mine = rec ? ((rec - 1) / K4_DEAL_RECORDS) % (uint64_t)n_ranks == (uint64_t)rank : false;  // the record we are inside
+      for (int q = 0; q < got; q++) {
+        const uint8_t ch = chunk[(size_t)q];
+        bool starts = false;
+        if (at_line_start) {
+          if (fastq) { if (lines == 0) starts = true; }
+          else if (ch == '>') starts = true;
+        }
+        if (starts) {
+          const bool m2 = (rec / K4_DEAL_RECORDS) % (uint64_t)n_ranks == (uint64_t)rank;
+          if (m2 != mine) {
+            if (mine) put(chunk.data() + run_start, (uint64_t)(q - run_start));
+            run_start = q;
+            mine = m2;
+          }
+          rec++;
+        }
+        at_line_start = ch == '\n';
+        if (fastq && at_line_start) lines = (lines + 1) & 3u;
+      }
+      if (mine) put(chunk.data() + run_start, (uint64_t)(got - run_start));
+      last = chunk[(size_t)got - 1];
+      if (rc != K4_OK) break;
+    }
+    gzclose(g);
+    if (last != '\n' && f + 1 < files.size()) {  // the next file starts on a line of its own
+      const bool mine = rec ? ((rec - 1) / K4_DEAL_RECORDS) % (uint64_t)n_ranks == (uint64_t)rank : false;
+      const uint8_t nl = '\n';
+      if (mine) put(&nl, 1);
+      at_line_start = true;
+      if (fastq == 1) lines = (lines + 1) & 3u;
+      last = '\n';
+    }
+  }
+  if (rc == K4_OK) {
+    if (!buf) { if ((rc = k4_pipeline_acquire(pl, end, &buf, &cap)) != K4_OK) return rc; used = 0; }
+    rc = k4_pipeline_submit(pl, end, used, 1);
+  }
+  if (secs_read) *secs_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t00).count() - waited;
   return rc;
 }
 
@@ -425,6 +565,15 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   int rc;
   const bool multi = o.n_ranks > 1 || o.shared;
   const bool chatty = o.rank == 0;  // only rank 0 of a -G run reports
+  const char* fault = multi ? getenv("K4ALIGN_FAULT") : nullptr;  // tests of run_multi_gpu: "<rank>:<stage>"
+  const int fault_rank = fault ? atoi(fault) : -1;
+  const char* fault_stage = fault && strchr(fault, ':') ? strchr(fault, ':') + 1 : "";
+  if (multi && fault) {
+    if (fault_rank == o.rank && strcmp(fault_stage, "start") == 0) { fprintf(stderr, "k4align: rank %d: injected fault at start\n", o.rank); return 3; }
+    const char* peers = getenv("K4ALIGN_FAULT_PEERS");
+    if (fault_rank != o.rank && peers && strcmp(peers, "block") == 0)
+      for (;;) pause();  // what a rank blocked in a collective looks like to the parent
+  }
   if (multi) {
     // the communicator id: rank 0 makes it, the others pick it up from the shared mapping
     MultiShared* sh = o.shared;
@@ -437,6 +586,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     // rank 0 reads the .sfx once; sequence + suffix array reach the peers over xGMI; every rank builds its own tables
     rc = k4_comm_open_index(comm, o.rank == 0 ? o.sfx.c_str() : nullptr, 0, &ix);
     if (rc != K4_OK) { fprintf(stderr, "k4align: rank %d: index broadcast failed: %s (%d)\n", o.rank, k4_comm_last_error(comm), rc); sh->failed = 1; return 2; }
+    if (fault_rank == o.rank && strcmp(fault_stage, "index") == 0) { fprintf(stderr, "k4align: rank %d: injected fault behind the index broadcast\n", o.rank); return 3; }
   } else {
     rc = k4_open(o.sfx.c_str(), o.gpu, 0, &ix);
     if (rc != K4_OK) { fprintf(stderr, "k4align: unable to load '%s': %s (%d)\n", o.sfx.c_str(), k4_global_error(), rc); return 2; }
@@ -654,20 +804,34 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       // reads are independent units: rank r aligns the r-th contiguous slice of the records (pairs stay together).  Rank 0
       // finds the slice boundaries (one pass over the files), every rank then reads only its own byte range
       MultiShared* sh = o.shared;
-      if (o.rank == 0) {
-        uint64_t R = 0, R2 = 0;
-        bool ok = slice_records(o.in1[0], o.n_ranks, UINT64_MAX, sh->slice_off[0], &R, o.io_threads);
-        if (ok && pe) {
-          ok = slice_records(o.in2[0], o.n_ranks, R, sh->slice_off[1], &R2, o.io_threads);
-          if (!ok && R2 != R) fprintf(stderr, "k4align: the PE1 and PE2 files hold different numbers of reads (%llu, %llu)\n", (unsigned long long)R, (unsigned long long)R2);
+      bool any_gz = false;
+      for (const std::string& q : o.in1) any_gz |= is_gzip(q);
+      for (const std::string& q : o.in2) any_gz |= is_gzip(q);
+      if (any_gz) {  // no byte offsets into a compressed stream: record blocks are dealt to the ranks
+        if (pe) t2 = std::thread([&] { rc_end[1] = feed_dealt(pl, 1, o.in2, o.rank, o.n_ranks, &rd[1]); });
+        rc_end[0] = feed_dealt(pl, 0, o.in1, o.rank, o.n_ranks, &rd[0]);
+      } else {
+        if (o.rank == 0) {
+          uint64_t R = 0, R2 = 0;
+          std::vector<uint64_t> counts;
+          std::string why;
+          bool ok = slice_files(o.in1, o.n_ranks, counts, false, sh->slice_off[0], &R, o.io_threads, &why);
+          if (ok && pe) ok = o.in2.size() == o.in1.size() ? slice_files(o.in2, o.n_ranks, counts, true, sh->slice_off[1], &R2, o.io_threads, &why)
+                                                          : (why = "as many -u files as -i files are needed", false);
+          if (!ok) { fprintf(stderr, "k4align: unable to cut the reads into slices: %s\n", why.c_str()); sh->failed = 1; return 2; }
+          sh->n_records = R;
+          sh->slices_ready = 1;
+        } else
+          while (!sh->slices_ready.load()) { if (sh->failed.load()) return 2; usleep(1000); }
+        std::vector<FileRange> fr[2];
+        for (int e = 0; e < (pe ? 2 : 1); e++) {
+          const std::vector<std::string>& fl = e ? o.in2 : o.in1;
+          for (size_t f = 0; f < fl.size(); f++)
+            fr[e].push_back(FileRange{fl[f], sh->slice_off[e][f][o.rank], sh->slice_off[e][f][o.rank + 1], file_size(fl[f])});
         }
-        if (!ok) { fprintf(stderr, "k4align: unable to cut the reads into slices\n"); sh->failed = 1; return 2; }
-        sh->n_records = R;
-        sh->slices_ready = 1;
-      } else
-        while (!sh->slices_ready.load()) { if (sh->failed.load()) return 2; usleep(1000); }
-      if (pe) t2 = std::thread([&] { rc_end[1] = feed_range(pl, 1, o.in2[0], sh->slice_off[1][o.rank], sh->slice_off[1][o.rank + 1], o.io_threads, &rd[1]); });
-      rc_end[0] = feed_range(pl, 0, o.in1[0], sh->slice_off[0][o.rank], sh->slice_off[0][o.rank + 1], o.io_threads, &rd[0]);
+        if (pe) t2 = std::thread([&] { rc_end[1] = feed_ranges(pl, 1, fr[1], o.io_threads, &rd[1]); });
+        rc_end[0] = feed_ranges(pl, 0, fr[0], o.io_threads, &rd[0]);
+      }
     } else {
       if (pe) t2 = std::thread([&] { rc_end[1] = feed_end(pl, 1, o.in2, o.io_threads, &rd[1]); });
       rc_end[0] = feed_end(pl, 0, o.in1, o.io_threads, &rd[0]);
@@ -954,18 +1118,21 @@ static int run_multi_gpu(Opts& o, bool pe, int max_ml) {
     fprintf(stderr, "k4align: -r2 / -r3 / -r4 / -a / -A look at all reads of the run; they cannot be combined with -G\n");
     return 1;
   }
-  if (o.in1.size() != 1 || (pe && o.in2.size() != 1)) { fprintf(stderr, "k4align: -G takes one reads file per end\n"); return 1; }
-  for (const std::string& q : {o.in1[0], pe ? o.in2[0] : o.in1[0]})
-    if (is_gzip(q)) { fprintf(stderr, "k4align: -G cuts the reads file by record offsets: '%s' must be uncompressed\n", q.c_str()); return 1; }
+  if (o.in1.size() > K4_MAX_FILES || o.in2.size() > K4_MAX_FILES) { fprintf(stderr, "k4align: -G takes at most %d reads files per end\n", K4_MAX_FILES); return 1; }
   MultiShared* sh = (MultiShared*)mmap(nullptr, sizeof(MultiShared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
   if (sh == MAP_FAILED) { fprintf(stderr, "k4align: unable to map shared memory\n"); return 2; }
   memset((void*)sh, 0, sizeof(*sh));
   const std::string final_out = o.out;
   auto t0 = std::chrono::steady_clock::now();
+  // fault injection for the tests of this function (K4ALIGN_FAULT=<rank>:<stage>): the named rank leaves with exit code 3 at
+  // "start" (before the communicator exists) / "index" (after the broadcast of the index); with K4ALIGN_FAULT_PEERS=block the
+  // other ranks then behave like ranks blocked inside a collective -- they wait for ever -- so that a machine without GPUs can
+  // show that the parent ends a run one of whose ranks died
   std::vector<pid_t> kids;
+  bool fork_failed = false;
   for (int r = 0; r < N; r++) {
     const pid_t pid = fork();
-    if (pid < 0) { fprintf(stderr, "k4align: fork failed\n"); sh->failed = 1; break; }
+    if (pid < 0) { fprintf(stderr, "k4align: fork failed\n"); sh->failed = 1; fork_failed = true; break; }
     if (pid == 0) {
       o.rank = r; o.n_ranks = N; o.gpu = o.gpus[(size_t)r]; o.shared = sh;
       o.out = final_out + ".rank" + std::to_string(r);
@@ -976,23 +1143,42 @@ static int run_multi_gpu(Opts& o, bool pe, int max_ml) {
     }
     kids.push_back(pid);
   }
-  int worst = 0;
-  for (pid_t k : kids) {
+  // The ranks meet in collectives: one that dies (or never started) leaves its peers waiting inside RCCL for ever.  So the
+  // parent reaps whichever child ends first; at the first failure -- a non-zero exit, a signal, a fork that failed -- the
+  // others are killed and reaped, the shards removed, and the run ends with that failure's code within moments.
+  int worst = fork_failed ? 2 : 0;
+  size_t alive = kids.size();
+  auto kill_rest = [&]() {
+    for (pid_t k : kids)
+      if (k > 0) kill(k, SIGKILL);
+  };
+  if (fork_failed) kill_rest();
+  while (alive) {
     int st = 0;
-    waitpid(k, &st, 0);
+    const pid_t done = waitpid(-1, &st, 0);
+    if (done < 0) { if (errno == EINTR) continue; break; }
+    bool ours = false;
+    for (pid_t& k : kids)
+      if (k == done) { k = -1; ours = true; }
+    if (!ours) continue;
+    alive--;
     const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 9;
-    if (rc) worst = rc;
+    if (rc && !worst) {
+      worst = rc;
+      fprintf(stderr, "k4align: a rank %s (%d): ending the others\n", WIFEXITED(st) ? "failed" : "was killed", WIFEXITED(st) ? rc : WTERMSIG(st));
+      kill_rest();
+    }
   }
   std::vector<std::string> shards;
   for (int r = 0; r < N; r++) shards.push_back(final_out + ".rank" + std::to_string(r));
   if (worst || sh->failed) {
     for (const std::string& q : shards) remove(q.c_str());
-    fprintf(stderr, "k4align: a rank failed (%d)\n", worst);
+    munmap((void*)sh, sizeof(*sh));
     return worst ? worst : 2;
   }
   auto t1 = std::chrono::steady_clock::now();
   unsigned long long n = 0;
-  const int rc = k4merge::merge_sam(shards, final_out, o.rpt_sq_thres, &n, "k4align");
+  const int rc = k4merge::merge_sam(shards, final_out, o.rpt_sq_thres, &n, "k4align", std::max(o.io_threads, 1) * N);  // (the ranks' reader threads are idle now)
   for (const std::string& q : shards) remove(q.c_str());
   if (rc) return rc;
   fprintf(stderr, "k4align: %llu alignments from %d GPUs written to %s; ranks %.2fs, merge %.2fs\n", n, N, final_out.c_str(),
@@ -1062,19 +1248,23 @@ int main(int argc, char** argv) {
       default: usage(); return 1;
     }
   }
-  if (o.print_slices > 0 && !o.in1.empty()) {  // the slice table of a -G run (host only)
-    uint64_t offs[2][K4_MAX_RANKS + 1], R = 0, R2 = 0;
-    if (o.print_slices > K4_MAX_RANKS) return 1;
-    if (!slice_records(o.in1[0], o.print_slices, UINT64_MAX, offs[0], &R, o.io_threads)) { fprintf(stderr, "k4align: unable to cut '%s'\n", o.in1[0].c_str()); return 2; }
-    if (!o.in2.empty() && !slice_records(o.in2[0], o.print_slices, R, offs[1], &R2, o.io_threads)) {
-      fprintf(stderr, "k4align: the PE1 and PE2 files hold different numbers of reads (%llu, %llu)\n", (unsigned long long)R, (unsigned long long)R2);
-      return 3;
-    }
-    printf("records %llu\n", (unsigned long long)R);
+  if (o.print_slices > 0 && !o.in1.empty()) {  // the slice table of a -G run (host only): per end and file, where each rank starts
+    if (o.print_slices > K4_MAX_RANKS || o.in1.size() > K4_MAX_FILES || o.in2.size() > K4_MAX_FILES) return 1;
+    std::vector<std::vector<uint64_t>> tab[2];
+    uint64_t R = 0, R2 = 0;
+    std::vector<uint64_t> counts;
+    std::string why;
+    auto offs = std::unique_ptr<uint64_t[][K4_MAX_RANKS + 1]>(new uint64_t[K4_MAX_FILES][K4_MAX_RANKS + 1]);
     for (int e = 0; e < (o.in2.empty() ? 1 : 2); e++) {
-      printf("end %d", e);
-      for (int r = 0; r <= o.print_slices; r++) printf(" %llu", (unsigned long long)offs[e][r]);
-      printf("\n");
+      const std::vector<std::string>& fl = e ? o.in2 : o.in1;
+      if (e && o.in2.size() != o.in1.size()) { fprintf(stderr, "k4align: as many -u files as -i files are needed\n"); return 3; }
+      if (!slice_files(fl, o.print_slices, counts, e == 1, offs.get(), e ? &R2 : &R, o.io_threads, &why)) { fprintf(stderr, "k4align: %s\n", why.c_str()); return e ? 3 : 2; }
+      if (e == 0) printf("records %llu\n", (unsigned long long)R);
+      for (size_t f = 0; f < fl.size(); f++) {
+        if (fl.size() == 1) printf("end %d", e); else printf("end %d file %d", e, (int)f);
+        for (int r = 0; r <= o.print_slices; r++) printf(" %llu", (unsigned long long)offs[f][r]);
+        printf("\n");
+      }
     }
     return 0;
   }

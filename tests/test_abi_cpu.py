@@ -89,7 +89,7 @@ def test_comm_library_exports_its_header():
     """include/k4comm.h (the RCCL side: index broadcast over xGMI, all-reduce of the tallies) <-> kit4b_amd/libk4comm.so"""
     hdr = open(os.path.join(ROOT, "include", "k4comm.h")).read()
     declared = set(re.findall(r"^(?:int|void|const char\*)\s+(k4_comm_\w+)\s*\(", hdr, flags=re.M))
-    assert len(declared) == 9
+    assert len(declared) == 10
     so = os.path.join(ROOT, "kit4b_amd", "libk4comm.so")
     assert os.path.exists(so), "make -C kit4b_amd/csrc"
     kit4b_amd.lib()  # libk4sfx.so first: libk4comm.so is linked against it
@@ -101,3 +101,59 @@ def test_comm_library_exports_its_header():
 
     needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "kit4b_amd", "libk4sfx.so")], capture_output=True, text=True).stdout
     assert "rccl" not in needed and "rccl" in subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+
+
+def test_index_exchange_schedule_for_every_rank_count():
+    """k4_comm_bcast_schedule (include/k4comm.h): the list of transfers the RCCL calls of k4_comm_open_index are issued from.
+    Simulated here for 1..8 ranks (and 64) and awkward sizes: a rank only sends what it holds when the phase starts, nothing is
+    written twice, every rank ends with every byte, no (src, dst) link carries more than one piece per phase, the root's
+    links carry exactly one piece each in phase 0 (all of its direct links busy, none twice)."""
+    kit4b_amd.lib()
+    Lc = C.CDLL(os.path.join(ROOT, "kit4b_amd", "libk4comm.so"))
+
+    class Xfer(C.Structure):
+        _fields_ = [("phase", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32), ("off", C.c_uint64), ("len", C.c_uint64)]
+
+    Lc.k4_comm_bcast_schedule.argtypes = [C.c_int, C.c_uint64, C.POINTER(Xfer), C.c_int]
+    for n in (1, 2, 3, 4, 5, 6, 7, 8, 64):
+        for size in (0, 1, 255, 256, 257, 4096 * n + 3, 1_000_003, 3_000_000_024, 15_000_000_120 * 5):
+            cap = 2 * n * n
+            buf = (Xfer * cap)()
+            k = Lc.k4_comm_bcast_schedule(n, size, buf, cap)
+            assert 0 <= k <= cap
+            assert Lc.k4_comm_bcast_schedule(n, size, buf, 0) == k  # the count alone
+            xs = [(x.phase, x.src, x.dst, x.off, x.len) for x in buf[:k]]
+            if n == 1 or size == 0:
+                assert k == 0
+                continue
+            piece = ((size + n - 1) // n + 255) & ~255
+            have = [[(0, size)] if r == 0 else [] for r in range(n)]  # byte intervals each rank holds
+
+            def holds(r, off, ln):
+                return any(a <= off and off + ln <= b for a, b in have[r])
+
+            for phase in (0, 1):
+                cur = [x for x in xs if x[0] == phase]
+                links = {}
+                for _, src, dst, off, ln in cur:
+                    assert src != dst and 0 <= src < n and 0 <= dst < n and ln > 0 and off + ln <= size
+                    assert holds(src, off, ln), (n, size, phase, src, dst)          # held BEFORE the phase (sends of a phase run together)
+                    assert not any(a < off + ln and off < b for a, b in have[dst])  # nothing arrives twice
+                    links[(src, dst)] = links.get((src, dst), 0) + ln
+                assert all(v <= piece for v in links.values())
+                if phase == 0:
+                    assert all(s == 0 for s, _ in links) and len(links) == len(cur)  # the root's links, each once
+                for _, src, dst, off, ln in cur:
+                    have[dst].append((off, off + ln))
+                for r in range(n):  # coalesce
+                    iv = sorted(have[r])
+                    out = []
+                    for a, b in iv:
+                        if out and a <= out[-1][1]:
+                            out[-1] = (out[-1][0], max(out[-1][1], b))
+                        else:
+                            out.append((a, b))
+                    have[r] = out
+            assert all(h == [(0, size)] for h in have), (n, size)
+            # volume: every byte reaches every non-root rank exactly once
+            assert sum(x[4] for x in xs) == size * (n - 1)

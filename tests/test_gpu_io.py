@@ -477,6 +477,47 @@ def test_k4align_rank_mode_over_rccl(golden_dir, tmp_path, case):
     assert not os.path.exists(out + ".rank0")
 
 
+@pytest.mark.parametrize("case,form", [("se_s2", "gz"), ("pe_u1", "gz"), ("se_s2", "split"), ("pe_u1", "split")])
+def test_k4align_rank_mode_takes_compressed_and_several_input_files(golden_dir, tmp_path, case, form):
+    """`k4align -G` on what a single `kalign` run takes as well: gzipped reads (no byte offsets into a compressed stream: every
+    rank inflates it and keeps the record blocks dealt to it) and several -i / -u files (one sequence of records, cut by record
+    numbers over all files).  One rank here; the SAM equals the reference's."""
+    import gzip
+    import json
+    import lzma
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(golden_dir, "sam_cases.json")))
+    names = ["sam_%s.fa.xz" % case] if case.startswith("se_") else ["sam_%s_1.fa.xz" % case, "sam_%s_2.fa.xz" % case]
+    files = []
+    for e, name in enumerate(names):
+        text = lzma.open(os.path.join(golden_dir, name)).read()
+        flag = "-i" if e == 0 else "-u"
+        if form == "gz":
+            dst = str(tmp_path / (name[:-3] + ".gz"))
+            gzip.open(dst, "wb").write(text)
+            files += [flag, dst]
+        else:  # three files per end, cut between records at the same record numbers in both ends (the middle one lacks its newline)
+            recs = text.decode().split(">")[1:]
+            cuts = [0, len(recs) // 3, len(recs) // 3 + 7, len(recs)]
+            for k in range(3):
+                dst = str(tmp_path / ("%d_%d.fa" % (e, k)))
+                part = "".join(">" + r for r in recs[cuts[k]:cuts[k + 1]])
+                open(dst, "w").write(part[:-1] if k == 1 else part)
+                files += [flag, dst]
+    out = str(tmp_path / "o.sam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-G", "0"]
+                       + cases[case]["args"] + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    want = [l for l in lzma.open(os.path.join(golden_dir, "sam_%s.sam.xz" % case)).read().decode().splitlines() if not l.startswith("@PG")]
+    assert [l for l in got if l.startswith("@")] == [l for l in want if l.startswith("@")]
+    assert sorted(got) == sorted(want)
+    for name, n in cases[case]["nar"].items():
+        assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+
+
 @pytest.mark.parametrize("case,level", [("se_s2", "6"), ("pe_u1", "1"), ("se_all_120", "6")])
 def test_k4align_writes_the_reference_bam(golden_dir, tmp_path, case, level):
     """`k4align -o x.bam`: records packed on the device (k4_pipeline_format_bam), BGZF blocks and .bai on host threads

@@ -128,6 +128,38 @@ def test_pipeline_all_reads_body(ix, k4):
     assert all(l.split("\t")[1:9] == ["4", "*", "0", "128", "100M", "*", "0", "0"] for l in rest)
 
 
+def test_format_sam_all_reads_through_the_python_api(ix, k4):
+    """k4_format_sam_all_dev / k4_format_bam_all_dev called through kit4b_amd.format_sam(all_reads=True) -- device addresses pass
+    through ctypes whole (every ABI symbol declares its argument types) -- give what the pipeline's -M1 form gives."""
+    names, chroms = synth.golden_genome()
+    reads = synth.make_reads(chroms, 6000, 100, seed=77, n_prob=0.05, edge_frac=0.05, random_frac=0.08)[0]
+    text = fastx(reads, False)
+    kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+    want, wst, _ = ix.pipeline_sam([text], kp, all_reads=True)
+    p = ix.parse_fastx(text)
+    prep = ix.prepare_reads(p, None, 50, 500)
+    n = prep["n_units"]
+    dev = prep["reads"].device
+    rr = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+    hits = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    ix.reserve(n, prep["max_len"], 1)
+    ix.kalign_batch_dev(kp, n, prep["max_len"], prep["reads"].data_ptr(), prep["offs"].data_ptr(), prep["lens"].data_ptr(), rr.data_ptr(),
+                        hits.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    body, st, _ = ix.format_sam(prep, p, rr=rr, hits=hits, max_ml=1, all_reads=True)
+    assert body == want and st["nar"] == wst["nar"] and st["n_lines"] == wst["n_lines"]
+    assert body.count(b"YU:Z:") == n - st["nar"][1] > 0
+    bam, bst, _ = ix.format_sam(prep, p, rr=rr, hits=hits, max_ml=1, all_reads=True, bam=True)
+    assert bst["n_lines"] == st["n_lines"] and len(bam) > 0
+    # the records' block sizes chain through the whole buffer
+    import struct
+    off, nrec = 0, 0
+    while off < len(bam):
+        off += 4 + struct.unpack_from("<i", bam, off)[0]
+        nrec += 1
+    assert off == len(bam) and nrec == st["n_lines"]
+
+
 def test_pipeline_degenerate_inputs(ix, k4):
     kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
     got, st, _ = ix.pipeline_sam([b""], kp)

@@ -37,3 +37,57 @@ def test_k4merge(tmp_path, golden_dir, case, n_shards):
     keys = sort_keys(got)
     assert keys == sorted(keys)
     assert ("%d alignments from %d shards" % (len(recs), n_shards)) in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="k4merge not built")
+def test_k4merge_parallel_equals_serial_and_a_reference_merge(tmp_path):
+    """The parallel merge (splitters sampled from the shards, every shard bisected per splitter, partitions merged side by side
+    and written with pwrite) against a plain sort: many records with EQUAL keys (ties go to the lower shard, and never straddle
+    a splitter), shards of very different sizes, an empty shard, thread counts 1 / 3 / 8."""
+    import random
+
+    rnd = random.Random(5)
+    chroms = ["chr%d" % (i + 1) for i in range(7)]
+    hdr = ["@HD\tVN:1.4\tSO:coordinate"] + ["@SQ\tAS:t\tSN:%s\tLN:1000000" % c for c in chroms] + ["@PG\tID:ngskit4b\tVN:2.0.2"]
+    sizes = [90000, 150, 0, 40000, 70000, 1]
+    shards, allrecs = [], []
+    for k, n in enumerate(sizes):
+        recs = []
+        for j in range(n):
+            c = rnd.randrange(7)
+            pos = rnd.randrange(1, 3000) if rnd.random() < 0.5 else rnd.randrange(1, 900000)  # a crowded stretch: equal keys
+            flag = 16 if rnd.random() < 0.5 else 0
+            ln = rnd.choice((100, 100, 100, 75))
+            cigar = "%dM" % ln if rnd.random() < 0.8 else "5S%dM" % (ln - 5)
+            recs.append((c, pos, ln - (5 if "S" in cigar else 0), 1 if flag else 0, k, j,
+                         "r%d_%d\t%d\t%s\t%d\t254\t%s\t*\t0\t0\t%s\t*" % (k, j, flag, chroms[c], pos, cigar, "A" * ln)))
+        recs.sort(key=lambda r: r[:4])  # a shard is sorted by (chrom, pos, len, strand); equal keys in load order
+        p = tmp_path / ("big%d.sam" % k)
+        p.write_text("\n".join(hdr + [r[6] for r in recs]) + "\n")
+        shards.append(str(p))
+        allrecs += recs
+    want = [r[6] for r in sorted(allrecs, key=lambda r: (r[0], r[1], r[2], r[3], r[4]))]  # ties: shard index (stable within one)
+    outs = []
+    for t in (1, 3, 8):
+        out = tmp_path / ("m%d.sam" % t)
+        r = subprocess.run([EXE, "-t", str(t), str(out)] + shards, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        got = out.read_text().splitlines()
+        assert got[:len(hdr)] == hdr
+        assert got[len(hdr):] == want, t
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] == outs[2]
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="k4merge not built")
+def test_k4merge_errors_leave_no_partial_file(tmp_path):
+    hdr = "@HD\tVN:1.4\tSO:coordinate\n@SQ\tAS:t\tSN:chr1\tLN:1000\n"
+    a = tmp_path / "a.sam"
+    a.write_text(hdr + "r1\t0\tchr1\t5\t254\t10M\t*\t0\t0\tAAAAAAAAAA\t*\n")
+    b = tmp_path / "b.sam"
+    b.write_text(hdr + "r2\t0\tchrX\t7\t254\t10M\t*\t0\t0\tAAAAAAAAAA\t*\n")  # a sequence no header declares
+    out = tmp_path / "o.sam"
+    r = subprocess.run([EXE, str(out), str(a), str(b)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "chrX" in r.stderr and not out.exists()
+    r = subprocess.run([EXE, str(out), str(a), str(tmp_path / "missing.sam")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and not out.exists()
