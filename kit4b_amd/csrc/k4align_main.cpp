@@ -800,6 +800,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     int rc_end[2] = {K4_OK, K4_OK};
     double rd[2] = {0, 0};
     std::thread t2;
+    std::vector<FileRange> fr[2];  // (outlive the reader thread of the second end)
     if (multi) {
       // reads are independent units: rank r aligns the r-th contiguous slice of the records (pairs stay together).  Rank 0
       // finds the slice boundaries (one pass over the files), every rank then reads only its own byte range
@@ -823,7 +824,6 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
           sh->slices_ready = 1;
         } else
           while (!sh->slices_ready.load()) { if (sh->failed.load()) return 2; usleep(1000); }
-        std::vector<FileRange> fr[2];
         for (int e = 0; e < (pe ? 2 : 1); e++) {
           const std::vector<std::string>& fl = e ? o.in2 : o.in1;
           for (size_t f = 0; f < fl.size(); f++)
