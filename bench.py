@@ -307,6 +307,8 @@ def parse_args(argv=None):
                          "(40 M pairs per step: the 200 M of BASELINE config 5 do not fit one GPU next to the 162 GB index); "
                          "rep: 50 M x 100 bp SE vs a repeat-rich 1 Gbp genome (40 000 implanted copies, N runs), -s2 -- the "
                          "secondary tracked line for real-genome-like input, bound by the general kernel")
+    ap.add_argument("--f2f-reads", type=int, default=50_000_000,
+                    help="reads (SE) / pairs (PE) of the file-to-file leg (k4align, files in tmpfs, index load inside the wall time; N=1, 0 = skip)")
     ap.add_argument("--chroms", type=int, default=None)
     ap.add_argument("--chrom-mbp", type=float, default=None)
     ap.add_argument("--reads", type=int, default=None, help="reads (SE) or pairs (PE) per GPU per step")
@@ -504,39 +506,111 @@ class GpuEngine:
             return out, self.out_pe[:, 6:10].contiguous(), self.out_pe
         return self.out, self.hits, None
 
-    def e2e(self, reads, n, L, max_subs, log_fn):
+    @staticmethod
+    def fastq_text(reads, first, count, L, dev, tag=ord("r")):
+        """[count, W] u8 on the GPU: '@r%09d' / bases / '+' / 'I' * L"""
+        W = 12 + L + 3 + L + 1
+        text = torch.empty((count, W), dtype=torch.uint8, device=dev)
+        text[:, 0] = ord("@"); text[:, 1] = tag
+        idx = torch.arange(first, first + count, device=dev)
+        for d in range(9):
+            text[:, 2 + d] = ((idx // (10 ** (8 - d))) % 10 + 48).to(torch.uint8)
+        text[:, 11] = 10
+        lut = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)
+        text[:, 12:12 + L] = lut[reads.long().clamp_(max=4)]
+        text[:, 12 + L] = 10; text[:, 13 + L] = ord("+"); text[:, 14 + L] = 10
+        text[:, 15 + L:15 + 2 * L] = ord("I")
+        text[:, W - 1] = 10
+        return text
+
+    def file_to_file(self, reads, n, L, max_subs, pe, log_fn):
+        """The program itself, files in, file out (all in tmpfs): `k4align -I g.sfx -i r.fq [-u r2.fq] -o o.sam` -- the index load
+        (a 15 GB .sfx at 3 Gbp) is INSIDE the wall figure and reported beside it.  Never `value`."""
+        import re
+        import shutil
+        import subprocess
+        import tempfile
+
+        dev = reads.device
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        tmp = tempfile.mkdtemp(prefix="k4f2f_", dir=base)
+        try:
+            info = self.ix.info()
+            n = min(n, reads.shape[0] // (2 if pe else 1))
+            need = info["concat_len"] * (1 + info["sfx_el_size"]) + (2 if pe else 1) * n * (2 * L + 16) * 2
+            if shutil.disk_usage(tmp).free < need * 1.15:
+                log_fn("file-to-file leg skipped: %s has too little free space" % tmp)
+                return None
+            sfx = os.path.join(tmp, "g.sfx")
+            self.ix.write_sfx(sfx)
+            files = []
+            for e in range(2 if pe else 1):
+                fq = os.path.join(tmp, "r%d.fq" % (e + 1))
+                with open(fq, "wb") as f:
+                    for b in range(0, n, 5_000_000):
+                        m = min(5_000_000, n - b)
+                        rows = reads[2 * b + e:2 * (b + m):2] if pe else reads[b:b + m]
+                        self.fastq_text(rows, b, m, L, dev).cpu().numpy().tofile(f)
+                files += ["-u" if e else "-i", fq]
+            torch.cuda.synchronize()
+            out = os.path.join(tmp, "o.sam")
+            cmd = [os.path.join(ROOT, "kit4b_amd", "k4align"), "-I", sfx, "-o", out, "-s%d" % max_subs, "-t", "16"] + files + (["-U2", "-d200", "-D600"] if pe else [])
+            best = None
+            for rep in range(2):
+                t0 = time.perf_counter()
+                p = subprocess.run(cmd, capture_output=True, text=True)
+                wall = time.perf_counter() - t0
+                if p.returncode != 0:
+                    log_fn("file-to-file leg failed: %s" % p.stderr[-400:])
+                    return None
+                if best is None or wall < best[0]:
+                    best = (wall, p.stderr)
+                if os.environ.get("K4_TRACE"):
+                    log_fn(p.stderr)
+            wall, err = best
+            rep_line = [l for l in err.splitlines() if "alignments written to" in l]
+            m = re.search(r"index ([\d.]+)s, read files ([\d.]+)s, upload\+parse ([\d.]+)s, align\+format ([\d.]+)s, write ([\d.]+)s", rep_line[-1]) if rep_line else None
+            units = 2 * n if pe else n
+            res = {"reads": units, "wall_s": wall, "Mreads_s_wall": units / wall / 1e6,
+                   "files_GB": {"sfx": os.path.getsize(sfx) / 1e9, "reads": sum(os.path.getsize(f) for f in files[1::2]) / 1e9, "sam": os.path.getsize(out) / 1e9},
+                   "note": "k4align, files in tmpfs, best of 2; the index load is inside wall_s"}
+            if m:
+                res.update(index_load_s=float(m.group(1)), read_files_s=float(m.group(2)), device_behind_reads_s=float(m.group(3)),
+                           align_format_s=float(m.group(4)), write_s=float(m.group(5)),
+                           Mreads_s_excl_index_load=units / max(wall - float(m.group(1)), 1e-9) / 1e6)
+            return res
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+    def e2e(self, reads, n, L, max_subs, log_fn, pe=False):
         """FASTQ text in (pinned) host memory -> SAM text in (pinned) host memory through the overlapped pipeline
         (k4_pipeline_*: chunks go up on the copy stream while earlier chunks are parsed and aligned; one global coordinate
         sort; the body comes down at the end).  PCIe-inclusive; never `value`.  Beside it: the time the same bytes take
         over PCIe alone -- up, then down: a coordinate-sorted output cannot start before the last read has arrived."""
         dev = reads.device
-        n = min(n, reads.shape[0])
+        ends = 2 if pe else 1
+        n = min(n, reads.shape[0] // ends)  # units: reads (SE) / pairs (PE)
         W = 12 + L + 3 + L + 1  # "@r%09d\n" + bases + "\n+\n" + quals + "\n"
         t0 = time.time()
-        text = torch.empty((n, W), dtype=torch.uint8, device=dev)
-        text[:, 0] = ord("@"); text[:, 1] = ord("r")
-        idx = torch.arange(n, device=dev)
-        for d in range(9):
-            text[:, 2 + d] = ((idx // (10 ** (8 - d))) % 10 + 48).to(torch.uint8)
-        text[:, 11] = 10
-        lut = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)
-        text[:, 12:12 + L] = lut[reads[:n].long().clamp_(max=4)]
-        text[:, 12 + L] = 10; text[:, 13 + L] = ord("+"); text[:, 14 + L] = 10
-        text[:, 15 + L:15 + 2 * L] = ord("I")
-        text[:, W - 1] = 10
         T = n * W
-        h_text = torch.empty(T, dtype=torch.uint8, pin_memory=True)
-        h_text.copy_(text.reshape(-1))
-        cap_out = n * (L + 80)
+        h_texts = []
+        for e in range(ends):
+            text = self.fastq_text(reads[e:ends * n:ends] if pe else reads[:n], 0, n, L, dev)
+            h = torch.empty(T, dtype=torch.uint8, pin_memory=True)
+            h.copy_(text.reshape(-1))
+            h_texts.append(h)
+            del text
+        h_text = h_texts[0]
+        cap_out = ends * n * (L + 90)
         h_sam = torch.empty(cap_out, dtype=torch.uint8, pin_memory=True)
-        del text, idx
         torch.cuda.synchronize()
-        log_fn("e2e: %d FASTQ records (%.2f GB) in pinned host memory in %.1fs" % (n, T / 1e9, time.time() - t0))
-        kp = k4.KalignParams(max_subs, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+        log_fn("e2e: %d FASTQ records (%.2f GB) in pinned host memory in %.1fs" % (ends * n, ends * T / 1e9, time.time() - t0))
+        kp = k4.KalignParams(max_subs, 1, 1, 0, k4.STRAND_BOTH, 10 if pe else 1, 1 if pe else 0, 0, 0)
+        pp = k4.PeParams(2, 200, 600, 0) if pe else None
         best = None
         for rep in range(3):
             t0 = time.perf_counter()
-            got, st, _ = self.ix.pipeline_sam([h_text], kp, min_len=50, max_len=500, out=h_sam)
+            got, st, _ = self.ix.pipeline_sam(h_texts, kp, pe=pp, min_len=50, max_len=500, out=h_sam)
             dt = time.perf_counter() - t0
             if best is None or dt < best[0]:
                 best = (dt, got, st)
@@ -545,9 +619,11 @@ class GpuEngine:
         # the same bytes over PCIe alone, pinned both ways
         d_buf = torch.empty(max(T, got), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        t0 = time.perf_counter(); d_buf[:T].copy_(h_text, non_blocking=True); torch.cuda.synchronize(); t_up = time.perf_counter() - t0
+        t0 = time.perf_counter(); d_buf[:T].copy_(h_text, non_blocking=True); torch.cuda.synchronize(); t_up = (time.perf_counter() - t0) * ends
         t0 = time.perf_counter(); h_sam[:got].copy_(d_buf[:got], non_blocking=True); torch.cuda.synchronize(); t_dn = time.perf_counter() - t0
         del d_buf
+        n = ends * n  # reads
+        T = ends * T
         return {"host_text_to_host_sam_Mreads_s": n / dt / 1e6, "reads": n, "seconds": dt, "text_in_GB": T / 1e9, "sam_out_GB": got / 1e9,
                 "pcie_h2d_GBps": T / t_up / 1e9, "pcie_d2h_GBps": got / t_dn / 1e9,
                 "pcie_bound_Mreads_s": n / (t_up + t_dn) / 1e6, "pcie_bound_frac": (t_up + t_dn) / dt,
@@ -636,8 +712,10 @@ def run(args, engine):
 
     # (3) end to end: FASTQ text in host memory -> SAM text in host memory through the overlapped pipeline (never `value`)
     e2e = None
-    if rank == 0 and world == 1 and engine.is_gpu and args.e2e_reads > 0 and not pe and not args.ext_kw and hasattr(engine, "e2e"):
-        e2e = engine.e2e(reads, min(args.e2e_reads, n_reads), L, args.max_subs, lambda *a: log(rank, *a))
+    if rank == 0 and world == 1 and engine.is_gpu and args.e2e_reads > 0 and not args.ext_kw and hasattr(engine, "e2e"):
+        e2e = engine.e2e(reads, min(args.e2e_reads, n_units), L, args.max_subs, lambda *a: log(rank, *a), pe=pe)
+        if args.f2f_reads > 0 and hasattr(engine, "file_to_file"):
+            e2e["file_to_file"] = engine.file_to_file(reads, min(args.f2f_reads, n_units), L, args.max_subs, pe, lambda *a: log(rank, *a))
 
     if rank == 0:
         value = job_value(n_reads, world, args.steps, elapsed)

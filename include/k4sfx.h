@@ -505,6 +505,10 @@ int k4_copy_to_host(k4_index* ix, void* dst, const void* d_src, uint64_t bytes);
 /* pageable or file-mapped host memory -> device memory through pinned pieces filled by several host threads (the way k4_open
  * itself uploads the two big arrays of an .sfx file); for callers that place an index themselves, e.g. libk4comm's rank 0 */
 int k4_upload_pageable(int device, void* d_dst, const void* h_src, uint64_t bytes);
+/* the caller's own host memory (page-aligned address and length, e.g. a mapped file) registered with the HIP runtime in place, so
+ * that the device copies of the *_dev / pipeline entry points run from / into it at the full PCIe rate without a staging copy */
+int k4_host_register(void* p, uint64_t bytes);
+int k4_host_unregister(void* p);
 
 /* kernel timing for roofline measurement: when enabled, every batch brackets the dominant kernel (k4k_align_step, one launch per AlignReads phase) with
  * HIP events on the stream it is launched on; k4_get_kernel_times synchronises, returns the summed duration and the

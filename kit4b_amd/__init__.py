@@ -122,7 +122,7 @@ ABI_SYMBOLS = [
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
     "k4_get_kernel_times", "k4_get_kernel_times_split", "k4_snp_csv_dev", "k4_snp_vcf_dev", "k4_snp_files_dev", "k4_snp_run_dev", "k4_free_host", "k4_format_bam_dev", "k4_format_sam_all_dev", "k4_pipeline_format_bam", "k4_pipeline_format_all", "k4_pipeline_format_bam_all", "k4_format_bam_all_dev", "k4_pipeline_set_trims", "k4_pipeline_set_sampling", "k4_unaligned_fasta_dev", "k4_prepare_reads_trim_dev", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
     "k4_parse_fastx_dev", "k4_prepare_reads_dev", "k4_format_sam_dev", "k4_free_device", "k4_alloc_device",
-    "k4_copy_to_device", "k4_copy_to_host", "k4_upload_pageable", "k4_best_matches_batch", "k4_best_matches_batch_dev",
+    "k4_copy_to_device", "k4_copy_to_host", "k4_upload_pageable", "k4_host_register", "k4_host_unregister", "k4_best_matches_batch", "k4_best_matches_batch_dev",
     "k4_get_sfx_header", "k4_set_description", "k4_select_hits_dev",
     "k4_assign_multi_dev", "k4_align_reads_ext_batch", "k4_align_reads_ext_batch_dev", "k4_kalign_ext_batch",
     "k4_kalign_ext_batch_dev", "k4_auto_trim_flanks_dev", "k4_remove_orphan_juncts_dev", "k4_format_sam_ext_dev",
@@ -218,6 +218,8 @@ def lib():
     L.k4_copy_to_device.argtypes = [vp, vp, vp, u64]
     L.k4_copy_to_host.argtypes = [vp, vp, vp, u64]
     L.k4_upload_pageable.argtypes = [i32, vp, vp, u64]
+    L.k4_host_register.argtypes = [vp, u64]
+    L.k4_host_unregister.argtypes = [vp]
     # (every argument list is declared: ctypes would otherwise pass a Python int -- a device address -- as a 32-bit C int)
     dbl, pvp, pu64 = C.c_double, C.POINTER(vp), C.POINTER(u64)
     fmt_head = [vp, i32, i64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(SamNames)]  # ix .. names of the *_all / *_ext formatters

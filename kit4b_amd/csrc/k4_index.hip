@@ -9,9 +9,11 @@
 #include <strings.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <algorithm>
 #include <mutex>
+#include <atomic>
 #include <thread>
 #include <vector>
 #include "k4_device.h"
@@ -470,8 +472,43 @@ static int mapped_fd(const uint8_t* p, size_t bytes, off_t* off) {
   return -1;
 }
 
+// The pages of a large pageable (or file-mapped) source registered with HIP in place, piece by piece, and copied straight from
+// there: no staging copy through pinned buffers.  Registering costs about as much per byte as one host memcpy, but several
+// pieces register side by side while the DMA engine (57 GB/s from registered pages) drains the ones before: a 15 GB .sfx in
+// tmpfs reaches the device at more than twice the rate of the staged path below, which stays as the fallback (a source
+// HIP refuses to register).  K4_NO_HOSTREG=1 forces the fallback.
+static bool k4i_upload_registered(void* d_dst, const uint8_t* src, size_t bytes) {
+  static const bool off = getenv("K4_NO_HOSTREG") != nullptr;
+  if (off) return false;
+  const size_t piece = (size_t)512 << 20, page = 4096;
+  const size_t n_pieces = (bytes + piece - 1) / piece;
+  const int NT = (int)std::min<size_t>(4, n_pieces);
+  std::atomic<size_t> next(0);
+  std::atomic<int> failed(0), copied(0);
+  auto work = [&]() {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }
+    for (size_t k; !failed && (k = next.fetch_add(1)) < n_pieces;) {
+      const size_t a = k * piece, len = std::min(piece, bytes - a);
+      // whole pages around the piece (the mapping holds them: it starts at the file's first byte and ends on a page boundary)
+      const uintptr_t lo = (uintptr_t)(src + a) & ~(uintptr_t)(page - 1), hi = ((uintptr_t)(src + a + len) + page - 1) & ~(uintptr_t)(page - 1);
+      if (hipHostRegister((void*)lo, (size_t)(hi - lo), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); failed = 1; break; }
+      const bool ok = hipMemcpyAsync((uint8_t*)d_dst + a, src + a, len, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+      (void)hipHostUnregister((void*)lo);
+      if (!ok) { failed = 1; break; }
+      copied++;
+    }
+    (void)hipStreamDestroy(st);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < NT; t++) th.emplace_back(work);
+  for (std::thread& x : th) x.join();
+  return !failed && (size_t)copied.load() == n_pieces;  // (a failure part-way: the staged path writes everything again)
+}
+
 static int k4i_upload_pageable(k4_index* ix, void* d_dst, const uint8_t* src, size_t bytes) {
   const size_t piece = (size_t)128 << 20;
+  if (bytes >= 2 * piece && k4i_upload_registered(d_dst, src, bytes)) return K4_OK;
   off_t file_off = 0;
   const int fd = bytes >= 2 * piece ? mapped_fd(src, bytes, &file_off) : -1;
   if (bytes < 2 * piece) return k4_check_hip(ix, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(index)");
@@ -518,6 +555,10 @@ static int k4i_upload_pageable(k4_index* ix, void* d_dst, const uint8_t* src, si
   return done();
 }
 
+// K4_TRACE=1: where the time of an index load goes, on stderr
+static double k4i_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+static bool k4i_trace() { static const bool on = getenv("K4_TRACE") != nullptr; return on; }
+
 static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void* d_seq_in, const uint8_t* h_sa,
                        void* d_sa_in, int adopt_sa, uint32_t ne, const k4_entry* entries, const char* dataset,
                        int device, int kmer_k, k4_index** out) {
@@ -552,26 +593,46 @@ static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void
   } else {
     if ((rc = k4_check_hip(ix, hipMalloc(&ix->sa, n * el + 16), "hipMalloc(sa)")) != K4_OK) return fail(rc);
     ix->device_bytes += n * el + 16;
+    const double t_a = k4i_now();
     rc = d_sa_in ? k4_check_hip(ix, hipMemcpy(ix->sa, d_sa_in, n * el, hipMemcpyDeviceToDevice), "hipMemcpy(sa)")
                  : k4i_upload_pageable(ix, ix->sa, h_sa, (size_t)(n * el));
     if (rc != K4_OK) return fail(rc);
+    if (k4i_trace()) fprintf(stderr, "[k4 trace] suffix array %.2f GB on the device in %.2fs\n", n * el / 1e9, k4i_now() - t_a);
   }
   // sequence bytes: temporary on the device, only needed to derive the packed form
   uint8_t* d_tmp = nullptr;
   const void* d_seq = d_seq_in;
   if (!d_seq) {
     if ((rc = k4_check_hip(ix, hipMalloc(&d_tmp, n + 64), "hipMalloc(seq)")) != K4_OK) return fail(rc);
-    if ((rc = k4i_upload_pageable(ix, d_tmp, h_seq, (size_t)n)) != K4_OK) {
+    const double t_c = k4i_now();
+    rc = k4i_upload_pageable(ix, d_tmp, h_seq, (size_t)n);
+    if (k4i_trace()) fprintf(stderr, "[k4 trace] sequence %.2f GB on the device in %.2fs\n", n / 1e9, k4i_now() - t_c);
+    if (rc != K4_OK) {
       hipFree(d_tmp);
       return fail(rc);
     }
     d_seq = d_tmp;
   }
+  const double t_b = k4i_now();
   rc = k4i_build_device_structures(ix, d_seq, kmer_k);
+  if (k4i_trace()) { (void)hipDeviceSynchronize(); fprintf(stderr, "[k4 trace] packed reference, exception tables, k-mer table built in %.2fs\n", k4i_now() - t_b); }
   if (d_tmp) hipFree(d_tmp);
   if (rc != K4_OK) return fail(rc);
   *out = ix;
   return K4_OK;
+}
+
+// host memory of the caller made DMA-able in place (page-aligned address and length): what a host program without a HIP runtime of
+// its own needs to let the *_dev / pipeline entry points copy straight from or into a mapped file
+extern "C" int k4_host_register(void* p, uint64_t bytes) {
+  if (!p || !bytes) return K4_ERR_PARAMS;
+  const hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return k4_check_hip(nullptr, e, "hipHostRegister"); }
+  return K4_OK;
+}
+extern "C" int k4_host_unregister(void* p) {
+  if (!p) return K4_ERR_PARAMS;
+  return k4_check_hip(nullptr, hipHostUnregister(p), "hipHostUnregister");
 }
 
 // pageable (or file-mapped) host memory -> device through pinned 128 MB pieces filled by several threads: what k4_open does with

@@ -1049,7 +1049,11 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       fpos += len;
     }
     fseeko(fp, (off_t)fpos, SEEK_SET);
-    k4_pipeline_close(pl);
+    {
+      auto tc0 = now();
+      k4_pipeline_close(pl);
+      if (getenv("K4_TRACE")) fprintf(stderr, "[k4 trace] pipeline closed in %.2fs\n", secs(tc0, now()));
+    }
   } else if (keep_sam) {
     std::vector<char> piece((size_t)std::min<uint64_t>(keep_bytes, 256ull << 20));
     for (uint64_t off = 0; off < keep_bytes; off += piece.size()) {
