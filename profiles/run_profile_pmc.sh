@@ -11,8 +11,8 @@ X="$@"
 O=$R/gpurun_out/prof_$T
 mkdir -p $O
 cd $R
-sha256sum kit4b_amd/csrc/k4_align.hip kit4b_amd/csrc/k4_device.h kit4b_amd/csrc/k4_internal.h kit4b_amd/csrc/k4_ext.h > $O/kernel_src.sha256
-B="python3 bench.py --workload $W --cpu-sample 0 --ref-sample 0 --e2e-reads 0 $X"
+sha256sum kit4b_amd/csrc/k4_align.hip kit4b_amd/csrc/k4_general.hip kit4b_amd/csrc/k4_align_common.h kit4b_amd/csrc/k4_device.h kit4b_amd/csrc/k4_internal.h kit4b_amd/csrc/k4_ext.h > $O/kernel_src.sha256
+B="python3 bench.py --workload $W --cpu-sample 0 --ref-sample 0 --e2e-reads 0 --f2f-reads 0 $X"
 set -x
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B --steps 3 --warmup 1 > $O/bench_trace.json 2> $O/bench_trace.err && \
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_sq -- $B --steps 2 --warmup 0 > $O/bench_pmc_sq.json 2> $O/bench_pmc_sq.err && \

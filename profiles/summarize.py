@@ -19,6 +19,7 @@ import sys
 
 tag = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
+label = sys.argv[3] if len(sys.argv) > 3 else workload  # e.g. c2_c50 for `bench.py --workload c2 --ext c50` (the record's file name)
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -43,7 +44,7 @@ json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 def per_batch(kind, counter):
     tot = 0.0
     for name, cs in out.get(kind, {}).items():
-        if "k4k_align_step" not in name:
+        if "k4k_align_step" not in name and "k4k_align_slow" not in name:  # every alignment kernel of a batch: step + general
             continue
         v = cs[counter]
         # the PMC benches run 2 steps: FIRST variant is dispatched once per batch, the other variant (phases-1) times
@@ -65,7 +66,7 @@ if os.path.exists(shaf):
         v, f = ln.split()
         box[os.path.basename(f)] = v
 same = True
-for f in ("k4_align.hip", "k4_device.h", "k4_internal.h"):
+for f in ("k4_align.hip", "k4_general.hip", "k4_align_common.h", "k4_device.h", "k4_internal.h"):
     data = open(os.path.join("kit4b_amd", "csrc", f), "rb").read()
     h.update(data)
     same &= box.get(f, hashlib.sha256(data).hexdigest()) == hashlib.sha256(data).hexdigest()
@@ -76,14 +77,14 @@ try:
     line = json.loads([l for l in open(os.path.join(src, "bench_trace.json")) if l.startswith("{")][-1])
 except Exception:
     pass
-hbm = {"tag": tag, "workload": workload, "kernel": "k4k_align_step (all phases of one batch)",
+hbm = {"tag": tag, "workload": label, "kernel": "k4k_align_step (all phases of one batch) + k4k_align_slow (the general kernel's passes)",
        "config": line.get("config", {}).get("workload"),
        "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_EA0_RDREQ": rdreq,
        "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
        "kernel_src_sha256": h.hexdigest() if same else None,
-       "kernel_src_note": "sha256 over k4_align.hip + k4_device.h + k4_internal.h (what the step kernels are compiled from); null when the sources profiled on the GPU box "
+       "kernel_src_note": "sha256 over k4_align.hip + k4_general.hip + k4_align_common.h + k4_device.h + k4_internal.h (what the alignment kernels are compiled from); null when the sources profiled on the GPU box "
                           "differ from the working tree at summarise time",
        "head": head + ("+uncommitted" if dirty else ""),
        "note": "read side doubled per MI355X_MICROARCH.md (FETCH_SIZE tallies 64 B per 128-B request on gfx950)"}
-json.dump(hbm, open(os.path.join("profiles", "pmc_hbm_%s.json" % workload), "w"), indent=1)
+json.dump(hbm, open(os.path.join("profiles", "pmc_hbm_%s.json" % label), "w"), indent=1)
 print(json.dumps(hbm, indent=1))
