@@ -36,6 +36,7 @@ enum {
   K4_ERR_FILE_VER = -86,   /* eBSFerrFileVer */
   K4_ERR_FILE_ACCESS = -85,/* eBSFerrFileAccess */
   K4_ERR_ENTRY = -51,      /* eBSFerrEntry */
+  K4_ERR_PARSE = -47,      /* eBSFerrParse */
   K4_ERR_INTERNAL = -1,    /* eBSFerrInternal */
   K4_ERR_NO_DEVICE = -2,   /* (new) no usable gfx950 device / HIP runtime error */
   K4_ERR_UNSUPPORTED = -3  /* (new) feature outside the hot-path scope (bisulfite, colourspace, ...) */
@@ -196,6 +197,12 @@ int k4_info(const k4_index* ix, k4_info_t* out);          /* <- GetNumEntries/Ge
 int k4_get_entry(const k4_index* ix, uint32_t entry_id, k4_entry* out); /* <- GetIdentName/GetSeqLen, SfxArray.h:967-969 */
 int k4_get_ident(const k4_index* ix, const char* name);   /* <- CSfxArray::GetIdent, SfxArray.h:968 */
 int k4_set_max_iter(k4_index* ix, int max_iter);          /* <- CSfxArray::SetMaxIter, SfxArray.h:556 */
+/* k4_set_fastq_quality <- kalign -g<n> (etFQMethod, KAlignerCL.cpp:241,499): how the quality line of a FASTQ record is read --
+ * 0 Sanger (Illumina 1.8+), 1 Illumina 1.3+, 2 Solexa / Illumina before 1.3, 3 ignore (the default).  With 0..2 k4_parse_fastx_dev
+ * (and the pipeline) scale every base's score to 4 bits as LoadRawReads does (KAligner.cpp:12096-12158: phred clamped to 40,
+ * (phred + 2) * 15 / 40) into bits 4..7 of the read byte, and the SAM / BAM writers report it as ReportBAMread does
+ * (KAligner.cpp:6120-6145: '!' + score * 40 / 15, reversed for a Crick alignment, `*` / 0xff when every score is zero). */
+int k4_set_fastq_quality(k4_index* ix, int method);
 int k4_get_seq(const k4_index* ix, uint32_t entry_id, uint32_t loci, uint8_t* out, uint32_t len); /* <- GetSeq, SfxArray.h:996 */
 int k4_write_sfx(const k4_index* ix, const char* sfx_path); /* <- CSfxArray::Finalise/Flush2Disk, SfxArray.cpp:892 */
 int k4_set_description(k4_index* ix, const char* description, const char* title); /* <- SetDescription / SetTitle, SfxArray.h:552-553 */

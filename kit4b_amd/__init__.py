@@ -117,7 +117,7 @@ _lib = None
 # every symbol include/k4sfx.h declares
 ABI_SYMBOLS = [
     "k4_open", "k4_open_host", "k4_open_device", "k4_close", "k4_last_error", "k4_global_error", "k4_info",
-    "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
+    "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_set_fastq_quality", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
     "k4_get_kernel_times", "k4_get_kernel_times_split", "k4_snp_csv_dev", "k4_snp_vcf_dev", "k4_snp_files_dev", "k4_snp_run_dev", "k4_free_host", "k4_format_bam_dev", "k4_format_sam_all_dev", "k4_pipeline_format_bam", "k4_pipeline_format_all", "k4_pipeline_format_bam_all", "k4_format_bam_all_dev", "k4_pipeline_set_trims", "k4_pipeline_set_sampling", "k4_unaligned_fasta_dev", "k4_prepare_reads_trim_dev", "k4_mate_rescue_batch", "k4_kalign_pe_batch", "k4_kalign_pe_batch_dev",
@@ -166,6 +166,7 @@ def lib():
     L.k4_get_entry.argtypes = [vp, u32, C.POINTER(Entry)]
     L.k4_get_ident.argtypes = [vp, C.c_char_p]
     L.k4_set_max_iter.argtypes = [vp, i32]
+    L.k4_set_fastq_quality.argtypes = [vp, i32]
     L.k4_get_seq.argtypes = [vp, u32, u32, vp, u32]
     L.k4_write_sfx.argtypes = [vp, C.c_char_p]
     L.k4_build_sa_device.argtypes = [u64, u32, vp, vp, i32]
@@ -362,6 +363,10 @@ class SfxIndex:
 
     def set_max_iter(self, it):
         return lib().k4_set_max_iter(self.h, it)
+
+    def set_fastq_quality(self, method):
+        """kalign -g: 0 Sanger, 1 Illumina 1.3+, 2 Solexa, 3 ignore the quality lines (default)"""
+        self._ck(lib().k4_set_fastq_quality(self.h, method))
 
     def get_seq(self, entry_id, loci, length):
         out = np.zeros(length, dtype=np.uint8)

@@ -2,6 +2,7 @@
 // the direct-address k-mer table.  Replaces CSfxArray::Open/SetTargBlock/Close and the accessors CKAligner uses
 // (libkit4b/SfxArray.h:524-1023; container layout SfxArray.h:95-123,191-223).
 #include <fcntl.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -789,6 +790,7 @@ extern "C" void k4_close(k4_index* ix) {
                   w.slow_probe, w.slow_hash, w.d_reads, w.d_offs, w.d_lens, w.d_out4, w.d_hits};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  if (ix->d_qlut) hipFree(ix->d_qlut);
   if (w.d_small) hipFree(w.d_small);
   if (w.h_small) hipHostFree(w.h_small);
   for (void* p : {(void*)ix->pe_rr, (void*)ix->pe_hits, (void*)ix->pe_list, (void*)ix->pe_ctl, ix->rs_tasks, ix->rs_reads, ix->rs_res, ix->rs_hits})
@@ -830,6 +832,39 @@ extern "C" int k4_get_ident(const k4_index* ix, const char* name) {  // CSfxArra
   for (const k4_entry& e : ix->entries)
     if (!strcasecmp(e.name, name)) return (int)e.entry_id;
   return K4_ERR_ENTRY;
+}
+
+// quality character -> 4-bit score, exactly as CKAligner::LoadRawReads scales it (KAligner.cpp:12096-12158), the clamps of
+// out-of-range characters included (Solexa's lower clamp is to 64 although its range starts at 59: the reference's)
+extern "C" int k4_set_fastq_quality(k4_index* ix, int method) {
+  if (!ix || method < 0 || method > 3) return K4_ERR_PARAMS;
+  int rc = k4_check_hip(ix, hipSetDevice(ix->device), "hipSetDevice");
+  if (rc != K4_OK) return rc;
+  ix->q_method = method;
+  if (method == 3) return K4_OK;
+  uint8_t lut[256];
+  for (int c = 0; c < 256; c++) {
+    uint8_t q = (uint8_t)c, Qphred = 0;
+    switch (method) {
+      case 0:
+        if (q < 33 || q >= 126) q = q < 33 ? 33 : 125;
+        Qphred = q - 33;
+        break;
+      case 1:
+        if (q < 64 || q >= 126) q = q < 64 ? 64 : 125;
+        Qphred = q - 64;
+        break;
+      default:
+        if (q < 59 || q >= 126) q = q < 64 ? 64 : 125;
+        Qphred = q - 59;
+        Qphred = (uint8_t)(10 * log(1 + pow(10.0, ((double)Qphred / 10.0) / log(10.0))));
+        break;
+    }
+    if (Qphred > 40) Qphred = 40;
+    lut[c] = (uint8_t)((((uint32_t)Qphred + 2) * 15) / 40);
+  }
+  if (!ix->d_qlut && (rc = k4_check_hip(ix, hipMalloc(&ix->d_qlut, 256), "hipMalloc(quality table)")) != K4_OK) return rc;
+  return k4_check_hip(ix, hipMemcpy(ix->d_qlut, lut, 256, hipMemcpyHostToDevice), "hipMemcpy(quality table)");
 }
 
 extern "C" int k4_set_max_iter(k4_index* ix, int max_iter) {  // CSfxArray::SetMaxIter, SfxArray.cpp:1501

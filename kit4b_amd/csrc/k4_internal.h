@@ -104,6 +104,10 @@ struct k4_index {
   uint64_t* ent_end = nullptr;
   uint32_t* ent_id = nullptr;
   uint64_t* counters = nullptr; // device k4_counters
+  // FASTQ qualities (kalign -g, etFQMethod): 3 = ignored (the default); 0 Sanger / 1 Illumina 1.3+ / 2 Solexa: the parser puts the
+  // scaled 4-bit score of every base into bits 4..7 of its read byte (the reference's own in-memory form), the SAM / BAM writers emit it
+  int q_method = 3;
+  uint8_t* d_qlut = nullptr;    // 256 bytes: quality character -> 4-bit score of the chosen method
   double deep_bucket_frac = 0;  // share of the suffixes that sit in k-mer buckets deeper than K4_DEEP_BUCKET (k4_index.hip)
   std::vector<k4_entry> entries;
   std::string dataset;

@@ -175,6 +175,26 @@ __global__ void __launch_bounds__(64) k4k_fastx_encode(const uint8_t* __restrict
   }
 }
 
+// FASTQ qualities (k4_set_fastq_quality 0..2): the 4-bit score of every base into bits 4..7 of its read byte, as LoadRawReads packs
+// them (KAligner.cpp:12096-12163).  Four records per wave, 16 lanes each; a quality line that is not as long as its read is an
+// error there (eBSFerrParse) and here.
+__global__ void __launch_bounds__(64) k4k_fastq_quals(const uint8_t* __restrict__ text, const uint32_t* __restrict__ nl, const uint64_t* __restrict__ offs,
+                                                      const uint32_t* __restrict__ lens, int64_t n_rec, uint8_t* __restrict__ reads,
+                                                      const uint8_t* __restrict__ lut, uint32_t* __restrict__ mismatch) {
+  const int lane = threadIdx.x, grp = lane >> 4, gl = lane & 15;
+  for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < n_rec; r0 += (int64_t)gridDim.x * 4) {
+    const int64_t r = r0 + grp;
+    if (r >= n_rec) continue;
+    const uint32_t qs = nl[4 * r + 2] + 1;
+    uint32_t qe = nl[4 * r + 3];
+    if (qe > qs && text[qe - 1] == '\r') qe--;
+    const uint32_t len = lens[r];
+    if (qe - qs != len) { if (gl == 0) atomicAdd(mismatch, 1u); continue; }
+    uint8_t* dst = reads + offs[r];
+    for (uint32_t q = gl; q < len; q += 16) dst[q] = (uint8_t)((dst[q] & 0x0f) | (lut[text[qs + q]] << 4));
+  }
+}
+
 // Line ends in two passes over 4 KB tiles (256 threads x 16 bytes): newlines per tile, then -- after a scan of the tile
 // counts -- their offsets, in text order (exclusive scan of the per-thread counts inside the block).
 #define K4_NL_TILE 4096
@@ -369,6 +389,16 @@ extern "C" int k4_parse_fastx_dev(k4_index* ix, const void* d_text_v, uint64_t t
     K4_HIP(ix, hipMemsetAsync(tot.p, 0, 16, st));  // bases and longest are counted again, exactly
     exact = true;
   }
+  if (fastq && ix->q_method != 3 && ix->d_qlut) {  // kalign -g0..2: the scores ride in the read bytes
+    K4_HIP(ix, hipMemsetAsync(tot.as<unsigned long long>() + 3, 0, 4, st));
+    hipLaunchKernelGGL(k4k_fastq_quals, dim3((unsigned)std::min<int64_t>((n_rec + 3) / 4, 1 << 16)), dim3(64), 0, st, text, nlb.as<uint32_t>(),
+                       (const uint64_t*)d_offs, (const uint32_t*)d_lens, n_rec, (uint8_t*)d_reads, (const uint8_t*)ix->d_qlut,
+                       reinterpret_cast<uint32_t*>(tot.as<unsigned long long>() + 3));
+    uint32_t mis = 0;
+    K4_HIP(ix, hipMemcpyAsync(&mis, tot.as<unsigned long long>() + 3, 4, hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+    if (mis) return k4_fail(ix, K4_ERR_PARSE, "%u FASTQ records whose quality line is not as long as the read", mis);
+  }
   unsigned long long t[3] = {0, 0, 0};
   K4_HIP(ix, hipMemcpy(t, tot.p, 24, hipMemcpyDeviceToHost));
   info->n_records = (uint64_t)n_rec;
@@ -485,9 +515,19 @@ struct K4SamArgs {
   uint32_t n_entries;
   const int32_t* refid;         // BAM: chromosome id - 1 -> index in the header's reference dictionary
   int all_reads;                // `-M1` (eFMsamAll): the reads that were not accepted are reported too, as unaligned records
+  int quals;                    // kalign -g0..2: bits 4..7 of the read bytes hold 4-bit scores; QUAL is written from them (KAligner.cpp:6120-6145)
 };
 #define K4_SAM_NAME_STRIDE 96
 
+// does read i carry any non-zero score?  (SumScores of ReportBAMread: none -> QUAL `*` / 0xff)
+K4_DEV bool k4d_sam_has_qual(const K4SamArgs& a, int64_t i) {
+  if (!a.quals) return false;
+  const uint8_t* s = a.reads + a.offs[i];
+  const uint32_t len = a.lens[i];
+  uint32_t acc = 0;
+  for (uint32_t q = 0; q < len; q++) acc |= s[q];
+  return (acc & 0xF0u) != 0;
+}
 // A SAM line is addressed by v = read * vm + instance (vm = max_ml for SE, 1 for PE): with MLMode eMLall a read with
 // NumHits instances yields that many lines (CKAligner::WriteHitLoci, KAligner.cpp:6922-6990).
 K4_DEV int k4d_sam_nar(const K4SamArgs& a, int64_t i) { return a.pe ? a.pr[i].nar : a.rr[i].nar; }
@@ -652,7 +692,8 @@ K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t v) {
     const int w = a.pe ? (int)(i & 1) : 0;
     const int64_t rec = a.pe ? (i >> 1) : i;
     return a.name_len[w][rec] + 1 + k4d_udigits(k4d_sam_unaligned_flag(a, i)) + 1 + 2 /* "*\t" */ + 2 /* "0\t" */ + 4 /* "128\t" */ +
-           k4d_udigits(a.lens[i]) + 2 /* "M\t" */ + 2 /* "*\t" */ + 2 + 2 /* "0\t0\t" */ + a.lens[i] + K4_SAM_UNALIGNED_TAIL;
+           k4d_udigits(a.lens[i]) + 2 /* "M\t" */ + 2 /* "*\t" */ + 2 + 2 /* "0\t0\t" */ + a.lens[i] + K4_SAM_UNALIGNED_TAIL +
+           (k4d_sam_has_qual(a, i) ? a.lens[i] - 1 : 0);
   }
   const k4_hit h = k4d_sam_hit(a, v);
   const K4SamFields f = k4d_sam_fields(a, v, h);
@@ -663,7 +704,7 @@ K4_DEV uint32_t k4d_sam_line_len(const K4SamArgs& a, int64_t v) {
                k4d_udigits(f.mapq) + 1 + 1 + 1 /*RNEXT*/ + 1 + k4d_udigits(f.pnext) + 1;
   for (uint32_t q = 0; q < f.n_ops; q++) n += k4d_udigits(f.op_len[q]) + 1;
   n += (f.tlen < 0 ? 1 : 0) + k4d_udigits((uint32_t)(f.tlen < 0 ? -(int64_t)f.tlen : f.tlen)) + 1;
-  n += a.lens[i] + 1 + 1 /* '*' */ + 1 /* '\n' */;
+  n += a.lens[i] + 1 + (k4d_sam_has_qual(a, i) ? a.lens[i] : 1 /* '*' */) + 1 /* '\n' */;
   return n;
 }
 // the same alignment as a BAM record (CSAMfile::AddAlignment's BAM branch, SAMfile.cpp:2379-2640, over ReportBAMread's fields):
@@ -773,7 +814,12 @@ K4_DEV void k4d_bam_put_rec(const K4SamArgs& a, int64_t v, const k4_hit& h, int6
     seq[b] = (char)((hi << 4) | lo);
   }
   const uint32_t q0 = (uint32_t)((uint64_t)len * sub / lpl), q1 = (uint32_t)((uint64_t)len * (sub + 1) / lpl);
-  for (uint32_t q = q0; q < q1; q++) qual[q] = (char)0xFF;
+  if (k4d_sam_has_qual(a, i)) {  // the reference stores the SAM characters themselves in the BAM record (SAMfile.cpp:2468 copies pBAMalign->qual)
+    const uint8_t* rs = a.reads + a.offs[i];
+    const bool rv = !unal && h.strand != '+';
+    for (uint32_t q = q0; q < q1; q++) qual[q] = (char)(33 + (((uint32_t)(rs[rv ? len - 1 - q : q] >> 4) & 0x0f) * 40) / 15);
+  } else
+    for (uint32_t q = q0; q < q1; q++) qual[q] = (char)0xFF;
 }
 
 // QNAME FLAG RNAME POS MAPQ <len>M RNEXT PNEXT TLEN SEQ * (AddAlignment, SAMfile.cpp:2194-2377).  The lines of the sorted
@@ -795,7 +841,8 @@ K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int
                              int lpl) {
   const uint32_t len = a.lens[i];
   const bool unal = k4d_sam_unaligned(a, v);
-  char* seq = line + line_len - (unal ? K4_SAM_UNALIGNED_TAIL : 3) - len;
+  const bool hq = k4d_sam_has_qual(a, i);  // QUAL holds len characters instead of `*`
+  char* seq = line + line_len - (unal ? K4_SAM_UNALIGNED_TAIL : 3) - len - (hq ? len - 1 : 0);
   if (sub == 0 && unal) {
     const int w = a.pe ? (int)(i & 1) : 0;
     const int64_t rec = a.pe ? (i >> 1) : i;
@@ -813,7 +860,10 @@ K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int
     const int nar = k4d_sam_nar(a, i);
     const int code = nar >= 0 && nar < 20 ? nar : 0;
     char* t = seq + len;
-    t[0] = '\t'; t[1] = '*'; t[2] = '\t'; t[3] = '\t'; t[4] = 'Y'; t[5] = 'U'; t[6] = ':'; t[7] = 'Z'; t[8] = ':';
+    t[0] = '\t';
+    if (!hq) t[1] = '*';
+    t += hq ? len - 1 : 0;  // (the scores themselves: below, with the bases)
+    t[2] = '\t'; t[3] = '\t'; t[4] = 'Y'; t[5] = 'U'; t[6] = ':'; t[7] = 'Z'; t[8] = ':';
     t[9] = k4_nar_codes[2 * code]; t[10] = k4_nar_codes[2 * code + 1]; t[11] = '\n';
   } else if (sub == 0) {
     const K4SamFields f = k4d_sam_fields(a, v, h);
@@ -839,7 +889,9 @@ K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int
     if (f.tlen < 0) *p++ = '-';
     p += k4d_put_uint(p, (uint32_t)(f.tlen < 0 ? -(int64_t)f.tlen : f.tlen));
     *p++ = '\t';
-    seq[len] = '\t'; seq[len + 1] = '*'; seq[len + 2] = '\n';
+    seq[len] = '\t';
+    if (!hq) seq[len + 1] = '*';
+    seq[len + 1 + (hq ? len : 1)] = '\n';
   }
   const uint8_t* s = a.reads + a.offs[i];
   const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3);
@@ -847,6 +899,11 @@ K4_DEV void k4d_sam_put_line(const K4SamArgs& a, int64_t v, const k4_hit& h, int
   const uint32_t span = len + sh;
   const uint32_t q0 = (uint32_t)((uint64_t)len * sub / lpl), q1 = (uint32_t)((uint64_t)len * (sub + 1) / lpl);
   const uint64_t fwd = 0x4E4E4E4E54474341ull, rev = 0x4E4E4E4E41434754ull;  // "ACGTNNNN" / "TGCANNNN" by symbol (:6279)
+  if (hq) {  // '!' + score * 40 / 15, in read order -- reversed with the bases of a Crick alignment (KAligner.cpp:6120-6145)
+    char* qv = seq + len + 1;
+    const bool rv = !unal && h.strand != '+';
+    for (uint32_t q = q0; q < q1; q++) qv[q] = (char)(33 + (((uint32_t)(s[rv ? len - 1 - q : q] >> 4) & 0x0f) * 40) / 15);
+  }
   if (unal || h.strand == '+') {
     for (uint32_t q = q0; q < q1; q += 4) {
       const uint32_t d = k4d_read4(s32, sh, span, q);
@@ -1190,6 +1247,7 @@ int k4i_format_records(k4_index* ix, int bam, int sq_all, int pe, int64_t n_unit
   }
   a.cnames = cn.as<char>(); a.cname_len = cl.as<uint8_t>(); a.n_entries = ne;
   a.all_reads = all_reads ? 1 : 0;
+  a.quals = ix->q_method != 3 ? 1 : 0;
 
   Buf stb, chb, cnt, idx0, idx1, k32a, k32b, k64a, k64b, tmp, ll, lo;
   K4_HIP(ix, stb.alloc(22 * 8));

@@ -46,6 +46,7 @@ struct Opts {
   int min_len = 50, max_len = 500;  // cDfltMinAcceptReadLen / cDfltMaxAcceptReadLen, KAligner.h:112-113
   int ml_mode = 0, max_multi = 0;   // -r / -R (etMLMode, KAligner.h:250-258)
   bool clamp = false, best = false; // -X / -N (KAlignerCL.cpp:278-280)
+  int q_method = 3;  // -g (etFQMethod, KAlignerCL.cpp:241,499): 3 = the quality lines are ignored
   int min_chimeric = 0, micro_indel = 0, splice_junct = 0, min_flank_exacts = 0;  // -c / -a / -A / -x (KAlignerCL.cpp:237,245,246,267)
   double batch_mb = 0;              // -b <MB>: stream the input, this much text per file per batch (0: the whole input at once)
   int shard = 0, n_shards = 1;      // -S i/N: this process aligns the i-th of N contiguous slices of the reads (one process per GPU)
@@ -525,7 +526,7 @@ const char* kNarAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM"
 void usage() {
   fprintf(stderr,
           "k4align -i reads.f[aq][.gz] [-i more ...] [-u mates ...] -I index.sfx -o out.sam|out.bam [-z bgzf level=6] [-s subs/100bp=5] [-e 1|2] [-m 0..3] [-n maxNs=1]\n"
-          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-j unaligned.fa] [-J multialigned.fa] [-# every nth read] [-4 all @SQ up to n=10000] [-y trim5] [-Y trim3] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
+          "        [-U 0..4 PE mode] [-d minins=100] [-D maxins=1000] [-E] [-l minlen=50] [-L maxlen=500] [-r 0..5] [-R maxmulti=5] [-X] [-N] [-j unaligned.fa] [-J multialigned.fa] [-# every nth read] [-4 all @SQ up to n=10000] [-y trim5] [-Y trim3] [-Q 0|1|2 strand] [-M 0|1 all reads] [-c minchimeric%%] [-a microindel] [-A splicejunct] [-x flankexacts] [-p minsnpreads [-P qvalue=0.05] [-1 nonref%%=25] [-S snps.csv]] [-S i/N] [-b MB per batch] [-B MB per upload=256] [-t io threads=8] [-Z] [-g 0..3 FASTQ qualities: Sanger | Illumina 1.3+ | Solexa | ignore=3] [-@ gpu=0] [-G gpu,gpu,... one rank per GPU]\n");
 }
 
 }  // namespace
@@ -593,6 +594,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   }
   k4_info_t info;
   k4_info(ix, &info);
+  if (o.q_method != 3) CK(k4_set_fastq_quality(ix, o.q_method));
   // SetMaxIter by sensitivity, KAligner.cpp:373-388
   k4_set_max_iter(ix, o.pmode == 2 ? 20000 : o.pmode == 1 ? 10000 : o.pmode == 0 ? 5000 : 2500);
   int slides = 0;
@@ -1232,7 +1234,8 @@ int main(int argc, char** argv) {
         else o.snp_file = v;
         break;
       }
-      case 'g': o.gpu = atoi(val().c_str()); break;
+      case 'g': o.q_method = atoi(val().c_str()); break;  // kalign's -g: FASTQ quality scoring (0 Sanger, 1 Illumina 1.3+, 2 Solexa, 3 ignore)
+      case '@': o.gpu = atoi(val().c_str()); break;
       case 'G': { std::string v = val(); for (size_t q = 0; q < v.size();) { size_t e = v.find(',', q); if (e == std::string::npos) e = v.size(); o.gpus.push_back(atoi(v.substr(q, e - q).c_str())); q = e + 1; } break; }
       case 'b': o.batch_mb = atof(val().c_str()); break;
       case 'B': o.chunk_mb = std::max(1, atoi(val().c_str())); break;
@@ -1292,6 +1295,7 @@ int main(int argc, char** argv) {
   if (o.min_chimeric != 0 && (o.min_chimeric < 15 || o.min_chimeric > 99)) { fprintf(stderr, "k4align: minimum chimeric length percentage '-c%d' specified outside of range 15..99\n", o.min_chimeric); return 1; }
   if (o.micro_indel < 0 || o.micro_indel > 20) { fprintf(stderr, "k4align: microInDel length maximum '-a%d' specified outside of range 0..20\n", o.micro_indel); return 1; }
   if (o.splice_junct != 0 && (o.splice_junct < 25 || o.splice_junct > 100000)) { fprintf(stderr, "k4align: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000\n", o.splice_junct); return 1; }
+  if (o.q_method < 0 || o.q_method > 3) { fprintf(stderr, "k4align: fastq quality '-g%d' specified outside of range 0..3\n", o.q_method); return 1; }
   if (o.min_flank_exacts < 0 || o.min_flank_exacts > 7) { fprintf(stderr, "k4align: max flank trimming '-x%d' specified outside of range 0..7\n", o.min_flank_exacts); return 1; }
   if (pe && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDel '-a' / splice junction '-A' processing not supported in paired end processing\n"); return 1; }
   if (o.ml_mode == 5 && (o.micro_indel || o.splice_junct)) { fprintf(stderr, "k4align: microInDels / splice junctions not supported when reporting multiloci alignments '-r5'\n"); return 1; }

@@ -570,6 +570,54 @@ def test_k4align_writes_the_reference_bam(golden_dir, tmp_path, case, level):
     assert p.returncode == 3 and "BAM output" in p.stderr
 
 
+@pytest.mark.parametrize("case", ["se_g0", "se_g2_M1", "pe_g1"])
+def test_k4align_reports_fastq_qualities_as_the_reference(golden_dir, tmp_path, case):
+    """`k4align -g0..2` (kalign's FASTQ quality scoring, KAlignerCL.cpp:241): every base's score scaled to 4 bits when the reads are
+    loaded (LoadRawReads, KAligner.cpp:12096-12163: Sanger / Illumina 1.3+ / Solexa, characters outside the encoding clamped),
+    carried in bits 4..7 of the read bytes, and written as QUAL (ReportBAMread :6120-6145: '!' + score * 40 / 15, reversed for a
+    Crick alignment, `*` when every score is zero; the unaligned records of -M1 as well) -- against the SAM and BAM files
+    `ngskit4b kalign -g<n>` wrote from the same FASTQ files (tests/golden/make_golden_qual.py)."""
+    import json
+    import lzma
+    import subprocess
+
+    import samutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(golden_dir, "qual_cases.json")))[case]
+    files = []
+    for e, name in enumerate(meta["reads"]):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        files += ["-u" if e else "-i", dst]
+    out = str(tmp_path / "o.sam")
+    exe = os.path.join(root, "kit4b_amd", "k4align")
+    p = subprocess.run([exe, "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out] + meta["args"] + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    want = [l for l in lzma.open(os.path.join(golden_dir, meta["sam"])).read().decode().splitlines() if not l.startswith("@PG")]
+    assert [l for l in got if l.startswith("@")] == [l for l in want if l.startswith("@")]
+    assert sorted(got) == sorted(want)
+    quals = [l.split("\t")[10] for l in got if not l.startswith("@")]
+    assert sum(q != "*" for q in quals) > len(quals) // 2
+    assert any(q == "*" for q in quals) or case == "se_g2_M1"  # (Solexa's lowest character still scales above zero: no all-zero read there)
+    # without -g the same run writes `*` everywhere (the default -g3)
+    p = subprocess.run([exe, "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out] + [a for a in meta["args"] if not a.startswith("-g")] + files,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and all(l.split("\t")[10] == "*" for l in open(out).read().splitlines() if not l.startswith("@"))
+    if "bam" in meta:
+        bam = str(tmp_path / "o.bam")
+        p = subprocess.run([exe, "-I", os.path.join(golden_dir, "g1.sfx"), "-o", bam] + meta["args"] + files, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        _, refs, recs = samutil.read_bam(bam)
+        _, wrefs, wrecs = samutil.read_bam(os.path.join(golden_dir, meta["bam"]))
+        key = lambda r: (r["ref"], r["pos"], r["name"], r["flag"])  # noqa: E731
+        assert refs == wrefs and sorted(recs, key=key) == sorted(wrecs, key=key)
+    # a value outside 0..3 is turned down as kalign does
+    p = subprocess.run([exe, "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-g4"] + files, capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "-g4" in p.stderr
+
+
 def test_k4align_bam_and_snp_outputs_of_a_run_without_alignments(golden_dir, tmp_path):
     """nothing aligns: the BAM holds header, dictionary and the end-of-file block, the .bai lists empty references, the SNP file its header"""
     import subprocess
