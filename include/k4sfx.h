@@ -170,6 +170,15 @@ typedef struct {
  * k4_close              <- CSfxArray::Close/Reset                    SfxArray.h:527,548
  * kmer_k: 0 = choose from the index size; device: HIP ordinal. */
 int k4_open(const char* sfx_path, int device, int kmer_k, k4_index** out);
+/* k4_open in two halves (the reading of the reads can run beside the index load, as kalign's loader runs beside its aligner threads,
+ * KAligner.cpp:4786-4866): k4_open_async returns once header and entry table are read; k4_info / k4_get_entry / k4_min_core_len /
+ * k4_set_max_iter / k4_set_fastq_quality and a pipeline's ingest side (k4_pipeline_open, acquire / submit) may be used at once, a
+ * library thread uploads the arrays and builds the device structures meanwhile.  k4_open_wait joins it and returns the load's
+ * result; the pipeline waits by itself before its first alignment batch, every other entry point needs k4_open_wait first.
+ * On an error from k4_open_wait the handle is still to be released with k4_close. */
+int k4_open_async(const char* sfx_path, int device, int kmer_k, k4_index** out);
+int k4_open_wait(k4_index* ix);
+double k4_open_seconds(const k4_index* ix);  /* wall seconds the background load took (after k4_open_wait) */
 int k4_open_host(uint64_t concat_len, uint32_t sfx_el_size, const uint8_t* seq, const uint8_t* sa,
                  uint32_t n_entries, const k4_entry* entries, const char* dataset, int device, int kmer_k,
                  k4_index** out);

@@ -116,7 +116,7 @@ _lib = None
 
 # every symbol include/k4sfx.h declares
 ABI_SYMBOLS = [
-    "k4_open", "k4_open_host", "k4_open_device", "k4_close", "k4_last_error", "k4_global_error", "k4_info",
+    "k4_open", "k4_open_async", "k4_open_wait", "k4_open_seconds", "k4_open_host", "k4_open_device", "k4_close", "k4_last_error", "k4_global_error", "k4_info",
     "k4_get_entry", "k4_get_ident", "k4_set_max_iter", "k4_set_fastq_quality", "k4_get_seq", "k4_write_sfx", "k4_build_sa_device",
     "k4_reserve", "k4_align_reads_batch", "k4_align_reads_batch_dev", "k4_kalign_batch", "k4_kalign_batch_dev",
     "k4_min_core_len", "k4_get_counters", "k4_reset_counters", "k4_abi_version", "k4_enable_kernel_timing",
@@ -155,6 +155,10 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
     L.k4_open.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.k4_open_async.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.k4_open_wait.argtypes = [vp]
+    L.k4_open_seconds.argtypes = [vp]
+    L.k4_open_seconds.restype = C.c_double
     L.k4_open_host.argtypes = [u64, u32, vp, vp, u32, C.POINTER(Entry), C.c_char_p, i32, i32, C.POINTER(vp)]
     L.k4_open_device.argtypes = [u64, u32, vp, vp, i32, u32, C.POINTER(Entry), C.c_char_p, i32, i32, C.POINTER(vp)]
     L.k4_close.argtypes = [vp]

@@ -416,7 +416,6 @@ int k4i_build_device_structures(k4_index* ix, const void* d_seq, int kmer_k) {
   ix->d.k = (uint32_t)choose_k(n, kmer_k);
   ix->d.ktab64 = n >= 0xFFFFFFFFull ? 1 : 0;
   if (ix->d.el == 5 && getenv("K4_FORCE_KTAB64")) ix->d.ktab64 = 1;  // test hook: 64-bit table fields on a small index
-  ix->d.max_iter = 50000;  // cDfltMaxIter, libkit4b/SfxArray.h:12
   int rc;
   if (ix->d.el == 4)
     rc = ix->d.ktab64 ? build_ktab<4, uint64_t>(ix) : build_ktab<4, uint32_t>(ix);
@@ -560,9 +559,8 @@ static int k4i_upload_pageable(k4_index* ix, void* d_dst, const uint8_t* src, si
 static double k4i_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 static bool k4i_trace() { static const bool on = getenv("K4_TRACE") != nullptr; return on; }
 
-static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void* d_seq_in, const uint8_t* h_sa,
-                       void* d_sa_in, int adopt_sa, uint32_t ne, const k4_entry* entries, const char* dataset,
-                       int device, int kmer_k, k4_index** out) {
+// the index object with what the file's tables say (entries, lengths): everything k4_info / k4_get_entry / k4_min_core_len answer
+static int open_prepare(uint64_t n, uint32_t el, uint32_t ne, const k4_entry* entries, const char* dataset, int device, k4_index** out) {
   if (!out) return K4_ERR_PARAMS;
   *out = nullptr;
   if (n == 0 || (el != 4 && el != 5) || (el == 4 && n > 0xFFFFFFFFull) || !entries || ne == 0) {
@@ -581,36 +579,45 @@ static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void
   ix->d.el = el;
   ix->entries.assign(entries, entries + ne);
   ix->dataset = dataset ? dataset : "";
-  auto fail = [&](int code) {
-    std::string keep = ix->err;
-    k4_close(ix);
-    k4_set_global_error("%s", keep.c_str());
-    return code;
-  };
+  ix->d.max_iter = 50000;  // cDfltMaxIter, libkit4b/SfxArray.h:12 (set here: k4_set_max_iter may come while the arrays still load)
+  ix->d.n_entries = ne;    // (k4_info answers from here on)
+  ix->tot_seqs_len = 0;
+  for (uint32_t i = 0; i < ne; i++) ix->tot_seqs_len += entries[i].seq_len;
+  *out = ix;
+  return K4_OK;
+}
+// ... and the arrays: suffix array and sequence onto the device, packed reference / exception tables / k-mer table built there
+static int open_load(k4_index* ix, const uint8_t* h_seq, const void* d_seq_in, const uint8_t* h_sa, void* d_sa_in, int adopt_sa, int kmer_k) {
+  const uint64_t n = ix->d.n;
+  const uint32_t el = ix->d.el;
+  int rc = k4_check_hip(ix, hipSetDevice(ix->device), "hipSetDevice");
+  if (rc != K4_OK) return rc;
   // suffix array (padded so the 5-byte reader may touch 8 bytes past the end)
   if (d_sa_in && adopt_sa) {
     ix->sa = (uint8_t*)d_sa_in;
     ix->owns_sa = false;
   } else {
-    if ((rc = k4_check_hip(ix, hipMalloc(&ix->sa, n * el + 16), "hipMalloc(sa)")) != K4_OK) return fail(rc);
+    const double t_m = k4i_now();
+    if ((rc = k4_check_hip(ix, hipMalloc(&ix->sa, n * el + 16), "hipMalloc(sa)")) != K4_OK) return rc;
+    if (k4i_trace()) fprintf(stderr, "[k4 trace] device selected and %.2f GB allocated for the suffix array in %.2fs\n", n * el / 1e9, k4i_now() - t_m);
     ix->device_bytes += n * el + 16;
     const double t_a = k4i_now();
     rc = d_sa_in ? k4_check_hip(ix, hipMemcpy(ix->sa, d_sa_in, n * el, hipMemcpyDeviceToDevice), "hipMemcpy(sa)")
                  : k4i_upload_pageable(ix, ix->sa, h_sa, (size_t)(n * el));
-    if (rc != K4_OK) return fail(rc);
+    if (rc != K4_OK) return rc;
     if (k4i_trace()) fprintf(stderr, "[k4 trace] suffix array %.2f GB on the device in %.2fs\n", n * el / 1e9, k4i_now() - t_a);
   }
   // sequence bytes: temporary on the device, only needed to derive the packed form
   uint8_t* d_tmp = nullptr;
   const void* d_seq = d_seq_in;
   if (!d_seq) {
-    if ((rc = k4_check_hip(ix, hipMalloc(&d_tmp, n + 64), "hipMalloc(seq)")) != K4_OK) return fail(rc);
+    if ((rc = k4_check_hip(ix, hipMalloc(&d_tmp, n + 64), "hipMalloc(seq)")) != K4_OK) return rc;
     const double t_c = k4i_now();
     rc = k4i_upload_pageable(ix, d_tmp, h_seq, (size_t)n);
     if (k4i_trace()) fprintf(stderr, "[k4 trace] sequence %.2f GB on the device in %.2fs\n", n / 1e9, k4i_now() - t_c);
     if (rc != K4_OK) {
       hipFree(d_tmp);
-      return fail(rc);
+      return rc;
     }
     d_seq = d_tmp;
   }
@@ -618,7 +625,23 @@ static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void
   rc = k4i_build_device_structures(ix, d_seq, kmer_k);
   if (k4i_trace()) { (void)hipDeviceSynchronize(); fprintf(stderr, "[k4 trace] packed reference, exception tables, k-mer table built in %.2fs\n", k4i_now() - t_b); }
   if (d_tmp) hipFree(d_tmp);
-  if (rc != K4_OK) return fail(rc);
+  return rc;
+}
+static int open_common(uint64_t n, uint32_t el, const uint8_t* h_seq, const void* d_seq_in, const uint8_t* h_sa,
+                       void* d_sa_in, int adopt_sa, uint32_t ne, const k4_entry* entries, const char* dataset,
+                       int device, int kmer_k, k4_index** out) {
+  k4_index* ix = nullptr;
+  int rc = open_prepare(n, el, ne, entries, dataset, device, &ix);
+  if (rc != K4_OK) return rc;
+  rc = open_load(ix, h_seq, d_seq_in, h_sa, d_sa_in, adopt_sa, kmer_k);
+  if (rc != K4_OK) {
+    const std::string keep = ix->err;
+    if (d_sa_in && adopt_sa) { ix->sa = nullptr; ix->owns_sa = true; }  // (the caller keeps what it handed in)
+    k4_close(ix);
+    k4_set_global_error("%s", keep.c_str());
+    *out = nullptr;
+    return rc;
+  }
   *out = ix;
   return K4_OK;
 }
@@ -762,15 +785,51 @@ extern "C" void k4_sfx_unmap(k4_sfx_file* o) {
   memset(o, 0, sizeof(*o));
 }
 
-extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out) {
+// k4_open in two halves: k4_open_async returns once the file's header and entry table are read -- k4_info, k4_get_entry,
+// k4_min_core_len, k4_set_max_iter, k4_set_fastq_quality and the ingest side of a pipeline (open, acquire / submit: upload,
+// parse, length filter) work from then on -- while a thread of the library uploads the two big arrays and builds the device
+// structures; k4_open_wait joins it (every alignment entry point of the pipeline does so itself before its first batch).  A
+// program's reading of its reads thereby runs beside the index load (kalign overlaps its loader and its aligner threads
+// likewise, KAligner.cpp:4786-4866).
+extern "C" int k4_open_async(const char* path, int device, int kmer_k, k4_index** out) {
   if (!out) return K4_ERR_PARAMS;
   *out = nullptr;
-  k4_sfx_file m;
-  int rc = k4_sfx_map(path, &m);
+  k4_sfx_file* m = new k4_sfx_file;
+  int rc = k4_sfx_map(path, m);
+  if (rc != K4_OK) { delete m; return rc; }
+  k4_index* ix = nullptr;
+  rc = open_prepare(m->concat_len, m->sfx_el_size, m->n_entries, m->entries, m->dataset, device, &ix);
+  if (rc != K4_OK) { k4_sfx_unmap(m); delete m; return rc; }
+  ix->raw_header.assign(m->header, m->header + 1224);
+  ix->load_rc = K4_OK;
+  ix->loader = std::thread([ix, m, kmer_k] {
+    const double t0 = k4i_now();
+    ix->load_rc = open_load(ix, m->seq, nullptr, m->sa, nullptr, 0, kmer_k);
+    ix->load_seconds = k4i_now() - t0;
+    k4_sfx_unmap(m);
+    delete m;
+  });
+  *out = ix;
+  return K4_OK;
+}
+extern "C" int k4_open_wait(k4_index* ix) {
+  if (!ix) return K4_ERR_PARAMS;
+  if (ix->loader.joinable()) ix->loader.join();
+  if (ix->load_rc != K4_OK) k4_set_global_error("%s", ix->err.c_str());
+  return ix->load_rc;
+}
+extern "C" double k4_open_seconds(const k4_index* ix) { return ix ? ix->load_seconds : 0.0; }
+extern "C" int k4_open(const char* path, int device, int kmer_k, k4_index** out) {
+  if (!out) return K4_ERR_PARAMS;
+  int rc = k4_open_async(path, device, kmer_k, out);
   if (rc != K4_OK) return rc;
-  rc = k4_open_host(m.concat_len, m.sfx_el_size, m.seq, m.sa, m.n_entries, m.entries, m.dataset, device, kmer_k, out);
-  if (rc == K4_OK && *out) (*out)->raw_header.assign(m.header, m.header + 1224);
-  k4_sfx_unmap(&m);
+  rc = k4_open_wait(*out);
+  if (rc != K4_OK) {
+    const std::string keep = (*out)->err;
+    k4_close(*out);
+    *out = nullptr;
+    k4_set_global_error("%s", keep.c_str());
+  }
   return rc;
 }
 
@@ -783,6 +842,7 @@ extern "C" int k4_set_raw_header(k4_index* ix, const void* hdr_1224) {
 
 extern "C" void k4_close(k4_index* ix) {
   if (!ix) return;
+  if (ix->loader.joinable()) ix->loader.join();
   hipSetDevice(ix->device);
   K4Workspace& w = ix->ws;
   void* ptrs[] = {ix->ref2_alloc, ix->excbm, ix->excsup, ix->excblk, ix->excnib, ix->owns_sa ? ix->sa : nullptr, ix->ktab,

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/k4sfx.h"
 
@@ -127,6 +128,10 @@ struct k4_index {
   // staging of k4_mate_rescue_batch (grow-only)
   void *rs_tasks = nullptr, *rs_reads = nullptr, *rs_res = nullptr, *rs_hits = nullptr;
   size_t rs_cap_tasks = 0, rs_cap_reads = 0;
+  // k4_open_async: the arrays are uploaded and the device structures built by this thread; k4_open_wait joins it
+  std::thread loader;
+  int load_rc = 0;
+  double load_seconds = 0;  // what that thread took
   hipStream_t stream = nullptr; // internal stream for the host-pointer entry points
   bool timing = false;          // bracket k4k_align_fast with events
   std::vector<hipEvent_t> ev0, ev1, ev2;  // before the step kernels, behind them, behind the general kernel's passes

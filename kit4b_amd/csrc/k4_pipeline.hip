@@ -182,6 +182,7 @@ int align_more(k4_pipeline* pl, bool flush) {
   const int64_t r0 = pe ? 2 * pl->units_done : pl->units_done, nr = pe ? 2 * n : n;
   const int max_ml = std::max(pl->prm.kp.max_ml, 1);
   int rc;
+  if ((rc = k4_open_wait(ix)) != K4_OK) return rc;  // (an index opened with k4_open_async: its arrays are needed from here on)
   // reads the whole input will hold, projected from the records of its first end so far (0: unknown) -- see parse_more
   const End& E0 = pl->end[0];
   const uint64_t expect0 = pl->prm.expect_text_bytes[0];

@@ -589,7 +589,8 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     if (rc != K4_OK) { fprintf(stderr, "k4align: rank %d: index broadcast failed: %s (%d)\n", o.rank, k4_comm_last_error(comm), rc); sh->failed = 1; return 2; }
     if (fault_rank == o.rank && strcmp(fault_stage, "index") == 0) { fprintf(stderr, "k4align: rank %d: injected fault behind the index broadcast\n", o.rank); return 3; }
   } else {
-    rc = k4_open(o.sfx.c_str(), o.gpu, 0, &ix);
+    // (the arrays load on a thread of the library while the reads are read: k4_open_wait below, or the pipeline's own)
+    rc = k4_open_async(o.sfx.c_str(), o.gpu, 0, &ix);
     if (rc != K4_OK) { fprintf(stderr, "k4align: unable to load '%s': %s (%d)\n", o.sfx.c_str(), k4_global_error(), rc); return 2; }
   }
   k4_info_t info;
@@ -777,6 +778,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   const bool pipelined = o.batch_mb <= 0 && o.n_shards == 1 && !o.legacy;
   // "-o x.bam": BGZF compressed BAM, any other extension SAM (KAlignerCL.cpp:857-866)
   const bool bam_out = o.out.size() >= 4 && strcasecmp(o.out.c_str() + o.out.size() - 4, ".bam") == 0;
+  if (!pipelined && !multi && (rc = k4_open_wait(ix)) != K4_OK) { fprintf(stderr, "k4align: unable to load '%s': %s (%d)\n", o.sfx.c_str(), k4_global_error(), rc); return 2; }
   if (bam_out && (!pipelined || multi)) { fprintf(stderr, "k4align: BAM output is written by the pipelined single-GPU mode (not with -b, -S, -G, -Z)\n"); return 3; }
   if (pipelined) {
     for (const std::vector<std::string>* fs : {&o.in1, &o.in2})
@@ -1002,7 +1004,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     if (chatty)
       fprintf(stderr, "k4align: %llu alignments reported to %s (%llu bytes) + .bai; index %.2fs, reads %.2fs, device side behind the reads %.2fs, "
                       "global stages + sort + records %.2fs, deflate + write %.2fs\n", (unsigned long long)bw.n_records(), o.out.c_str(),
-              (unsigned long long)bw.compressed_bytes() + 28, secs(t0, t_open), s_read, s_parse, s_align, s_write_bam);
+              (unsigned long long)bw.compressed_bytes() + 28, std::max(secs(t0, t_open), k4_open_seconds(ix)), s_read, s_parse, s_align, s_write_bam);
     k4_close(ix);
     return 0;
   }
@@ -1105,7 +1107,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   s_write += secs(tw, now());
   fprintf(stderr, "k4align: %s%llu alignments written to %s (%zu batch%s); index %.2fs, read files %.2fs, upload+parse %.2fs, align+format %.2fs, write %.2fs\n",
           multi ? ("rank " + std::to_string(o.rank) + ": ").c_str() : "", (unsigned long long)my_lines, o.out.c_str(),
-          parts.empty() ? (size_t)1 : parts.size(), parts.size() > 1 ? "es" : "", secs(t0, t_open), s_read, s_parse, s_align, s_write);
+          parts.empty() ? (size_t)1 : parts.size(), parts.size() > 1 ? "es" : "", std::max(secs(t0, t_open), k4_open_seconds(ix)), s_read, s_parse, s_align, s_write);
   if (comm) { k4_comm_barrier(comm); }
   k4_close(ix);
   if (comm) k4_comm_close(comm);

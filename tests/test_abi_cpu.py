@@ -20,7 +20,7 @@ def L():
 
 def test_header_symbols_all_exported(L):
     hdr = open(os.path.join(ROOT, "include", "k4sfx.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(k4_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|double|const char\*)\s+(k4_\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(kit4b_amd.ABI_SYMBOLS), declared ^ set(kit4b_amd.ABI_SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s

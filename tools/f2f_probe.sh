@@ -10,7 +10,7 @@ seq = bench.make_genome(dev, n_chrom, chrom_len)
 eng.build_index(seq, n_chrom, chrom_len, 0, lambda *a: print(*a, file=sys.stderr))
 reads, _ = bench.make_reads(seq, n_chrom, chrom_len, 50_000_000, L, bench.READS_SEED, dev)
 res = {}
-for tag, env in (("registered", {"K4_TRACE": "1"}),):
+for tag, env in (("overlapped", {"K4_TRACE": "1"}),):
     os.environ.pop("K4_NO_HOSTREG", None); os.environ.update(env)
     res[tag] = eng.file_to_file(reads, 50_000_000, L, 2, False, lambda *a: print(*a, file=sys.stderr))
 print(json.dumps(res))
