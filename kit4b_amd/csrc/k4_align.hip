@@ -185,7 +185,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           uint64_t sub;
           k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j], sub);
           if (CAPTURE && defer_deep && tshift == 0 && (uint64_t)(lb1[j] - lb0[j]) > K4_DEFER_BUCKET) return K4_DEFER;
-          if (a.deep_general && tshift == 0 && (uint64_t)(lb1[j] - lb0[j]) > K4_DEFER_BUCKET) return K4_NEED_SLOW;
+          if (a.deep_general && (!CAPTURE || a.deep_general == 1) && tshift == 0 && (uint64_t)(lb1[j] - lb0[j]) > K4_DEFER_BUCKET) return K4_NEED_SLOW;
           if (sizeof(KT) == 8 && tshift == 0 && cl >= kk + 2 && sub != K4_KTAB64_IRREGULAR) {
             // straight to the suffixes that continue with the core's next two bases
             uint32_t before, count;
@@ -712,8 +712,8 @@ static int launch_steps(k4_index* ix, K4AlignArgs& a, int n_steps, hipStream_t s
   // -- on an index with repeat families (share of the suffixes in deep k-mer buckets, measured when the table was built);
   // elsewhere one launch without the code for it, which costs the first phase 4 % in registers (C2: 2335 -> 2254 M reads/s)
   static const int deep_mode = getenv("K4_DEEP_TO_GENERAL") ? atoi(getenv("K4_DEEP_TO_GENERAL")) : 0;  // (experiment)
-  a.deep_general = (deep_mode && ix->deep_bucket_frac >= K4_DEFER_MIN_FRAC) ? 1 : 0;
-  if (ix->deep_bucket_frac >= K4_DEFER_MIN_FRAC && !a.deep_general) {
+  a.deep_general = (deep_mode && ix->deep_bucket_frac >= K4_DEFER_MIN_FRAC) ? deep_mode : 0;  // 1: from the first phase on, 2: from the second
+  if (ix->deep_bucket_frac >= K4_DEFER_MIN_FRAC && a.deep_general != 1) {
     a.defer_ids = w.ids[1];
     hipLaunchKernelGGL((k4k_align_step<EL, NCH, true, KT, true>), dim3(grid0), dim3(K4_BS(NCH)), lds, st, a, 0, (const uint32_t*)nullptr,
                        (const uint64_t*)nullptr, (const uint32_t*)nullptr, w.ids[0], w.rows[0], w.ctl + 2);
