@@ -599,6 +599,10 @@ extern "C" void k4_pipeline_close(k4_pipeline* pl) {
   pl->sam_buf.st = pl->s_comp;  // (everything is idle: hipDeviceSynchronize above)
   pl->sam_buf.release();
   for (hipStream_t s : {pl->s_in, pl->s_comp, pl->s_out}) if (s) hipStreamDestroy(s);
-  k4_pool_trim_to(32ull << 30);  // what a run of a few ten million reads needs stays cached for the next one; more goes back
+  // what a run of a few ten million reads (or pairs) needs stays cached for the next one -- up to a quarter of the device's
+  // memory, 32 GB at least; more goes back (freeing and allocating tens of gigabytes anew costs a second per run)
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  k4_pool_trim_to(std::max<size_t>(32ull << 30, total_b / 4));
   delete pl;
 }

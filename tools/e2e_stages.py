@@ -23,47 +23,53 @@ def main():
     ap.add_argument("--chrom-mbp", type=float, default=125.0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--chunk-mb", type=str, default="0", help="comma list of upload chunk sizes (MB; 0 = the default)")
+    ap.add_argument("--pe", action="store_true", help="2 x 150 bp pairs (C3-shaped: -U2 -d200 -D600) instead of 100 bp single reads")
     a = ap.parse_args()
     eng = bench.GpuEngine()
     dev = eng.device(0)
     chrom_len = int(a.chrom_mbp * 1e6)
     seq = bench.make_genome(dev, a.chroms, chrom_len)
     eng.build_index(seq, a.chroms, chrom_len, 0, lambda *x: print("[e2e]", *x, file=sys.stderr))
-    L_ = 100
-    reads, _ = bench.make_reads(seq, a.chroms, chrom_len, a.reads, L_, 4321, dev)
-    n = a.reads
+    pe = a.pe
+    L_ = 150 if pe else 100
+    if pe:
+        reads, _ = bench.make_pe_reads(seq, a.chroms, chrom_len, a.reads // 2, L_, 4321, dev)
+    else:
+        reads, _ = bench.make_reads(seq, a.chroms, chrom_len, a.reads, L_, 4321, dev)
+    ends = 2 if pe else 1
+    n = a.reads // ends
     W = 12 + L_ + 3 + L_ + 1
-    text = torch.empty((n, W), dtype=torch.uint8, device=dev)
-    text[:, 0] = ord("@"); text[:, 1] = ord("r")
-    idx = torch.arange(n, device=dev)
-    for d in range(9):
-        text[:, 2 + d] = ((idx // (10 ** (8 - d))) % 10 + 48).to(torch.uint8)
-    text[:, 11] = 10
-    lut = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)
-    text[:, 12:12 + L_] = lut[reads.long().clamp_(max=4)]
-    text[:, 12 + L_] = 10; text[:, 13 + L_] = ord("+"); text[:, 14 + L_] = 10
-    text[:, 15 + L_:15 + 2 * L_] = ord("I")
-    text[:, W - 1] = 10
     T = n * W
-    h_text = torch.empty(T, dtype=torch.uint8, pin_memory=True)
-    h_text.copy_(text.reshape(-1))
-    h_sam = torch.empty(n * (L_ + 80), dtype=torch.uint8, pin_memory=True)
-    del text, idx, reads
+    h_texts = []
+    for e in range(ends):
+        text = eng.fastq_text(reads[e:ends * n:ends] if pe else reads[:n], 0, n, L_, dev)
+        h = torch.empty(T, dtype=torch.uint8, pin_memory=True)
+        h.copy_(text.reshape(-1))
+        h_texts.append(h)
+        del text
+    h_text = h_texts[0]
+    h_sam = torch.empty(ends * n * (L_ + 90), dtype=torch.uint8, pin_memory=True)
+    del reads
     torch.cuda.synchronize()
     lib = k4.lib()
-    kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 1, 0, 0, 0)
+    kp = k4.KalignParams(2, 1, 1, 0, k4.STRAND_BOTH, 10 if pe else 1, 1 if pe else 0, 0, 0)
     runs = []
     for chunk_mb in [int(x) for x in a.chunk_mb.split(',')]:
       for rep in range(a.reps):
           prm = k4.PipelineParams()
-          prm.paired = 0
+          prm.paired = 1 if pe else 0
           prm.kp = kp
+          if pe:
+              prm.pe = k4.PeParams(2, 200, 600, 0)
+              prm.expect_text_bytes[1] = T
           prm.min_len, prm.max_len, prm.chunk_bytes = 50, 500, chunk_mb << 20
           prm.expect_text_bytes[0] = T
           pl = C.c_void_p()
           t = [time.perf_counter()]
           eng.ix._ck(lib.k4_pipeline_open(eng.ix.h, C.byref(prm), C.byref(pl))); t.append(time.perf_counter())
-          eng.ix._ck(lib.k4_pipeline_submit_host(pl, 0, h_text.data_ptr(), T, 1)); t.append(time.perf_counter())
+          for e in range(ends):
+              eng.ix._ck(lib.k4_pipeline_submit_host(pl, e, h_texts[e].data_ptr(), T, 1))
+          t.append(time.perf_counter())
           view = k4.PipelineView()
           eng.ix._ck(lib.k4_pipeline_wait_aligned(pl, C.byref(view))); t.append(time.perf_counter())
           stats, nbytes = k4.SamStats(), C.c_uint64()
