@@ -839,7 +839,7 @@ def cpu_baseline(args, engine, seq, reads, out, hits, out_pe, n, el, n_chrom, ch
     log(rank, "index copied to the host for the CPU baseline in %.1fs" % (time.time() - t0))
     # the GPU box gives one GPU a 16-core CPU share (os.cpu_count() reports the whole host)
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
-    l_all = np.full(min(args.cpu_sample, n_reads), L, dtype=np.uint32)
+    l_all = np.full(max(min(args.cpu_sample, n_reads), min(50_000, n_reads)), L, dtype=np.uint32)  # (the pilot takes 50k whatever the bound)
 
     def run_cpu(a, b):  # reads [a, b) (PE: a and b even, i.e. whole pairs)
         if pe:

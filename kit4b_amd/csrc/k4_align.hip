@@ -798,7 +798,7 @@ static int run_dev(k4_index* ix, K4AlignArgs& a, int max_len, void* stream) {
     tot_mm = std::min(tot_mm, 63);
   }
   const int n_steps = tot_mm + 1;
-  if (ix->d.el == 4) return launch_all<4, uint32_t>(ix, a, max_len, n_steps, st);
+  if (ix->d.el == 4) return ix->d.ktab64 ? launch_all<4, uint64_t>(ix, a, max_len, n_steps, st) : launch_all<4, uint32_t>(ix, a, max_len, n_steps, st);
   return ix->d.ktab64 ? launch_all<5, uint64_t>(ix, a, max_len, n_steps, st) : launch_all<5, uint32_t>(ix, a, max_len, n_steps, st);
 }
 

@@ -34,11 +34,14 @@ def check_against(res, exp, max_hits, what=""):
         assert not res["hits"][i, nh:].view(np.uint8).any(), (what, i, "stale hit slots")
 
 
+@pytest.mark.parametrize("table", ["16-byte entries (default)", "12-byte entries"])
 @pytest.mark.parametrize("kmer_k", [0, 5, 11])
 @pytest.mark.parametrize("case", CASES)
-def test_golden_vectors_from_reference(k4, golden_dir, g1_el5_path, case, kmer_k):
+def test_golden_vectors_from_reference(k4, golden_dir, g1_el5_path, monkeypatch, case, kmer_k, table):
     if kmer_k and case not in ("c2_s2", "c3_pe150_el5", "maxiter3", "short60"):
         pytest.skip("k sweep on a subset")
+    if table.startswith("12"):  # the {lb, pos0, sig} form a device short of memory falls back to (k4_index.hip: open_common)
+        monkeypatch.setenv("K4_FORCE_KTAB64", "0")
     g = np.load(os.path.join(golden_dir, "align_%s.npz" % case))
     tm, cl, cd, sl, mcl, md, strand, mh, maxiter = [int(x) for x in g["params"]]
     ix = k4.SfxIndex.open(g1_el5_path if case.endswith("_el5") else os.path.join(golden_dir, "g1.sfx"), kmer_k=kmer_k)
@@ -765,14 +768,17 @@ def test_c5_scale_15gbp_se_and_pe_truth(k4):
         ix.close()
 
 
+@pytest.mark.parametrize("layout", ["el5_kt64", "el5_kt32", "el4_kt32"])
 @pytest.mark.parametrize("case", ["se_s2", "pe_u1", "se_r5_R8_N", "se_r5_R6_X", "pe_c50_u1", "pe_c60_u3_wide"])
-def test_reference_sam_on_5byte_index_with_64bit_table(k4, golden_dir, g1_el5_path, monkeypatch, case):
-    """The same golden SAMs through the layouts a >= 2^32-symbol block uses: 5-byte suffix elements and (forced) 64-bit
-    k-mer table fields -- the EL=5 / 64-bit instantiations of the step, general, pairing and rescue kernels."""
-    monkeypatch.setenv("K4_FORCE_KTAB64", "1")
+def test_reference_sam_on_5byte_index_with_64bit_table(k4, golden_dir, g1_el5_path, monkeypatch, case, layout):
+    """The same golden SAMs through the other index layouts: 5-byte suffix elements with 16-byte table entries (what a
+    >= 2^32-symbol block uses) and the 12-byte table entries of a device short of memory, with either element size -- every
+    (EL, table) instantiation of the step, general, pairing and rescue kernels (4-byte elements with 16-byte entries is
+    the default every other test runs)."""
+    monkeypatch.setenv("K4_FORCE_KTAB64", "1" if layout.endswith("kt64") else "0")
     kw, pe = _kalign_args(SAM_CASES[case]["args"])
-    ix = k4.SfxIndex.open(g1_el5_path)
-    assert ix.info()["sfx_el_size"] == 5
+    ix = k4.SfxIndex.open(g1_el5_path if layout.startswith("el5") else os.path.join(golden_dir, "g1.sfx"))
+    assert ix.info()["sfx_el_size"] == (5 if layout.startswith("el5") else 4)
     ix.set_max_iter(5000)
     _, recs = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
     if case.startswith("se_"):
