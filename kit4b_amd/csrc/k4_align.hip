@@ -19,6 +19,7 @@
 //   k4k_align_slow   ... the general kernel: a literal lane-per-read restatement over exact 4-bit symbols with a
 //                    hash-set dedupe in HBM scratch.
 #include <stdlib.h>
+#include <type_traits>
 #include "k4_align_common.h"
 
 // ==== fast kernel ==================================================================================================
@@ -133,6 +134,10 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
   const int64_t n = (int64_t)ix.n;
   const int kk = min((int)ix.k, cl);
   const int tshift = 2 * ((int)ix.k - kk);
+  // what a lane keeps of a table entry: with 4-byte suffix elements (fewer than 2^32 - 1 symbols) 32 bits hold lb and pos0 whatever
+  // the entry's own width -- the 16-byte entries in 64-bit registers cost the 100 bp kernel 40 spilled registers more
+  typedef typename std::conditional<EL == 4, uint32_t, KT>::type RT;
+  constexpr uint64_t NOPOS = sizeof(RT) == 4 ? 0xFFFFFFFFull : K4_KTAB64_MASK;  // pos0 not usable (it is the whole bucket's first suffix)
   int s = rp.strand == K4_STRAND_CRICK ? 1 : 0;
   const int s_end = rp.strand == K4_STRAND_WATSON ? 0 : 1;
   bool stop = false;
@@ -149,7 +154,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       // the next K4_PF cores are fetched together before any of them is searched: one memory round trip, not K4_PF.
       constexpr int PFN = NCH == 5 ? K4_PF5 : K4_PF;
       int oo[PFN];
-      KT lb0[PFN], ps0[PFN], lb1[PFN];
+      RT lb0[PFN], ps0[PFN], lb1[PFN];
       uint32_t sig[PFN];
       int cnt = 0;
 #pragma unroll
@@ -176,23 +181,27 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
             const int kind = (int)(mv >> 62), fm = (int)((mv >> 48) & 0x3FFF), mmv = (int)((mv >> 40) & 0xFF);
             if (kind == 1 || (kind == 2 && fm < cl)) continue;                   // nothing starts with this core
             if (kind == 2 && mmv != 0xFF) {                                      // exactly the suffix at pos does
-              lb0[0] = 0; lb1[0] = 1; ps0[0] = (KT)(mv & 0xFFFFFFFFFFull);
+              lb0[0] = 0; lb1[0] = 1; ps0[0] = (RT)(mv & 0xFFFFFFFFFFull);
               memo_hit = true; memo_mm = mmv;
               continue;
             }
           }
           const uint64_t code = ln.chunk_at(s, oo[j]) >> (64 - 2 * kk);
           uint64_t sub;
-          k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, lb0[j], ps0[j], sig[j], lb1[j], sub);
+          {
+            KT e_lb0, e_ps0, e_lb1;
+            k4d_ktab_fetch<KT>(ix, code << tshift, (code + 1) << tshift, e_lb0, e_ps0, sig[j], e_lb1, sub);
+            lb0[j] = (RT)e_lb0; ps0[j] = (RT)e_ps0; lb1[j] = (RT)e_lb1;
+          }
           if (CAPTURE && defer_deep && tshift == 0 && (uint64_t)(lb1[j] - lb0[j]) > K4_DEFER_BUCKET) return K4_DEFER;
           if (a.deep_general && (!CAPTURE || a.deep_general == 1) && tshift == 0 && (uint64_t)(lb1[j] - lb0[j]) > K4_DEFER_BUCKET) return K4_NEED_SLOW;
           if (sizeof(KT) == 8 && tshift == 0 && cl >= kk + 2 && sub != K4_KTAB64_IRREGULAR) {
             // straight to the suffixes that continue with the core's next two bases
             uint32_t before, count;
             k4d_ktab_sub(sub, (uint32_t)(ln.chunk_at(s, oo[j] + kk) >> 60), before, count);
-            if (before) ps0[j] = (KT)K4_KTAB64_MASK;  // pos0 is the whole bucket's first suffix, not this one's
-            lb0[j] += (KT)before;
-            lb1[j] = lb0[j] + (KT)count;
+            if (before) ps0[j] = (RT)NOPOS;  // pos0 is the whole bucket's first suffix, not this one's
+            lb0[j] += (RT)before;
+            lb1[j] = lb0[j] + (RT)count;
           }
           if (CAPTURE && j == 0 && first_group && tshift == 0) {
             if (lb1[0] == lb0[0]) ln.memo[s * K4_BS(NCH)] = k4d_memo_pack(1, 0, 0, 0);
@@ -218,7 +227,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
       uint32_t touch = 0;
 #pragma unroll
       for (int j = 0; j < PFN; j++)
-        if (j < cnt && tshift == 0 && lb1[j] > lb0[j] && !(j == 0 && memo_hit) && (sizeof(KT) == 4 || (uint64_t)ps0[j] != K4_KTAB64_MASK))
+        if (j < cnt && tshift == 0 && lb1[j] > lb0[j] && !(j == 0 && memo_hit) && (sizeof(KT) == 4 || (uint64_t)ps0[j] != NOPOS))
           touch |= ix.ref2[((int64_t)ps0[j] - oo[j]) >> 4];
 
 #pragma unroll
@@ -237,7 +246,7 @@ K4_DEV int k4d_lcm_fast(const K4AlignArgs& a, const K4Lane<NCH>& ln, int len, in
           const int64_t mid = (lo + hi) >> 1;
           // pos0 belongs to the bucket of the exact k-mer: with a core shorter than k the interval spans several
           // buckets and the first of them may be empty (pos0 unset), so the suffix array is read instead
-          const uint64_t p = (tshift == 0 && mid == (int64_t)lb0[j] && (sizeof(KT) == 4 || (uint64_t)ps0[j] != K4_KTAB64_MASK))
+          const uint64_t p = (tshift == 0 && mid == (int64_t)lb0[j] && (sizeof(KT) == 4 || (uint64_t)ps0[j] != NOPOS))
                                  ? (uint64_t)ps0[j] : k4d_sa_at<EL>(ix, (uint64_t)mid);
           K4Probe pr;
           if (!CAPTURE && j == 0 && memo_hit) { pr.cmp = 0; pr.mm = memo_mm; pr.fm = len; pr.exc = false; }

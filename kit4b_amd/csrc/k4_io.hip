@@ -977,7 +977,7 @@ extern "C" int k4_alloc_device(k4_index* ix, uint64_t bytes, void** p) {
   if (!ix || !p) return K4_ERR_PARAMS;
   *p = nullptr;
   K4_HIP(ix, hipSetDevice(ix->device));
-  K4_HIP(ix, hipMalloc(p, bytes ? bytes : 1));
+  K4_HIP(ix, k4_malloc_retry(p, bytes ? bytes : 1));
   return K4_OK;
 }
 extern "C" int k4_copy_to_device(k4_index* ix, void* d_dst, const void* src, uint64_t bytes) {

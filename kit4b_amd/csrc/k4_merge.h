@@ -22,6 +22,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -325,6 +326,98 @@ inline int merge_sam(const std::vector<std::string>& shards, const std::string& 
     return bad;
   }
   if (n_out) *n_out = n_rec.load();
+  return 0;
+}
+
+// ---- BAM record streams (k4align -G -o x.bam) ---------------------------------------------------------------------------------
+// Each file: the coordinate-sorted BAM records of one rank, uncompressed, one behind the other (block_size, refID, pos, ...; SAM
+// specification 4.2), refID numbering every sequence of the index.  They are merged by the key the ranks sorted by -- sequence,
+// position, length of the first aligned block, strand (SortHitMatch, KAligner.cpp:10969-11014) -- equal keys in file order, records
+// without coordinates (refID -1) last; ref_map (optional) renumbers refID / next_refID.  `emit(ptr, n)` takes the merged stream
+// in pieces of whole records and returns false on an output error.  Sequential: the deflate behind emit is what takes the time.
+struct BamKey {
+  uint32_t ref; int32_t pos; uint32_t len; uint32_t strand;
+  bool operator<(const BamKey& o) const {
+    if (ref != o.ref) return ref < o.ref;
+    if (pos != o.pos) return pos < o.pos;
+    if (len != o.len) return len < o.len;
+    return strand < o.strand;
+  }
+};
+inline bool bam_key(const uint8_t* p, size_t avail, BamKey& k, size_t& rec_bytes) {
+  if (avail < 36) return false;
+  uint32_t bs; int32_t ref, pos; uint16_t n_cig, flag;
+  memcpy(&bs, p, 4); memcpy(&ref, p + 4, 4); memcpy(&pos, p + 8, 4); memcpy(&n_cig, p + 16, 2); memcpy(&flag, p + 18, 2);
+  const size_t l_name = p[12];
+  if (bs < 32 || (size_t)bs + 4 > avail || 36 + l_name + 4 * (size_t)n_cig > (size_t)bs + 4) return false;
+  rec_bytes = (size_t)bs + 4;
+  uint32_t len = 0;
+  if (n_cig) {
+    uint32_t op;
+    memcpy(&op, p + 36 + l_name, 4);
+    if ((op & 15u) == 4u && n_cig > 1) memcpy(&op, p + 36 + l_name + 4, 4);  // behind a leading soft clip
+    len = op >> 4;
+  }
+  k.ref = (uint32_t)ref; k.pos = pos; k.len = len; k.strand = (flag & 0x10) ? 1u : 0u;
+  return true;
+}
+template <class Emit>
+inline int merge_bam_records(const std::vector<std::string>& files, const std::vector<int32_t>* ref_map, Emit&& emit, unsigned long long* n_out, std::string* why) {
+  struct Src { const uint8_t* p = nullptr; size_t len = 0, at = 0, rec = 0; BamKey k; int fd = -1; };
+  std::vector<Src> src(files.size());
+  auto fail = [&](const std::string& m, int rc) {
+    if (why) *why = m;
+    for (Src& x : src) { if (x.p && x.len) munmap((void*)x.p, x.len); if (x.fd >= 0) close(x.fd); }
+    return rc;
+  };
+  for (size_t f = 0; f < files.size(); f++) {
+    Src& x = src[f];
+    x.fd = open(files[f].c_str(), O_RDONLY);
+    struct stat sb;
+    if (x.fd < 0 || fstat(x.fd, &sb) != 0) return fail("unable to open " + files[f], 2);
+    x.len = (size_t)sb.st_size;
+    if (x.len) {
+      void* m = mmap(nullptr, x.len, PROT_READ, MAP_PRIVATE, x.fd, 0);
+      if (m == MAP_FAILED) { x.len = 0; return fail("unable to map " + files[f], 2); }
+      x.p = (const uint8_t*)m;
+      madvise(m, x.len, MADV_SEQUENTIAL);
+      if (!bam_key(x.p, x.len, x.k, x.rec)) return fail("malformed BAM record at the start of " + files[f], 4);
+    }
+  }
+  std::vector<uint8_t> buf;
+  buf.reserve((size_t)9 << 20);
+  unsigned long long n = 0;
+  for (;;) {
+    int best = -1;
+    for (size_t f = 0; f < src.size(); f++)
+      if (src[f].at < src[f].len && (best < 0 || src[f].k < src[(size_t)best].k)) best = (int)f;  // (strict: ties stay with the lower file)
+    if (best < 0) break;
+    Src& x = src[(size_t)best];
+    const size_t o = buf.size();
+    buf.insert(buf.end(), x.p + x.at, x.p + x.at + x.rec);
+    if (ref_map) {
+      for (size_t fo : {(size_t)4, (size_t)24}) {
+        int32_t v;
+        memcpy(&v, &buf[o + fo], 4);
+        if (v >= 0) {
+          if ((size_t)v >= ref_map->size() || (*ref_map)[(size_t)v] < 0) return fail("a record of " + files[(size_t)best] + " names a sequence no rank reported as hit", 4);
+          v = (*ref_map)[(size_t)v];
+          memcpy(&buf[o + fo], &v, 4);
+        }
+      }
+    }
+    n++;
+    x.at += x.rec;
+    if (x.at < x.len && !bam_key(x.p + x.at, x.len - x.at, x.k, x.rec)) return fail("malformed BAM record in " + files[(size_t)best], 4);
+    if (buf.size() >= ((size_t)8 << 20)) {
+      if (!emit(buf.data(), buf.size())) return fail("", 5);
+      buf.clear();
+    }
+  }
+  if (!buf.empty() && !emit(buf.data(), buf.size())) return fail("", 5);
+  if (n_out) *n_out = n;
+  fail("", 0);
+  if (why) why->clear();
   return 0;
 }
 

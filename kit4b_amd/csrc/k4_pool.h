@@ -61,6 +61,18 @@ inline size_t k4_pool_class(size_t bytes) {
   return (bytes + step - 1) / step * step;
 }
 
+// hipMalloc for everything that is not a pool block: when the device is out of memory while gigabytes sit cached in the pool,
+// the cache is given back and the allocation tried once more
+inline hipError_t k4_malloc_retry(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    k4_pool_trim_current_device();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+
 inline hipError_t k4_pool_get(void** p, size_t bytes, hipStream_t st, size_t* cap_out, hipEvent_t* ev_out) {
   const size_t want = k4_pool_class(bytes ? bytes : 1);
   K4Pool& P = k4_pool_of_current_device();
@@ -77,7 +89,11 @@ inline hipError_t k4_pool_get(void** p, size_t bytes, hipStream_t st, size_t* ca
   }
   if (pick.p) {
     hipError_t e = hipStreamWaitEvent(st, pick.ev, 0);  // behind the block's last user, whichever stream that was
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {  // (the block goes back on the list: nothing is leaked)
+      std::lock_guard<std::mutex> lk(P.m);
+      P.free_.push_back(pick);
+      return e;
+    }
     *p = pick.p; *cap_out = pick.cap; *ev_out = pick.ev;
     return hipSuccess;
   }

@@ -10,13 +10,14 @@
 #include <rocprim/rocprim.hpp>
 #include "k4_device.h"
 #include "k4_internal.h"
+#include "k4_pool.h"
 
 namespace {
 
 struct Buf {
   void* p = nullptr;
   ~Buf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  hipError_t alloc(size_t bytes) { return k4_malloc_retry(&p, bytes ? bytes : 1); }
   template <typename T> T* as() { return (T*)p; }
 };
 

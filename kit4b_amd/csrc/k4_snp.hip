@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include "k4_device.h"
+#include "k4_pool.h"
 
 namespace {
 
@@ -82,6 +83,19 @@ __global__ void __launch_bounds__(256) k4k_snp_pileup(SnpArgs a) {
     if (m) atomicAdd(&a.tot[0], m);
     if (mm) atomicAdd(&a.tot[1], mm);
     if (nr) { atomicAdd(&a.tot[2], nr); atomicAdd(&a.tot[3], nb); }
+  }
+}
+
+// which sequences hold an alignment the pile-up would take at all: one pass over the reads before the per-sequence work, so that
+// an assembly of 10^5 contigs costs its hit contigs, not its contigs (the reference walks its sorted reads once)
+__global__ void __launch_bounds__(256) k4k_snp_mark(SnpArgs a, uint8_t* __restrict__ flags, uint32_t n_entries) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_reads; i += stride) {
+    const int nar = a.pe ? a.pr[i].nar : a.rr[i].nar;
+    if (nar != K4_NAR_ACCEPTED) continue;
+    const k4_hit h = a.pe ? a.pr[i].hit : a.hits[i * a.max_ml];
+    if ((h.ext & (K4_EXT_INDEL | K4_EXT_SPLICE)) || h.chrom_id < 1 || h.chrom_id > n_entries) continue;
+    flags[h.chrom_id] = 1;
   }
 }
 
@@ -306,7 +320,7 @@ static WigOut wig_chromosome(std::unique_ptr<uint8_t[]> cov, int width, uint32_t
 struct Buf {
   void* p = nullptr;
   ~Buf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  hipError_t alloc(size_t bytes) { return k4_malloc_retry(&p, bytes ? bytes : 1); }
   template <typename T> T* as() { return (T*)p; }
 };
 
@@ -442,14 +456,22 @@ static int snp_text_dev(k4_index* ix, int vcf, int pe, int64_t n_units, const vo
   std::vector<Cand> hc;
   std::vector<LociPV> pv;
   char alts[100] = "", freq[100] = "";  // VCF: ALT and AF of the last SNP that had any (see below)
+  std::vector<uint8_t> chrom_hit((size_t)ix->d.n_entries + 1, 0);
+  std::vector<uint64_t> ent_start_h((size_t)ix->d.n_entries, 0);
+  if (a.n_reads > 0 && ix->d.n_entries) {
+    Buf flags;
+    K4_HIP(ix, flags.alloc(chrom_hit.size()));
+    K4_HIP(ix, hipMemsetAsync(flags.p, 0, chrom_hit.size(), st));
+    hipLaunchKernelGGL(k4k_snp_mark, dim3((unsigned)std::min<int64_t>((a.n_reads + 255) / 256, 2048)), dim3(256), 0, st, a, flags.as<uint8_t>(), ix->d.n_entries);
+    K4_HIP(ix, hipMemcpyAsync(chrom_hit.data(), flags.p, chrom_hit.size(), hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipMemcpyAsync(ent_start_h.data(), ix->ent_start, ent_start_h.size() * 8, hipMemcpyDeviceToHost, st));
+    K4_HIP(ix, hipStreamSynchronize(st));
+  }
   for (uint32_t chrom = 1; chrom <= ix->d.n_entries && a.n_reads > 0; chrom++) {  // the sorted reads: one chromosome after the other
+    if (!chrom_hit[chrom]) continue;  // (nothing the pile-up would take: no device work, no synchronisation for it)
     const k4_entry& e = ix->entries[chrom - 1];
     a.chrom_id = chrom; a.clen = e.seq_len; a.cnt = cnt.as<uint32_t>(); a.tot = tot.as<unsigned long long>();
-    {
-      uint64_t cs = 0;
-      K4_HIP(ix, hipMemcpy(&cs, ix->ent_start + (chrom - 1), 8, hipMemcpyDeviceToHost));
-      a.cs = cs;
-    }
+    a.cs = ent_start_h[chrom - 1];
     const size_t Sc = K4_SNP_STRIDE(a);
     K4_HIP(ix, hipMemsetAsync(cnt.p, 0, 7 * Sc * 4, st));
     K4_HIP(ix, hipMemsetAsync(tot.p, 0, 32, st));

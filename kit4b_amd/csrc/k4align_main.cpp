@@ -53,6 +53,7 @@ struct Opts {
   int gpu = 0;
   std::vector<int> gpus;            // -G g0,g1,...: one rank process per listed GPU (RCCL over xGMI, libk4comm.so)
   int rank = 0, n_ranks = 1;        // this process's place in a -G run
+  bool rank_bam = false;            // ... whose output is a BAM file: the rank leaves its sorted records (all sequences numbered) + a dictionary beside them
   struct MultiShared* shared = nullptr;
   int print_slices = 0;             // -W <n>: print the byte offsets -G would cut the reads files at for n ranks, and stop (no GPU needed)
   int rpt_sq_thres = 10000;         // -4 <n>: with more reference sequences than this only those with alignments are declared in the header (KAlignerCL.cpp:289,868-870)
@@ -558,6 +559,19 @@ static GlibcRand draws;
 
 static int run_multi_gpu(Opts& o, bool pe, int max_ml);
 
+// A run that fails after it created its output leaves no artefact behind (a SAM sized in advance and padded with NULs, a BAM
+// without its end-of-file block), and the pipeline's threads and pinned buffers are gone before main returns.
+struct RunGuard {
+  k4_pipeline** pl;
+  std::vector<std::string> made;
+  bool ok = false;
+  ~RunGuard() {
+    if (ok) return;
+    if (pl && *pl) { k4_pipeline_close(*pl); *pl = nullptr; }
+    for (const std::string& f : made) remove(f.c_str());
+  }
+};
+
 // one process, one GPU: the whole run, or rank o.rank of a -G run
 static int run_rank(Opts& o, const bool pe, const int max_ml) {
   auto t0 = std::chrono::steady_clock::now();
@@ -774,12 +788,13 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   // compute stream; one global sort + SAM body at the end, handed out while its next pieces come down.
   // -b <MB>: bounded memory, coordinate-sorted parts merged on the host; -S i/N: one slice of the reads (one process per GPU)
   k4_pipeline* pl = nullptr;
+  RunGuard guard{&pl};
   uint64_t pl_sam_bytes = 0;
   const bool pipelined = o.batch_mb <= 0 && o.n_shards == 1 && !o.legacy;
   // "-o x.bam": BGZF compressed BAM, any other extension SAM (KAlignerCL.cpp:857-866)
-  const bool bam_out = o.out.size() >= 4 && strcasecmp(o.out.c_str() + o.out.size() - 4, ".bam") == 0;
+  const bool bam_out = o.rank_bam || (o.out.size() >= 4 && strcasecmp(o.out.c_str() + o.out.size() - 4, ".bam") == 0);
   if (!pipelined && !multi && (rc = k4_open_wait(ix)) != K4_OK) { fprintf(stderr, "k4align: unable to load '%s': %s (%d)\n", o.sfx.c_str(), k4_global_error(), rc); return 2; }
-  if (bam_out && (!pipelined || multi)) { fprintf(stderr, "k4align: BAM output is written by the pipelined single-GPU mode (not with -b, -S, -G, -Z)\n"); return 3; }
+  if (bam_out && (!pipelined || (multi && !o.rank_bam))) { fprintf(stderr, "k4align: BAM output is written by the pipelined modes (not with -b, -S, -Z)\n"); return 3; }
   if (pipelined) {
     for (const std::vector<std::string>* fs : {&o.in1, &o.in2})
       for (const std::string& q : *fs) {
@@ -910,8 +925,10 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       if (chatty) fprintf(stderr, "k4align: SNP processing completed with %llu putative SNPs discovered, written to %s in %.2fs\n",
                           (unsigned long long)sf.n_snps, o.snp_file.c_str(), secs(ts, now()));
     }
-    if (bam_out && o.fmode == 1) CK(k4_pipeline_format_bam_all(pl, info.n_entries <= (uint32_t)o.rpt_sq_thres ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
-    else if (bam_out) CK(k4_pipeline_format_bam(pl, info.n_entries <= (uint32_t)o.rpt_sq_thres ? 1 : 0, &tot, hit_chrom.data(), &pl_sam_bytes));
+    // (a rank of a -G run numbers every sequence: the parent renumbers when it knows which ones any rank has hit)
+    const int bam_all_sq = (info.n_entries <= (uint32_t)o.rpt_sq_thres || o.rank_bam) ? 1 : 0;
+    if (bam_out && o.fmode == 1) CK(k4_pipeline_format_bam_all(pl, bam_all_sq, &tot, hit_chrom.data(), &pl_sam_bytes));
+    else if (bam_out) CK(k4_pipeline_format_bam(pl, bam_all_sq, &tot, hit_chrom.data(), &pl_sam_bytes));
     else if (o.fmode == 1) CK(k4_pipeline_format_all(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     else CK(k4_pipeline_format(pl, &tot, hit_chrom.data(), &pl_sam_bytes));
     s_align = secs(tg, now());
@@ -974,6 +991,39 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
 
   // ---- SAM file: header here, body as formatted on the device ----------------------------------------------------------
   auto tw = now();
+  if (bam_out && o.rank_bam) {
+    // ---- a rank of a -G run: its coordinate-sorted BAM records as they are (refID = sequence number - 1), and beside them the
+    // dictionary with this rank's hit flags; the parent merges the ranks' streams into the one BAM file (run_multi_gpu) ----------
+    FILE* fp = fopen(o.out.c_str(), "wb");
+    if (!fp) { fprintf(stderr, "k4align: unable to create %s\n", o.out.c_str()); return 5; }
+    guard.made.push_back(o.out);
+    guard.made.push_back(o.out + ".sq");
+    uint64_t nbytes = 0;
+    for (;;) {
+      const void* ptr = nullptr;
+      uint64_t len = 0;
+      CK(k4_pipeline_next_sam(pl, &ptr, &len));
+      if (len == 0) break;
+      if (fwrite(ptr, 1, (size_t)len, fp) != (size_t)len) { fprintf(stderr, "k4align: unable to write %s\n", o.out.c_str()); fclose(fp); return 5; }
+      nbytes += len;
+    }
+    if (fclose(fp) != 0) { fprintf(stderr, "k4align: unable to write %s\n", o.out.c_str()); return 5; }
+    FILE* fd = fopen((o.out + ".sq").c_str(), "wb");
+    if (!fd) { fprintf(stderr, "k4align: unable to create %s.sq\n", o.out.c_str()); return 5; }
+    fprintf(fd, "%s\n", info.dataset);
+    for (uint32_t c = 1; c <= info.n_entries; c++) {
+      k4_entry e;
+      k4_get_entry(ix, c, &e);
+      fprintf(fd, "%s\t%u\t%d\n", e.name, e.seq_len, hit_chrom[c] ? 1 : 0);
+    }
+    if (fclose(fd) != 0) { fprintf(stderr, "k4align: unable to write %s.sq\n", o.out.c_str()); return 5; }
+    k4_pipeline_close(pl);
+    pl = nullptr;
+    guard.ok = true;
+    if (chatty) fprintf(stderr, "k4align: rank %d: %llu alignments as BAM records (%llu bytes) for the merge\n", o.rank, (unsigned long long)my_lines, (unsigned long long)nbytes);
+    k4_close(ix);
+    return 0;
+  }
   if (bam_out) {
     // ---- BAM (+ .bai): dictionary and BGZF blocks here (include/k4_bam.hpp), the records as packed on the device ------------
     std::string hdr = "@HD\tVN:1.4\tSO:coordinate\n";
@@ -989,6 +1039,8 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     hdr += "@PG\tID:k4align\tVN:1.0\n";
     k4bam::Writer bw;
     if (!bw.open(o.out, hdr, refs, o.bam_level, std::max(o.io_threads, 1))) { fprintf(stderr, "k4align: %s\n", bw.error().c_str()); return 5; }
+    guard.made.push_back(o.out);
+    guard.made.push_back(o.out + ".bai");
     for (;;) {  // the records come down piece by piece; the previous piece is deflated and written meanwhile
       const void* ptr = nullptr;
       uint64_t len = 0;
@@ -1000,6 +1052,8 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
     if (!bw.indexed() && chatty) fprintf(stderr, "k4align: a sequence of 512 Mbp or more: no .bai written (the reference writes a CSI index there)\n");
     if (bw.n_records() != my_lines) { fprintf(stderr, "k4align: internal error: %llu BAM records for %llu alignments\n", (unsigned long long)bw.n_records(), (unsigned long long)my_lines); return 5; }
     k4_pipeline_close(pl);
+    pl = nullptr;
+    guard.ok = true;
     const double s_write_bam = secs(tw, now());
     if (chatty)
       fprintf(stderr, "k4align: %llu alignments reported to %s (%llu bytes) + .bai; index %.2fs, reads %.2fs, device side behind the reads %.2fs, "
@@ -1010,6 +1064,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   }
   FILE* fp = fopen(o.out.c_str(), "wb");
   if (!fp) { fprintf(stderr, "k4align: unable to create %s\n", o.out.c_str()); return 5; }
+  guard.made.push_back(o.out);
   static char iobuf[1 << 22];
   setvbuf(fp, iobuf, _IOFBF, sizeof(iobuf));
   fprintf(fp, "@HD\tVN:1.4\tSO:coordinate\n");
@@ -1027,13 +1082,18 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   if (pl) {  // the body comes down piece by piece while the previous piece is written
     fflush(fp);
     const int fd = fileno(fp);
-    uint64_t fpos = (uint64_t)ftello(fp);
-    if (ftruncate(fd, (off_t)(fpos + pl_sam_bytes)) != 0) { /* (the size is only a hint for the file system) */ }
+    const bool seekable = lseek(fd, 0, SEEK_CUR) != (off_t)-1;  // (-o /dev/stdout, a pipe: written in order by one thread)
+    uint64_t fpos = seekable ? (uint64_t)ftello(fp) : 0;
+    if (seekable && ftruncate(fd, (off_t)(fpos + pl_sam_bytes)) != 0) { /* (the size is only a hint for the file system) */ }
     for (;;) {
       const void* ptr = nullptr;
       uint64_t len = 0;
       CK(k4_pipeline_next_sam(pl, &ptr, &len));
       if (len == 0) break;
+      if (!seekable) {
+        if (fwrite(ptr, 1, (size_t)len, fp) != (size_t)len) { fprintf(stderr, "k4align: write to %s failed\n", o.out.c_str()); return 5; }
+        continue;
+      }
       // (several pwrite()s side by side: one thread does not saturate tmpfs / the page cache)
       const int nt = len >= (8u << 20) ? std::max(o.io_threads, 1) : 1;
       std::atomic<bool> ok(true);
@@ -1052,10 +1112,11 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
       if (!ok) { fprintf(stderr, "k4align: write to %s failed\n", o.out.c_str()); return 5; }
       fpos += len;
     }
-    fseeko(fp, (off_t)fpos, SEEK_SET);
+    if (seekable) fseeko(fp, (off_t)fpos, SEEK_SET);
     {
       auto tc0 = now();
       k4_pipeline_close(pl);
+      pl = nullptr;
       if (getenv("K4_TRACE")) fprintf(stderr, "[k4 trace] pipeline closed in %.2fs\n", secs(tc0, now()));
     }
   } else if (keep_sam) {
@@ -1108,6 +1169,7 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
   fprintf(stderr, "k4align: %s%llu alignments written to %s (%zu batch%s); index %.2fs, read files %.2fs, upload+parse %.2fs, align+format %.2fs, write %.2fs\n",
           multi ? ("rank " + std::to_string(o.rank) + ": ").c_str() : "", (unsigned long long)my_lines, o.out.c_str(),
           parts.empty() ? (size_t)1 : parts.size(), parts.size() > 1 ? "es" : "", std::max(secs(t0, t_open), k4_open_seconds(ix)), s_read, s_parse, s_align, s_write);
+  guard.ok = true;
   if (comm) { k4_comm_barrier(comm); }
   k4_close(ix);
   if (comm) k4_comm_close(comm);
@@ -1118,6 +1180,56 @@ static int run_rank(Opts& o, const bool pe, const int max_ml) {
 // form an RCCL communicator (the id travels through a shared anonymous mapping), rank 0 reads the .sfx once and every rank
 // receives sequence + suffix array over xGMI (k4_comm_open_index), each aligns its contiguous slice of the reads, the NAR
 // tallies are summed with one all-reduce, and the parent merges the ranks' coordinate-sorted shards.
+// The ranks' record streams + dictionaries -> the one BAM file: header by kalign's @SQ rule over the union of the ranks' hit
+// flags (m_MaxRptSAMSeqsThres, KAligner.cpp:5785-5821), records merged by (refID, pos) with equal keys in rank order -- the order
+// the reads were loaded in -- renumbered when not every sequence is declared, deflated and indexed by k4bam::Writer.
+static int merge_rank_bams(const std::vector<std::string>& shards, const std::string& out, const Opts& o, unsigned long long* n_out) {
+  std::string dataset;
+  std::vector<k4bam::RefSeq> all;
+  std::vector<char> hit;
+  for (size_t r = 0; r < shards.size(); r++) {
+    FILE* fd = fopen((shards[r] + ".sq").c_str(), "rb");
+    if (!fd) { fprintf(stderr, "k4align: unable to open %s.sq\n", shards[r].c_str()); return 5; }
+    char line[512];
+    size_t c = 0;
+    bool first = true, ok = true;
+    while (ok && fgets(line, sizeof(line), fd)) {
+      size_t L = strlen(line);
+      if (L && line[L - 1] == '\n') line[--L] = 0;
+      if (first) { if (r == 0) dataset = line; first = false; continue; }
+      char* t1 = strchr(line, '\t');
+      char* t2 = t1 ? strchr(t1 + 1, '\t') : nullptr;
+      if (!t2) { ok = false; break; }
+      *t1 = 0; *t2 = 0;
+      if (r == 0) { all.push_back({line, (uint32_t)strtoul(t1 + 1, nullptr, 10)}); hit.push_back(0); }
+      else if (c >= all.size() || all[c].name != line) { ok = false; break; }
+      if (t2[1] == '1') hit[c] = 1;
+      c++;
+    }
+    fclose(fd);
+    if (!ok || c != all.size()) { fprintf(stderr, "k4align: %s.sq does not match the other ranks' dictionaries\n", shards[r].c_str()); return 5; }
+  }
+  const bool all_sq = all.size() <= (size_t)o.rpt_sq_thres;
+  std::string hdr = "@HD\tVN:1.4\tSO:coordinate\n";
+  std::vector<k4bam::RefSeq> refs;
+  std::vector<int32_t> ref_map(all.size(), -1);
+  for (size_t c = 0; c < all.size(); c++) {
+    if (!(all_sq || hit[c])) continue;
+    ref_map[c] = (int32_t)refs.size();
+    hdr += "@SQ\tAS:" + dataset + "\tSN:" + all[c].name + "\tLN:" + std::to_string(all[c].len) + "\n";
+    refs.push_back(all[c]);
+  }
+  hdr += "@PG\tID:k4align\tVN:1.0\n";
+  k4bam::Writer bw;
+  if (!bw.open(out, hdr, refs, o.bam_level, std::max(o.io_threads, 1) * (int)shards.size())) { fprintf(stderr, "k4align: %s\n", bw.error().c_str()); return 5; }
+  std::string why;
+  const int rc = k4merge::merge_bam_records(shards, all_sq ? nullptr : &ref_map, [&](const void* p, size_t n) { return bw.write(p, n); }, n_out, &why);
+  if (rc) { fprintf(stderr, "k4align: %s\n", why.empty() ? bw.error().c_str() : why.c_str()); return rc; }
+  if (!bw.close()) { fprintf(stderr, "k4align: %s\n", bw.error().c_str()); return 5; }
+  if (bw.n_records() != *n_out) { fprintf(stderr, "k4align: internal error: %llu BAM records written, %llu merged\n", (unsigned long long)bw.n_records(), *n_out); return 5; }
+  return 0;
+}
+
 static int run_multi_gpu(Opts& o, bool pe, int max_ml) {
   const int N = (int)o.gpus.size();
   if (N > K4_MAX_RANKS) { fprintf(stderr, "k4align: at most %d GPUs\n", K4_MAX_RANKS); return 1; }
@@ -1131,6 +1243,7 @@ static int run_multi_gpu(Opts& o, bool pe, int max_ml) {
   if (sh == MAP_FAILED) { fprintf(stderr, "k4align: unable to map shared memory\n"); return 2; }
   memset((void*)sh, 0, sizeof(*sh));
   const std::string final_out = o.out;
+  const bool bam_final = final_out.size() >= 4 && strcasecmp(final_out.c_str() + final_out.size() - 4, ".bam") == 0;
   auto t0 = std::chrono::steady_clock::now();
   // fault injection for the tests of this function (K4ALIGN_FAULT=<rank>:<stage>): the named rank leaves with exit code 3 at
   // "start" (before the communicator exists) / "index" (after the broadcast of the index); with K4ALIGN_FAULT_PEERS=block the
@@ -1144,6 +1257,7 @@ static int run_multi_gpu(Opts& o, bool pe, int max_ml) {
     if (pid == 0) {
       o.rank = r; o.n_ranks = N; o.gpu = o.gpus[(size_t)r]; o.shared = sh;
       o.out = final_out + ".rank" + std::to_string(r);
+      o.rank_bam = bam_final;
       const int rc = run_rank(o, pe, max_ml);
       if (rc != 0) sh->failed = 1;
       fflush(nullptr);
@@ -1180,12 +1294,21 @@ static int run_multi_gpu(Opts& o, bool pe, int max_ml) {
   std::vector<std::string> shards;
   for (int r = 0; r < N; r++) shards.push_back(final_out + ".rank" + std::to_string(r));
   if (worst || sh->failed) {
-    for (const std::string& q : shards) remove(q.c_str());
+    for (const std::string& q : shards) { remove(q.c_str()); remove((q + ".sq").c_str()); }
     munmap((void*)sh, sizeof(*sh));
     return worst ? worst : 2;
   }
   auto t1 = std::chrono::steady_clock::now();
   unsigned long long n = 0;
+  if (bam_final) {
+    const int rc = merge_rank_bams(shards, final_out, o, &n);
+    for (const std::string& q : shards) { remove(q.c_str()); remove((q + ".sq").c_str()); }
+    munmap((void*)sh, sizeof(*sh));
+    if (rc) return rc;
+    fprintf(stderr, "k4align: %llu alignments from %d GPUs written to %s (+ .bai); ranks %.2fs, merge + deflate %.2fs\n", n, N, final_out.c_str(),
+            std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+    return 0;
+  }
   const int rc = k4merge::merge_sam(shards, final_out, o.rpt_sq_thres, &n, "k4align", std::max(o.io_threads, 1) * N);  // (the ranks' reader threads are idle now)
   for (const std::string& q : shards) remove(q.c_str());
   if (rc) return rc;

@@ -8,7 +8,20 @@
 int main(int argc, char** argv) {
   int threads = 0, a0 = 1;
   if (argc > 2 && strcmp(argv[1], "-t") == 0) { threads = atoi(argv[2]); a0 = 3; }
-  if (argc - a0 < 2) { fprintf(stderr, "k4merge [-t threads] out.sam shard0.sam [shard1.sam ...]\n"); return 1; }
+  if (argc > 3 && strcmp(argv[1], "--bam-records") == 0) {
+    // the merge `k4align -G -o x.bam` runs over its ranks' record streams, on its own: uncompressed BAM records in, the merged
+    // stream out (no header, no BGZF)
+    std::vector<std::string> in(argv + 3, argv + argc);
+    FILE* fo = fopen(argv[2], "wb");
+    if (!fo) { fprintf(stderr, "k4merge: unable to create %s\n", argv[2]); return 5; }
+    unsigned long long n = 0;
+    std::string why;
+    const int rc = k4merge::merge_bam_records(in, nullptr, [&](const void* p, size_t len) { return fwrite(p, 1, len, fo) == len; }, &n, &why);
+    if (fclose(fo) != 0 || rc) { fprintf(stderr, "k4merge: %s\n", why.empty() ? "write failed" : why.c_str()); remove(argv[2]); return rc ? rc : 5; }
+    fprintf(stderr, "k4merge: %llu BAM records from %d streams written to %s\n", n, (int)in.size(), argv[2]);
+    return 0;
+  }
+  if (argc - a0 < 2) { fprintf(stderr, "k4merge [-t threads] out.sam shard0.sam [shard1.sam ...]\n        k4merge --bam-records out.rec rank0.rec [rank1.rec ...]\n"); return 1; }
   std::vector<std::string> shards(argv + a0 + 1, argv + argc);
   unsigned long long n = 0;
   const auto t0 = std::chrono::steady_clock::now();

@@ -23,7 +23,7 @@ label = sys.argv[3] if len(sys.argv) > 3 else workload  # e.g. c2_c50 for `bench
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
+shutil.copy(max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime), os.path.join(dst, "kernel_stats.csv"))  # (gpurun merges into gpurun_out: an earlier run's files may still lie there)
 for f in ("bench_trace.json", "randgather_pmc.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
@@ -33,7 +33,7 @@ for kind in ("pmc_sq", "pmc_tcc", "pmc_fetch", "pmc_write", "cal_fetch", "cal_tc
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         k = r["Kernel_Name"]
         if "k4k_align" in k or "k_indep" in k or "k_chain" in k:
             agg[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))

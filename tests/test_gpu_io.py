@@ -477,6 +477,52 @@ def test_k4align_rank_mode_over_rccl(golden_dir, tmp_path, case):
     assert not os.path.exists(out + ".rank0")
 
 
+@pytest.mark.parametrize("case,extra", [("se_s2", []), ("pe_u1", []), ("se_s2", ["-4", "2"]), ("pe_u1", ["-4", "3"])])
+def test_k4align_rank_mode_writes_bam(golden_dir, tmp_path, case, extra):
+    """`k4align -G 0 -o x.bam`: the rank leaves its sorted BAM records (every sequence numbered) and its dictionary with hit
+    flags, the parent merges the ranks' streams (k4_merge.h: merge_bam_records), applies kalign's @SQ rule over the union of the
+    flags (renumbering refID / next_refID when only hit sequences are declared: `-4 2`), deflates and indexes.  With one rank the
+    file must decode to what the reference wrote (golden BAM) / to what the single-GPU run writes with the same options."""
+    import json
+    import lzma
+    import subprocess
+
+    import samutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(golden_dir, "sam_cases.json")))
+
+    def unxz(name):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        return dst
+
+    files = ["-i", unxz("sam_%s.fa.xz" % case)] if case.startswith("se_") else \
+        ["-i", unxz("sam_%s_1.fa.xz" % case), "-u", unxz("sam_%s_2.fa.xz" % case)]
+    base = [os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx")] + cases[case]["args"] + extra + files
+    out = str(tmp_path / "ranks.bam")
+    p = subprocess.run(base + ["-o", out, "-G", "0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "from 1 GPUs written" in p.stderr and "(+ .bai)" in p.stderr
+    assert not os.path.exists(out + ".rank0") and not os.path.exists(out + ".rank0.sq")
+    text, refs, recs = samutil.read_bam(out)
+    if not extra:
+        wtext, wrefs, wrecs = samutil.read_bam(os.path.join(golden_dir, "bam_%s.bam" % case))
+    else:
+        one = str(tmp_path / "one.bam")
+        q = subprocess.run(base + ["-o", one], capture_output=True, text=True, timeout=300)
+        assert q.returncode == 0, q.stderr
+        wtext, wrefs, wrecs = samutil.read_bam(one)
+        assert len(wrefs) < 5  # (the rule was in force: not every sequence of g1 is declared)
+    assert refs == wrefs
+    assert [l for l in text.splitlines() if not l.startswith("@PG")] == [l for l in wtext.splitlines() if not l.startswith("@PG")]
+    key = lambda r: (r["ref"], r["pos"], r["name"], r["flag"])  # noqa: E731
+    assert sorted(recs, key=key) == sorted(wrecs, key=key)
+    coords = [(r["ref"] if r["ref"] >= 0 else 1 << 30, r["pos"]) for r in recs]
+    assert coords == sorted(coords)
+    assert os.path.exists(out + ".bai")
+
+
 @pytest.mark.parametrize("case,form", [("se_s2", "gz"), ("pe_u1", "gz"), ("se_s2", "split"), ("pe_u1", "split")])
 def test_k4align_rank_mode_takes_compressed_and_several_input_files(golden_dir, tmp_path, case, form):
     """`k4align -G` on what a single `kalign` run takes as well: gzipped reads (no byte offsets into a compressed stream: every

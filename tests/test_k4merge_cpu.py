@@ -91,3 +91,55 @@ def test_k4merge_errors_leave_no_partial_file(tmp_path):
     assert r.returncode == 3 and "chrX" in r.stderr and not out.exists()
     r = subprocess.run([EXE, str(out), str(a), str(tmp_path / "missing.sam")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and not out.exists()
+
+
+def _bam_record(ref, pos, name, cigar, flag, seq_len=10):
+    import struct
+
+    nm = name.encode() + b"\0"
+    cig = b"".join(struct.pack("<I", (n << 4) | "MIDNSHP=X".index(op)) for n, op in cigar)
+    body = struct.pack("<iiBBHHHIiii", ref, pos, len(nm), 255, 4680, len(cigar), flag, seq_len, -1, -1, 0) + nm + cig
+    body += bytes((seq_len + 1) // 2) + b"\xff" * seq_len
+    return struct.pack("<I", len(body)) + body
+
+
+def _bam_sort_key(rec):
+    import struct
+
+    ref, pos, l_name, _, _, n_cig, flag = struct.unpack_from("<iiBBHHH", rec, 4)
+    ops = struct.unpack_from("<%dI" % n_cig, rec, 36 + l_name)
+    first = ops[1] if (ops[0] & 15) == 4 and n_cig > 1 else ops[0]
+    return (ref & 0xFFFFFFFF, pos, first >> 4, 1 if flag & 0x10 else 0)
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="k4merge not built")
+@pytest.mark.parametrize("n_streams", [1, 3, 8])
+def test_k4merge_bam_record_streams(tmp_path, n_streams):
+    """The merge behind `k4align -G -o x.bam`: sorted streams of BAM records (many tied keys, soft clips, both strands,
+    records without coordinates at the end, an empty stream) come out as one stable sort would leave them."""
+    import random
+
+    rng = random.Random(77 + n_streams)
+    streams = []
+    for s in range(n_streams):
+        recs = []
+        for q in range(0 if (s == 1 and n_streams > 1) else 4000):
+            ref = rng.choice([0, 0, 1, 2, 5, -1])
+            pos = -1 if ref < 0 else rng.randrange(0, 60)  # few positions: ties everywhere
+            cigar = rng.choice([[(10, "M")], [(3, "S"), (7, "M")], [(6, "M"), (100, "N"), (4, "M")], [(8, "M"), (2, "S")]])
+            recs.append(_bam_record(ref, pos, "s%d_%d" % (s, q), cigar, rng.choice([0, 16]) | (4 if ref < 0 else 0)))
+        recs.sort(key=_bam_sort_key)  # (stable: file order within a key)
+        streams.append(recs)
+        (tmp_path / ("r%d.rec" % s)).write_bytes(b"".join(recs))
+    out = tmp_path / "m.rec"
+    r = subprocess.run([EXE, "--bam-records", str(out)] + [str(tmp_path / ("r%d.rec" % s)) for s in range(n_streams)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    want = sorted((x for recs in streams for x in recs), key=_bam_sort_key)  # stable: ties keep stream order, then order in the stream
+    assert out.read_bytes() == b"".join(want)
+    assert ("%d BAM records from %d streams" % (len(want), n_streams)) in r.stderr
+    # a truncated stream is refused and no output is left behind
+    bad = tmp_path / "bad.rec"
+    bad.write_bytes(b"".join(streams[0])[:-5])
+    r = subprocess.run([EXE, "--bam-records", str(out), str(bad)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "malformed" in r.stderr and not out.exists()
