@@ -68,7 +68,7 @@ K4_DEV uint64_t k4d_ktab_lb(const K4DevIndex& ix, uint64_t c) {
 // bucket of the k-mer prefix range [c0, c1): lb0 = lb(c0), pos0 = pos0(c0), lb1 = lb(c1); sig = sig(c0) (32-bit form) /
 // sub = the 48 bits of sub-bucket counts of c0 (64-bit form).  KT = field type.
 template <typename KT>
-K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& lb0, KT& pos0, uint32_t& sig, KT& lb1, uint64_t& sub) {
+K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& lb0, KT& pos0, uint32_t& sig, KT& lb1, uint64_t& sub, bool lazy_lb1 = false) {
   sub = K4_KTAB64_IRREGULAR;
   if (sizeof(KT) == 4) {
     const uint32_t* t = reinterpret_cast<const uint32_t*>(ix.ktab);
@@ -85,7 +85,10 @@ K4_DEV void k4d_ktab_fetch(const K4DevIndex& ix, uint64_t c0, uint64_t c1, KT& l
     const k4_u64x2_a8 v = *reinterpret_cast<const k4_u64x2_a8*>(t + K4_KTAB_STRIDE64 * c0);
     lb0 = (KT)(v.x & K4_KTAB64_MASK); pos0 = (KT)(v.y & K4_KTAB64_MASK); sig = 0;
     sub = (v.x >> 40) | ((v.y >> 40) << 24);
-    lb1 = (KT)(t[K4_KTAB_STRIDE64 * c1] & K4_KTAB64_MASK);
+    // lazy_lb1: the caller goes on to the sub-bucket of a regular bucket and has no use for the bucket's end -- one load and,
+    // for one entry in eight, one more 128-byte line less per lookup; an irregular bucket fetches it behind the entry
+    if (!lazy_lb1 || sub == K4_KTAB64_IRREGULAR) lb1 = (KT)(t[K4_KTAB_STRIDE64 * c1] & K4_KTAB64_MASK);
+    else lb1 = lb0;
   }
 }
 // the sub-bucket of two-base extension e (0..15) inside a regular bucket: (suffixes in front of it, its own count)
