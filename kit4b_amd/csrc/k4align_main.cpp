@@ -568,7 +568,10 @@ struct RunGuard {
   ~RunGuard() {
     if (ok) return;
     if (pl && *pl) { k4_pipeline_close(*pl); *pl = nullptr; }
-    for (const std::string& f : made) remove(f.c_str());
+    for (const std::string& f : made) {
+      struct stat sb;
+      if (lstat(f.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) remove(f.c_str());  // (never a device node or /dev/stdout's link)
+    }
   }
 };
 

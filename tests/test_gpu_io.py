@@ -477,6 +477,30 @@ def test_k4align_rank_mode_over_rccl(golden_dir, tmp_path, case):
     assert not os.path.exists(out + ".rank0")
 
 
+def test_k4align_output_to_a_pipe_and_a_failed_write(golden_dir, tmp_path):
+    """`-o /dev/stdout` into a pipe: not seekable, so the body is written in order by one thread instead of with pwrite() -- the same
+    bytes as the file the seekable path writes.  And a run whose write fails (`/dev/full`) ends with an error, leaves the device node
+    alone and no output artefact behind (RunGuard, k4align_main.cpp)."""
+    import lzma
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "kit4b_amd", "k4align")
+    fa = str(tmp_path / "r.fa")
+    open(fa, "wb").write(lzma.open(os.path.join(golden_dir, "sam_se_s2.fa.xz")).read())
+    base = [exe, "-I", os.path.join(golden_dir, "g1.sfx"), "-s2", "-i", fa]
+    out = str(tmp_path / "o.sam")
+    p = subprocess.run(base + ["-o", out], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    q = subprocess.run(base + ["-o", "/dev/stdout"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert q.returncode == 0, q.stderr
+    assert q.stdout == open(out, "rb").read()
+    if os.path.exists("/dev/full"):
+        r = subprocess.run(base + ["-o", "/dev/full"], capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "write to /dev/full failed" in r.stderr
+        assert os.path.exists("/dev/full")
+
+
 @pytest.mark.parametrize("case,extra", [("se_s2", []), ("pe_u1", []), ("se_s2", ["-4", "2"]), ("pe_u1", ["-4", "3"])])
 def test_k4align_rank_mode_writes_bam(golden_dir, tmp_path, case, extra):
     """`k4align -G 0 -o x.bam`: the rank leaves its sorted BAM records (every sequence numbered) and its dictionary with hit
