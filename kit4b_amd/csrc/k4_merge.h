@@ -48,6 +48,15 @@ struct Names {  // RNAME -> position in the merged header
 
 // FLAG (2), RNAME (3), POS (4), CIGAR (6) of the record that starts at `l` (ends before `e`).  last_*: the previous lookup of the
 // calling thread (consecutive records mostly share their RNAME).  Returns false on a malformed record / unknown RNAME.
+static const long kUnplaced = 0x7fffffffffffffffL;  // RNAME '*': behind every sequence
+// the NAR abbreviations in the order of their codes (KAligner.h teNAR; k4align's tally lines): -M1 lists the reads without an
+// accepted alignment by ascending code, so the code takes the place of the position in such a record's key
+inline long nar_code_of(const char* two) {
+  static const char* const kAbbr[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"};
+  for (long k = 0; k < 20; k++)
+    if (two[0] == kAbbr[k][0] && two[1] == kAbbr[k][1]) return k;
+  return 20;
+}
 struct KeyReader {
   const Names* nm;
   const char* last_name = nullptr;
@@ -65,7 +74,9 @@ struct KeyReader {
     const char* name = t[1] + 1;
     const size_t nl = (size_t)(t[2] - name);
     long chrom;
-    if (last_name && nl == last_len && memcmp(name, last_name, nl) == 0)
+    if (nl == 1 && name[0] == '*')
+      chrom = kUnplaced;  // (-M1: the reads without an accepted alignment follow the alignments, in shard order)
+    else if (last_name && nl == last_len && memcmp(name, last_name, nl) == 0)
       chrom = last_chrom;
     else {
       auto it = nm->order.find(std::string(name, nl));
@@ -73,13 +84,18 @@ struct KeyReader {
       chrom = it->second;
       last_name = name; last_len = nl; last_chrom = chrom;
     }
-    const long pos = atol(t[2] + 1);
+    long pos = atol(t[2] + 1);
+    if (chrom == kUnplaced) {  // "...\tYU:Z:<NAR>\n" ends the record
+      const char* z = e;
+      while (z > l && (z[-1] == '\n' || z[-1] == '\r')) z--;
+      pos = (z - l >= 7 && memcmp(z - 7, "YU:Z:", 5) == 0) ? nar_code_of(z - 2) : 20;
+    }
     const long strand = (atol(t[0] + 1) & 0x10) ? 1 : 0;  // '+' (43) sorts before '-' (45)
     // AdjHitLen(Seg[0]): the M block that follows an optional leading soft clip
     const char* c = t[4] + 1;
     long v = strtol(c, (char**)&c, 10);
     if (*c == 'S') v = strtol(c + 1, (char**)&c, 10);
-    k = Key(chrom, pos, v, strand);
+    k = chrom == kUnplaced ? Key(chrom, pos, 0, 0) : Key(chrom, pos, v, strand);  // (within a NAR code: shard order, then order in the shard)
     return true;
   }
 };
@@ -226,7 +242,7 @@ inline int merge_sam(const std::vector<std::string>& shards, const std::string& 
               const char* le = line_end(l, e);
               Key k;
               if (!kr.key(l, le, k)) { note_bad(kr); break; }
-              mine[(size_t)c][(size_t)std::get<0>(k)] = 1;
+              if (std::get<0>(k) != kUnplaced) mine[(size_t)c][(size_t)std::get<0>(k)] = 1;
               l = le;
             }
       });
@@ -359,6 +375,11 @@ inline bool bam_key(const uint8_t* p, size_t avail, BamKey& k, size_t& rec_bytes
     len = op >> 4;
   }
   k.ref = (uint32_t)ref; k.pos = pos; k.len = len; k.strand = (flag & 0x10) ? 1u : 0u;
+  if (ref < 0) {  // -M1's records without coordinates: by NAR code (their last aux field, YU:Z:<two letters>), then file order
+    const uint8_t* z = p + rec_bytes;
+    k.pos = (rec_bytes >= 42 && z[-1] == 0 && memcmp(z - 6, "YUZ", 3) == 0) ? (int32_t)nar_code_of((const char*)z - 3) : 20;
+    k.len = 0; k.strand = 0;
+  }
   return true;
 }
 template <class Emit>

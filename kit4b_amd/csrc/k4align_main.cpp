@@ -1433,8 +1433,8 @@ int main(int argc, char** argv) {
   if (o.fmode < 0 || o.fmode > 3) { fprintf(stderr, "k4align: output format mode '-M%d' specified outside of range 0..3\n", o.fmode); return 1; }
   if (o.fmode >= 2) { fprintf(stderr, "k4align: output format -M%d (BED / packed base alleles) is not built\n", o.fmode); return 3; }
   if (o.fmode == 1) {
-    if (o.batch_mb > 0 || o.n_shards > 1 || !o.gpus.empty() || o.legacy || o.ml_mode == 5) {
-      fprintf(stderr, "k4align: -M1 is written by the pipelined single-GPU mode (not with -b, -S i/N, -G, -Z, -r5)\n");
+    if (o.batch_mb > 0 || o.n_shards > 1 || o.legacy || o.ml_mode == 5) {
+      fprintf(stderr, "k4align: -M1 is written by the pipelined modes (not with -b, -S i/N, -Z, -r5)\n");
       return 3;
     }
     if (o.min_snp_reads > 0 || !o.snp_file.empty()) { fprintf(stderr, "k4align: SNP calling is not available in '-M1' output mode\n"); return 1; }  // KAlignerCL.cpp:935

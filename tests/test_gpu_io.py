@@ -501,7 +501,7 @@ def test_k4align_output_to_a_pipe_and_a_failed_write(golden_dir, tmp_path):
         assert os.path.exists("/dev/full")
 
 
-@pytest.mark.parametrize("case,extra", [("se_s2", []), ("pe_u1", []), ("se_s2", ["-4", "2"]), ("pe_u1", ["-4", "3"])])
+@pytest.mark.parametrize("case,extra", [("se_s2", []), ("pe_u1", []), ("se_s2", ["-4", "2"]), ("pe_u1", ["-4", "3"]), ("se_s2", ["-M1"]), ("pe_u1", ["-M1"])])
 def test_k4align_rank_mode_writes_bam(golden_dir, tmp_path, case, extra):
     """`k4align -G 0 -o x.bam`: the rank leaves its sorted BAM records (every sequence numbered) and its dictionary with hit
     flags, the parent merges the ranks' streams (k4_merge.h: merge_bam_records), applies kalign's @SQ rule over the union of the
@@ -530,7 +530,9 @@ def test_k4align_rank_mode_writes_bam(golden_dir, tmp_path, case, extra):
     assert "from 1 GPUs written" in p.stderr and "(+ .bai)" in p.stderr
     assert not os.path.exists(out + ".rank0") and not os.path.exists(out + ".rank0.sq")
     text, refs, recs = samutil.read_bam(out)
-    if not extra:
+    if extra == ["-M1"]:  # every loaded read: the ones without an accepted alignment follow, without coordinates
+        wtext, wrefs, wrecs = samutil.read_bam(os.path.join(golden_dir, "bam_%s_M1.bam" % case))
+    elif not extra:
         wtext, wrefs, wrecs = samutil.read_bam(os.path.join(golden_dir, "bam_%s.bam" % case))
     else:
         one = str(tmp_path / "one.bam")
@@ -744,6 +746,39 @@ def test_k4align_all_reads_mode_writes_the_reference_sam(golden_dir, tmp_path, c
     assert any(l.endswith("\t*\t\tYU:Z:NL") for l in got)
     for name, n in meta["nar"].items():
         assert ("%d (%s)" % (n, name)) in p.stderr, (name, n)
+
+
+@pytest.mark.parametrize("case", ["se_s2_M1", "pe_u1_M1"])
+def test_k4align_rank_mode_all_reads(golden_dir, tmp_path, case):
+    """`-G 0 -M1`: the rank's shard ends with its reads without an accepted alignment (RNAME '*', NAR in YU:Z), the merge keeps them
+    behind the alignments and in NAR order (k4_merge.h: KeyReader) -- the reference's file as in the single-GPU test above."""
+    import json
+    import lzma
+    import subprocess
+
+    import samutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(golden_dir, "sam_all_cases.json")))[case]
+    base = meta["reads_of"]
+
+    def unxz(name):
+        dst = str(tmp_path / name[:-3])
+        open(dst, "wb").write(lzma.open(os.path.join(golden_dir, name)).read())
+        return dst
+
+    files = ["-i", unxz("sam_%s_1.fa.xz" % base), "-u", unxz("sam_%s_2.fa.xz" % base)] if base.startswith("pe_") else ["-i", unxz("sam_%s.fa.xz" % base)]
+    out = str(tmp_path / "o.sam")
+    p = subprocess.run([os.path.join(root, "kit4b_amd", "k4align"), "-I", os.path.join(golden_dir, "g1.sfx"), "-o", out, "-G", "0"] + meta["args"] + files,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    got = [l for l in open(out).read().split("\n") if l and not l.startswith("@")]
+    _, want = samutil.read_sam_xz(os.path.join(golden_dir, "sam_%s.sam.xz" % case))
+    n_acc = meta["nar"]["AA"]
+    assert len(got) == len(want) and sorted(got[:n_acc]) == sorted(want[:n_acc])
+    code = lambda l: samutil.NAR_CODES.index(l.rsplit("YU:Z:", 1)[1])  # noqa: E731
+    assert [code(l) for l in got[n_acc:]] == [code(l) for l in want[n_acc:]]
+    assert sorted(got[n_acc:]) == sorted(want[n_acc:])
 
 
 @pytest.mark.gpu

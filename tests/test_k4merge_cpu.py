@@ -93,13 +93,18 @@ def test_k4merge_errors_leave_no_partial_file(tmp_path):
     assert r.returncode == 2 and not out.exists()
 
 
-def _bam_record(ref, pos, name, cigar, flag, seq_len=10):
+_NAR = ["NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"]
+
+
+def _bam_record(ref, pos, name, cigar, flag, seq_len=10, nar=None):
     import struct
 
     nm = name.encode() + b"\0"
     cig = b"".join(struct.pack("<I", (n << 4) | "MIDNSHP=X".index(op)) for n, op in cigar)
     body = struct.pack("<iiBBHHHIiii", ref, pos, len(nm), 255, 4680, len(cigar), flag, seq_len, -1, -1, 0) + nm + cig
     body += bytes((seq_len + 1) // 2) + b"\xff" * seq_len
+    if nar:
+        body += b"YUZ" + nar.encode() + b"\0"  # (-M1: a read without an accepted alignment carries its NAR)
     return struct.pack("<I", len(body)) + body
 
 
@@ -109,6 +114,8 @@ def _bam_sort_key(rec):
     ref, pos, l_name, _, _, n_cig, flag = struct.unpack_from("<iiBBHHH", rec, 4)
     ops = struct.unpack_from("<%dI" % n_cig, rec, 36 + l_name)
     first = ops[1] if (ops[0] & 15) == 4 and n_cig > 1 else ops[0]
+    if ref < 0:  # behind every sequence, by NAR code, then stream / file order
+        return (0xFFFFFFFF, _NAR.index(rec[-3:-1].decode()) if rec[-6:-3] == b"YUZ" else 20, 0, 0)
     return (ref & 0xFFFFFFFF, pos, first >> 4, 1 if flag & 0x10 else 0)
 
 
@@ -127,7 +134,8 @@ def test_k4merge_bam_record_streams(tmp_path, n_streams):
             ref = rng.choice([0, 0, 1, 2, 5, -1])
             pos = -1 if ref < 0 else rng.randrange(0, 60)  # few positions: ties everywhere
             cigar = rng.choice([[(10, "M")], [(3, "S"), (7, "M")], [(6, "M"), (100, "N"), (4, "M")], [(8, "M"), (2, "S")]])
-            recs.append(_bam_record(ref, pos, "s%d_%d" % (s, q), cigar, rng.choice([0, 16]) | (4 if ref < 0 else 0)))
+            recs.append(_bam_record(ref, pos, "s%d_%d" % (s, q), cigar, rng.choice([0, 16]) | (4 if ref < 0 else 0),
+                                    nar=rng.choice(["NL", "ML", "EN"]) if ref < 0 else None))
         recs.sort(key=_bam_sort_key)  # (stable: file order within a key)
         streams.append(recs)
         (tmp_path / ("r%d.rec" % s)).write_bytes(b"".join(recs))
@@ -143,3 +151,37 @@ def test_k4merge_bam_record_streams(tmp_path, n_streams):
     bad.write_bytes(b"".join(streams[0])[:-5])
     r = subprocess.run([EXE, "--bam-records", str(out), str(bad)], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "malformed" in r.stderr and not out.exists()
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="k4merge not built")
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_k4merge_keeps_unplaced_records_behind_and_by_nar_code(tmp_path, golden_dir, threads):
+    """Shards of a `-M1` run (`k4align -G -M1`): the alignments, then every other read as a record with RNAME '*' and its NAR in a
+    YU:Z tag, NAR codes ascending.  Merged: all alignments first (coordinate order), then the unplaced records by NAR code, within
+    a code in shard order and order in the shard."""
+    lines = lzma.open(os.path.join(golden_dir, "sam_se_s2_M1.sam.xz")).read().decode().splitlines()
+    hdr = [l for l in lines if l.startswith("@")]
+    recs = [l for l in lines if not l.startswith("@")]
+    placed = [l for l in recs if l.split("\t")[2] != "*"]
+    unplaced = [l for l in recs if l.split("\t")[2] == "*"]
+    assert len(unplaced) > 10 and len({l.rsplit("YU:Z:", 1)[1] for l in unplaced}) >= 2
+    n = 3
+    paths = []
+    for k in range(n):  # contiguous thirds of the unplaced reads (what rank slices are), alignments dealt round-robin
+        a, b = len(unplaced) * k // n, len(unplaced) * (k + 1) // n
+        part = unplaced[a:b]
+        p = tmp_path / ("s%d.sam" % k)
+        p.write_text("\n".join(hdr + placed[k::n] + part) + "\n")
+        paths.append(str(p))
+    out = tmp_path / "m.sam"
+    r = subprocess.run([EXE, "-t", threads, str(out)] + paths, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = [l for l in out.read_text().splitlines() if not l.startswith("@")]
+    assert got[:len(placed)] == placed or sorted(got[:len(placed)]) == sorted(placed)
+    assert all(l.split("\t")[2] != "*" for l in got[:len(placed)])
+    tail = got[len(placed):]
+    codes = ["NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"]
+    code = lambda l: codes.index(l.rsplit("YU:Z:", 1)[1])  # noqa: E731
+    assert [code(l) for l in tail] == sorted(code(l) for l in unplaced)
+    # stable: within a code, the order of the single file (its shards were contiguous slices in order)
+    assert tail == sorted(unplaced, key=code)
