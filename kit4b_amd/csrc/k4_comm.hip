@@ -8,7 +8,11 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <stdlib.h>
+#include <time.h>
 #include "../../include/k4comm.h"
+
+static double comm_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 
 struct k4_comm {
   ncclComm_t comm = nullptr;
@@ -118,7 +122,9 @@ extern "C" int k4_comm_init(int device, int rank, int n_ranks, const uint8_t id[
   if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) return bail(K4_ERR_NO_DEVICE);
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
+  const double t_i = comm_now();
   if (ncclCommInitRank(&c->comm, n_ranks, u, rank) != ncclSuccess) { hipStreamDestroy(c->st); return bail(K4_ERR_NO_DEVICE); }
+  if (getenv("K4_TRACE")) fprintf(stderr, "[k4 trace] rank %d: RCCL communicator of %d formed in %.2fs\n", rank, n_ranks, comm_now() - t_i);
   *out = c;
   return K4_OK;
 }
@@ -175,14 +181,19 @@ extern "C" int k4_comm_open_index(k4_comm* c, const char* sfx_path, int kmer_k, 
   DevBuf d_seq, d_sa;
   CK_HIP(c, hipMalloc(&d_seq.p, m.n + 64));
   CK_HIP(c, hipMalloc(&d_sa.p, m.n * m.el + 16));
-  if (c->rank == 0) {  // the mapped file goes up through pinned pieces filled by several threads (k4_open's own way)
+  const bool trace = getenv("K4_TRACE") != nullptr;
+  const double t_u = comm_now();
+  if (c->rank == 0) {  // the mapped file goes up from its registered pages (k4_open's own way)
     int urc = k4_upload_pageable(c->device, d_seq.p, f.seq, m.n);
     if (urc == K4_OK) urc = k4_upload_pageable(c->device, d_sa.p, f.sa, m.n * m.el);
     if (urc != K4_OK) return fail(c, urc, "%s", k4_global_error());  // (the peers wait in the exchange: the caller's job to end them)
+    if (trace) fprintf(stderr, "[k4 trace] rank 0: %.2f GB of the index file on the device in %.2fs\n", (m.n + m.n * m.el) / 1e9, comm_now() - t_u);
   }
+  const double t_x = comm_now();
   int rc = bcast_all_links(c, (uint8_t*)d_seq.p, m.n);
   if (rc == K4_OK) rc = bcast_all_links(c, (uint8_t*)d_sa.p, m.n * m.el);
   if (rc != K4_OK) return rc;
+  if (trace) fprintf(stderr, "[k4 trace] rank %d: exchange over the links done in %.2fs\n", c->rank, comm_now() - t_x);
   // the suffix array stays where it arrived (adopted; released with the index), the byte sequence is only the source of the
   // packed form
   rc = k4_open_device(m.n, m.el, d_seq.p, d_sa.p, 1, m.ne, ents.data(), m.dataset, c->device, kmer_k, out);

@@ -59,15 +59,19 @@ res = {"workload": "C2: %d x 100 bp FASTQ reads (%.1f GB) vs 3 Gbp .sfx (%.1f GB
 exe = os.path.join(ROOT, "kit4b_amd", "k4align")
 sams = {}
 only = os.environ.get("K4_E2E_TAGS", "").split(",") if os.environ.get("K4_E2E_TAGS") else None  # a subset of the runs below
-for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("pipelined_t16", ["-t", "16"]), ("serial_r01", ["-Z"]), ("bam_z6_t16", ["-t", "16"]), ("bam_z1_t16", ["-t", "16", "-z", "1"]), ("snp_p5", ["-p", "5"])):
+for tag, extra in (("pipelined", []), ("pipelined_t8", ["-t", "8"]), ("pipelined_t16", ["-t", "16"]), ("serial_r01", ["-Z"]), ("bam_z6_t16", ["-t", "16"]), ("bam_z1_t16", ["-t", "16", "-z", "1"]), ("snp_p5", ["-p", "5"]),
+                   ("rank1_sam", ["-G", "0", "-t", "16"]), ("bam_rank1_z6_t16", ["-G", "0", "-t", "16"])):  # the -G path with one rank: shard + merge
     if only and tag not in only:
         continue
     sam = os.path.join(tmp, tag + (".bam" if tag.startswith("bam") else ".sam"))
     t0 = time.time()
-    p = subprocess.run([exe, "-I", sfx, "-i", fq, "-o", sam, "-s2"] + extra, capture_output=True, text=True)
+    p = subprocess.run([exe, "-I", sfx, "-i", fq, "-o", sam, "-s2"] + extra, capture_output=True, text=True,
+                       env=dict(os.environ, K4_TRACE="1") if "-G" in extra else None)
     wall = time.time() - t0
-    last = [l for l in p.stderr.splitlines() if "alignments written" in l or "alignments reported to" in l]
+    last = [l for l in p.stderr.splitlines() if "alignments written" in l or "alignments reported to" in l or "GPUs written to" in l]
     res[tag] = {"rc": p.returncode, "wall_s": wall, "report": last[-1] if last else p.stderr[-500:], "sam_GB": os.path.getsize(sam) / 1e9 if os.path.exists(sam) else None}
+    if "-G" in extra:  # what the rank itself reported, with the stage trace
+        res[tag]["rank_stderr"] = [l for l in p.stderr.splitlines() if l.startswith("[k4 trace]") or "rank 0" in l or "index '" in l][-24:]
     import re
     m = re.search(r"index ([\d.]+)s", res[tag]["report"])
     if m:
