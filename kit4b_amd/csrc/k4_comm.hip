@@ -7,6 +7,7 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 #include <stdlib.h>
 #include <time.h>
@@ -19,9 +20,19 @@ struct k4_comm {
   hipStream_t st = nullptr;
   int device = 0, rank = 0, n = 1;
   std::string err;
+  // ncclCommInitRank takes seconds (5 s for ONE rank on the test box) and needs nothing the caller has: it runs on a thread of its
+  // own from k4_comm_init on and is joined by the first call that talks to the peers -- rank 0 brings the index file up meanwhile
+  std::thread former;
+  int form_rc = K4_OK;
 };
 
 namespace {
+
+int comm_ready(k4_comm* c) {  // the communicator is formed (or could not be)
+  if (c->former.joinable()) c->former.join();
+  if (c->form_rc != K4_OK && c->err.empty()) c->err = "ncclCommInitRank failed";
+  return c->form_rc;
+}
 
 int fail(k4_comm* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -122,9 +133,11 @@ extern "C" int k4_comm_init(int device, int rank, int n_ranks, const uint8_t id[
   if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) return bail(K4_ERR_NO_DEVICE);
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
-  const double t_i = comm_now();
-  if (ncclCommInitRank(&c->comm, n_ranks, u, rank) != ncclSuccess) { hipStreamDestroy(c->st); return bail(K4_ERR_NO_DEVICE); }
-  if (getenv("K4_TRACE")) fprintf(stderr, "[k4 trace] rank %d: RCCL communicator of %d formed in %.2fs\n", rank, n_ranks, comm_now() - t_i);
+  c->former = std::thread([c, u]() {
+    const double t_i = comm_now();
+    if (hipSetDevice(c->device) != hipSuccess || ncclCommInitRank(&c->comm, c->n, u, c->rank) != ncclSuccess) { c->form_rc = K4_ERR_NO_DEVICE; return; }
+    if (getenv("K4_TRACE")) fprintf(stderr, "[k4 trace] rank %d: RCCL communicator of %d formed in %.2fs\n", c->rank, c->n, comm_now() - t_i);
+  });
   *out = c;
   return K4_OK;
 }
@@ -150,12 +163,27 @@ extern "C" int k4_comm_open_index(k4_comm* c, const char* sfx_path, int kmer_k, 
     } else
       c->err = k4_global_error();
   }
-  // geometry first (a small ncclBroadcast), then the entries table, then the two big arrays over every link
   struct Unmap {  // rank 0's mapping: released on every way out
     k4_sfx_file* f;
     bool on;
     ~Unmap() { if (on) k4_sfx_unmap(f); }
   } unmap{&f, c->rank == 0 && m.rc == K4_OK};
+  // rank 0: the two big arrays go up to the device now, while the communicator is still being formed
+  DevBuf d_seq, d_sa;
+  const bool trace = getenv("K4_TRACE") != nullptr;
+  if (c->rank == 0 && m.rc == K4_OK) {
+    const double t_u = comm_now();
+    if (hipMalloc(&d_seq.p, m.n + 64) != hipSuccess || hipMalloc(&d_sa.p, m.n * m.el + 16) != hipSuccess) m.rc = K4_ERR_MEM;
+    if (m.rc == K4_OK) m.rc = k4_upload_pageable(c->device, d_seq.p, f.seq, m.n);
+    if (m.rc == K4_OK) m.rc = k4_upload_pageable(c->device, d_sa.p, f.sa, m.n * m.el);
+    if (m.rc != K4_OK) c->err = k4_global_error();
+    else if (trace) fprintf(stderr, "[k4 trace] rank 0: %.2f GB of the index file on the device in %.2fs\n", (m.n + m.n * m.el) / 1e9, comm_now() - t_u);
+  }
+  {
+    const int frc = comm_ready(c);
+    if (frc != K4_OK) return frc;
+  }
+  // geometry first (a small ncclBroadcast), then the entries table, then the two big arrays over every link
   {
     DevBuf d_m;
     CK_HIP(c, hipMalloc(&d_m.p, sizeof(Meta)));
@@ -178,16 +206,9 @@ extern "C" int k4_comm_open_index(k4_comm* c, const char* sfx_path, int kmer_k, 
     CK_HIP(c, hipStreamSynchronize(c->st));
     CK_HIP(c, hipMemcpy(ents.data(), d_e.p, eb, hipMemcpyDeviceToHost));
   }
-  DevBuf d_seq, d_sa;
-  CK_HIP(c, hipMalloc(&d_seq.p, m.n + 64));
-  CK_HIP(c, hipMalloc(&d_sa.p, m.n * m.el + 16));
-  const bool trace = getenv("K4_TRACE") != nullptr;
-  const double t_u = comm_now();
-  if (c->rank == 0) {  // the mapped file goes up from its registered pages (k4_open's own way)
-    int urc = k4_upload_pageable(c->device, d_seq.p, f.seq, m.n);
-    if (urc == K4_OK) urc = k4_upload_pageable(c->device, d_sa.p, f.sa, m.n * m.el);
-    if (urc != K4_OK) return fail(c, urc, "%s", k4_global_error());  // (the peers wait in the exchange: the caller's job to end them)
-    if (trace) fprintf(stderr, "[k4 trace] rank 0: %.2f GB of the index file on the device in %.2fs\n", (m.n + m.n * m.el) / 1e9, comm_now() - t_u);
+  if (c->rank != 0) {
+    CK_HIP(c, hipMalloc(&d_seq.p, m.n + 64));
+    CK_HIP(c, hipMalloc(&d_sa.p, m.n * m.el + 16));
   }
   const double t_x = comm_now();
   int rc = bcast_all_links(c, (uint8_t*)d_seq.p, m.n);
@@ -205,6 +226,7 @@ extern "C" int k4_comm_open_index(k4_comm* c, const char* sfx_path, int kmer_k, 
 
 extern "C" int k4_comm_allreduce_sum_u64(k4_comm* c, uint64_t* vals, int n) {
   if (!c || !vals || n < 1) return K4_ERR_PARAMS;
+  if (const int frc = comm_ready(c)) return frc;
   CK_HIP(c, hipSetDevice(c->device));
   DevBuf d;
   CK_HIP(c, hipMalloc(&d.p, (size_t)n * 8));
@@ -222,6 +244,7 @@ extern "C" int k4_comm_barrier(k4_comm* c) {
 
 extern "C" void k4_comm_close(k4_comm* c) {
   if (!c) return;
+  (void)comm_ready(c);
   hipSetDevice(c->device);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->st) (void)hipStreamDestroy(c->st);
