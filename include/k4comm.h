@@ -35,6 +35,9 @@ typedef struct { int32_t phase, src, dst; uint64_t off, len; } k4_comm_xfer;
 int k4_comm_bcast_schedule(int n_ranks, uint64_t bytes, k4_comm_xfer* out, int cap);
 
 int k4_comm_unique_id(uint8_t id[K4_COMM_ID_BYTES]);  /* one rank calls it and hands the bytes to the others (pipe, file, shared memory) */
+/* Returns at once: ncclCommInitRank (seconds) runs on a thread of the library and is joined by the first call that talks to the
+ * peers (k4_comm_open_index's first broadcast, k4_comm_allreduce_sum_u64, k4_comm_close) -- a communicator that could not be
+ * formed is reported there.  Rank 0 maps and uploads the index file meanwhile. */
 int k4_comm_init(int device, int rank, int n_ranks, const uint8_t id[K4_COMM_ID_BYTES], k4_comm** out);
 int k4_comm_rank(const k4_comm* c);
 int k4_comm_size(const k4_comm* c);
